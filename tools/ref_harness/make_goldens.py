@@ -9,7 +9,8 @@ decode results) — never reference source.  RNG-free settings: dropout 0, layer
 Fixtures
   chimera_tiny.npz   s2t_transformer_w2v2_interlingua + triplet_st_mt_contrastive (config 4, tiny dims)
   s2t_w2v2_tiny.npz  s2t_transformer_w2v2 + label_smoothed_cross_entropy          (config 2/3, tiny dims)
-  optim_tiny.npz     one trainer-equivalent update on the chimera model (multiply_grads, clip, Adam, inverse_sqrt)
+  decode_tiny.npz    the chimera model after fitting the sample: greedy / beam-5 hypotheses from SequenceGenerator
+  optim_tiny.npz     two trainer-equivalent updates on the chimera model (multiply_grads, clip, Adam, inverse_sqrt)
 """
 import argparse
 import math
@@ -223,7 +224,7 @@ def gen_chimera(tmp):
         "w2v_cnn": "encoder.wav2vec_model.feature_extractor",
         "w2v_ln": "encoder.wav2vec_model.layer_norm",
         "w2v_proj": "encoder.wav2vec_model.post_extract_proj",
-        "w2v_out": "encoder.wav2vec_model",
+        "w2v_out": "encoder.wav2vec_model.encoder",
         "subsample": "encoder.subsample",
         "enc_layer_last": "encoder.transformer_layers.%d" % (args.encoder_layers - 1),
         "enc_ln": "encoder.layer_norm",
