@@ -1,0 +1,493 @@
+// attention.hip — flash-style fused attention for gfx950: scores never reach HBM.
+//
+// Replaces F.multi_head_attention_forward / the in-tree bmm-softmax-bmm branch of
+// fairseq/modules/multihead_attention.py:155-187,326-361 (softmax in fp32, key padding -> -inf).
+//
+// Forward (per wave: 32 query rows, KV tiles of 64 keys staged through LDS, shared by the 4 waves):
+//   S^T[key][q] = K Q^T      (A = K fragment from LDS, B = Q fragment held in registers)
+//   online softmax per query: every lane owns ONE query column (q = lane&31) -> row max / sum are
+//   lane-local + one exchange with lane^32 (the "swapped QK^T" idiom).
+//   O^T[d][q] += V^T P^T     (A = V^T gathered from the [key][d] LDS image, B = P straight from the
+//   S accumulator registers: the MFMA k-slot <-> key permutation of the C layout is applied to the
+//   V gather instead of shuffling P).
+// Backward = two kernels that both recompute P from (Q,K,lse):
+//   dQ kernel : grid over query blocks, loops KV tiles  -> dQ
+//   dKV kernel: grid over key blocks,   loops Q tiles   -> dK, dV   (no atomics, deterministic)
+// plus a row-wise delta = sum_d dO*O pre-pass.
+// dtype: bf16 (v_mfma_f32_32x32x16_bf16, P rounded to bf16 like the reference's fp16/bf16 path) or
+// f32 (v_mfma_f32_32x32x2_f32, exact-fp32 products) from one source via Frag<T>.
+#include "cst_common.h"
+
+namespace {
+
+constexpr int NW = 4;          // waves per workgroup
+constexpr int QB = 32;         // rows per wave
+constexpr int KT = 64;         // keys (fwd/dQ) or queries (dKV) per LDS tile
+
+struct AttnParams {
+  int64_t B, H, Tq, Tk;
+  const void *Q, *K, *V; void* O;
+  int64_t q_sb, q_sh, q_st, k_sb, k_sh, k_st, v_sb, v_sh, v_st, o_sb, o_sh, o_st;
+  float* lse;
+  const uint8_t* kpm; int64_t kpm_stride;
+  int causal;
+  float scale;
+  const void* dO; int64_t do_sb, do_sh, do_st;
+  void *dQ, *dK, *dV;
+  int64_t dq_sb, dq_sh, dq_st, dk_sb, dk_sh, dk_st, dv_sb, dv_sh, dv_st;
+  float* delta;
+};
+
+// the row (within a 32-row MFMA tile) that k-slot j of half-wave `hi` holds for the 16-row step t
+__device__ __forceinline__ int slot_row(int t, int j, int hi) { return 16 * t + (j & 3) + 8 * (j >> 2) + 4 * hi; }
+
+// cooperative copy of a [rows<=KT][D] tile (row stride `st` in global) into LDS [KT][D+VEC]; rows >= nrows zero-filled
+template <typename T, int D>
+__device__ __forceinline__ void load_tile(T* lds, const T* g, int64_t st, int nrows, int tid) {
+  constexpr int VEC = DT<T>::VEC, LD = D + VEC, VPR = D / VEC;
+  for (int v = tid; v < KT * VPR; v += NW * 64) {
+    const int r = v / VPR, c = (v % VPR) * VEC;
+    u32x4 x = {0, 0, 0, 0};
+    if (r < nrows) x = *reinterpret_cast<const u32x4*>(g + (int64_t)r * st + c);
+    *reinterpret_cast<u32x4*>(lds + r * LD + c) = x;
+  }
+}
+
+// registers: D/16 fragments of one row (row = lane&31) of a [T][D] matrix in global memory
+template <typename T, int D>
+__device__ __forceinline__ void load_row_frags(Frag<T> (&f)[D / 16], const T* g, int64_t st, int row, int nrows, int lane) {
+  const int lk = 8 * (lane >> 5);
+#pragma unroll
+  for (int kk = 0; kk < D / 16; ++kk) {
+    if (row < nrows) frag_load_contig(f[kk], g + (int64_t)row * st + kk * 16 + lk);
+    else {
+      float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      frag_from_f32(f[kk], z);
+    }
+  }
+}
+
+// A fragment "transposed": row = d (lane&31 + d0), the 8 k-slots are tile rows slot_row(t, j, hi)
+template <typename T, int LD>
+__device__ __forceinline__ void frag_gather_rows(Frag<float>& f, const float* lds, int d, int t, int hi, int rbase) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = lds[(rbase + slot_row(t, j, hi)) * LD + d];
+}
+template <typename T, int LD>
+__device__ __forceinline__ void frag_gather_rows(Frag<bf16_t>& f, const bf16_t* lds, int d, int t, int hi, int rbase) {
+  u16x8 x;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const unsigned short*>(lds + (rbase + slot_row(t, j, hi)) * LD + d);
+  f.v = __builtin_bit_cast(bf16x8, x);
+}
+
+// store acc (rows = d = d0 + acc_row(r), col = this lane's token) as 4-element runs along d
+template <typename T>
+__device__ __forceinline__ void store_dcol(T* g, const f32x16& acc, int d0, int lane, float mul) {
+  const int hi = lane >> 5;
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) {
+    T* p = g + d0 + 8 * gq + 4 * hi;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) DT<T>::st(p + e, acc[gq * 4 + e] * mul);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
+  constexpr int VEC = DT<T>::VEC, LD = D + VEC;
+  __shared__ __attribute__((aligned(16))) T sK[KT * LD];
+  __shared__ __attribute__((aligned(16))) T sV[KT * LD];
+  __shared__ uint8_t sM[KT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  const int64_t b = blockIdx.z, h = blockIdx.y;
+  const int q_blk0 = blockIdx.x * (NW * QB);
+  const int q = q_blk0 + wave * QB + (lane & 31);
+  const T* Qg = (const T*)p.Q + b * p.q_sb + h * p.q_sh;
+  const T* Kg = (const T*)p.K + b * p.k_sb + h * p.k_sh;
+  const T* Vg = (const T*)p.V + b * p.v_sb + h * p.v_sh;
+  const int64_t cshift = p.Tk - p.Tq;  // causal: key j visible to query i iff j <= i + cshift
+
+  Frag<T> fq[D / 16];
+  load_row_frags<T, D>(fq, Qg, p.q_st, q, (int)p.Tq, lane);
+
+  f32x16 o[D / 32];
+#pragma unroll
+  for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.0f;
+  float m_run = -INFINITY, l_run = 0.0f;
+
+  int64_t kend = p.Tk;
+  if (p.causal) {
+    const int64_t last = (int64_t)q_blk0 + NW * QB - 1 + cshift + 1;
+    if (last < kend) kend = last;
+  }
+  for (int64_t j0 = 0; j0 < kend; j0 += KT) {
+    const int nk = (int)((p.Tk - j0 < KT) ? (p.Tk - j0) : KT);
+    __syncthreads();
+    load_tile<T, D>(sK, Kg + j0 * p.k_st, p.k_st, nk, tid);
+    load_tile<T, D>(sV, Vg + j0 * p.v_st, p.v_st, nk, tid);
+    if (tid < KT) sM[tid] = (tid >= nk) ? 1 : (p.kpm ? p.kpm[b * p.kpm_stride + j0 + tid] : 0);
+    __syncthreads();
+
+    f32x16 s[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[ks][r] = 0.0f;
+#pragma unroll
+      for (int kk = 0; kk < D / 16; ++kk) {
+        Frag<T> fk;
+        frag_load_contig(fk, sK + (ks * 32 + (lane & 31)) * LD + kk * 16 + 8 * hi);
+        mma16(s[ks], fk, fq[kk]);
+      }
+    }
+    float mt = -INFINITY;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kr = ks * 32 + acc_row(r, lane);
+        float v = s[ks][r] * p.scale;
+        const bool masked = sM[kr] || (p.causal && (j0 + kr > (int64_t)q + cshift));
+        v = masked ? -INFINITY : v;
+        s[ks][r] = v;
+        mt = fmaxf(mt, v);
+      }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    float alpha = 1.0f;
+    if (m_new != -INFINITY) {
+      alpha = __expf(m_run - m_new);  // m_run = -inf -> 0
+      float ls = 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = __expf(s[ks][r] - m_new);
+          s[ks][r] = e;
+          ls += e;
+        }
+      l_run = l_run * alpha + ls;
+      m_run = m_new;
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[ks][r] = 0.0f;
+    }
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    // O^T += V^T P^T
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        Frag<T> fp;
+        float pv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pv[j] = s[ks][8 * t + j];
+        frag_from_f32(fp, pv);
+#pragma unroll
+        for (int dt = 0; dt < D / 32; ++dt) {
+          Frag<T> fv;
+          frag_gather_rows<T, LD>(fv, sV, dt * 32 + (lane & 31), t, hi, ks * 32);
+          mma16(o[dt], fv, fp);
+        }
+      }
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (q < p.Tq) {
+    const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+    T* Og = (T*)p.O + b * p.o_sb + h * p.o_sh + (int64_t)q * p.o_st;
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt) store_dcol<T>(Og, o[dt], dt * 32, lane, inv);
+    if (hi == 0) p.lse[(b * p.H + h) * p.Tq + q] = l_tot > 0.0f ? m_run + __logf(l_tot) : -INFINITY;
+  }
+}
+
+// delta[b,h,q] = sum_d dO*O
+template <typename T, int D>
+__global__ void attn_delta_kernel(AttnParams p) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = p.B * p.H * p.Tq;
+  if (row >= total) return;
+  const int64_t q = row % p.Tq, h = (row / p.Tq) % p.H, b = row / (p.Tq * p.H);
+  const T* o = (const T*)p.O + b * p.o_sb + h * p.o_sh + q * p.o_st;
+  const T* g = (const T*)p.dO + b * p.do_sb + h * p.do_sh + q * p.do_st;
+  float acc = 0.0f;
+#pragma unroll
+  for (int d = 0; d < D; d += 8) {
+    float a[8], c[8];
+    load8(o + d, a);
+    load8(g + d, c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc += a[e] * c[e];
+  }
+  p.delta[row] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dQ: per wave 32 queries (lane-local query column), loop over KV tiles.
+template <typename T, int D>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnParams p) {
+  constexpr int VEC = DT<T>::VEC, LD = D + VEC;
+  __shared__ __attribute__((aligned(16))) T sK[KT * LD];
+  __shared__ __attribute__((aligned(16))) T sV[KT * LD];
+  __shared__ uint8_t sM[KT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  const int64_t b = blockIdx.z, h = blockIdx.y;
+  const int q_blk0 = blockIdx.x * (NW * QB);
+  const int q = q_blk0 + wave * QB + (lane & 31);
+  const T* Qg = (const T*)p.Q + b * p.q_sb + h * p.q_sh;
+  const T* Kg = (const T*)p.K + b * p.k_sb + h * p.k_sh;
+  const T* Vg = (const T*)p.V + b * p.v_sb + h * p.v_sh;
+  const T* dOg = (const T*)p.dO + b * p.do_sb + h * p.do_sh;
+  const int64_t cshift = p.Tk - p.Tq;
+
+  Frag<T> fq[D / 16], fdo[D / 16];
+  load_row_frags<T, D>(fq, Qg, p.q_st, q, (int)p.Tq, lane);
+  load_row_frags<T, D>(fdo, dOg, p.do_st, q, (int)p.Tq, lane);
+  float lse = -INFINITY, dlt = 0.0f;
+  if (q < p.Tq) {
+    lse = p.lse[(b * p.H + h) * p.Tq + q];
+    dlt = p.delta[(b * p.H + h) * p.Tq + q];
+  }
+  f32x16 dq[D / 32];
+#pragma unroll
+  for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[dt][r] = 0.0f;
+
+  int64_t kend = p.Tk;
+  if (p.causal) {
+    const int64_t last = (int64_t)q_blk0 + NW * QB + cshift;
+    if (last < kend) kend = last;
+  }
+  for (int64_t j0 = 0; j0 < kend; j0 += KT) {
+    const int nk = (int)((p.Tk - j0 < KT) ? (p.Tk - j0) : KT);
+    __syncthreads();
+    load_tile<T, D>(sK, Kg + j0 * p.k_st, p.k_st, nk, tid);
+    load_tile<T, D>(sV, Vg + j0 * p.v_st, p.v_st, nk, tid);
+    if (tid < KT) sM[tid] = (tid >= nk) ? 1 : (p.kpm ? p.kpm[b * p.kpm_stride + j0 + tid] : 0);
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
+#pragma unroll
+      for (int kk = 0; kk < D / 16; ++kk) {
+        Frag<T> fk, fv;
+        frag_load_contig(fk, sK + (ks * 32 + (lane & 31)) * LD + kk * 16 + 8 * hi);
+        frag_load_contig(fv, sV + (ks * 32 + (lane & 31)) * LD + kk * 16 + 8 * hi);
+        mma16(s, fk, fq[kk]);     // S^T[key][q]
+        mma16(dp, fv, fdo[kk]);   // dP^T[key][q] = V dO^T
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kr = ks * 32 + acc_row(r, lane);
+        const bool masked = sM[kr] || (p.causal && (j0 + kr > (int64_t)q + cshift)) || lse == -INFINITY;
+        const float pr = masked ? 0.0f : __expf(s[r] * p.scale - lse);
+        s[r] = pr * (dp[r] - dlt);  // dS^T (scale folded in at the end)
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        Frag<T> fds;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = s[8 * t + j];
+        frag_from_f32(fds, x);
+#pragma unroll
+        for (int dt = 0; dt < D / 32; ++dt) {
+          Frag<T> fkt;
+          frag_gather_rows<T, LD>(fkt, sK, dt * 32 + (lane & 31), t, hi, ks * 32);
+          mma16(dq[dt], fkt, fds);  // dQ^T[d][q] += K^T dS^T
+        }
+      }
+    }
+  }
+  if (q < p.Tq) {
+    T* g = (T*)p.dQ + b * p.dq_sb + h * p.dq_sh + (int64_t)q * p.dq_st;
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt) store_dcol<T>(g, dq[dt], dt * 32, lane, p.scale);
+  }
+}
+
+// dK,dV: per wave 32 keys (lane-local key column), loop over Q tiles of 64 queries.
+template <typename T, int D>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
+  constexpr int VEC = DT<T>::VEC, LD = D + VEC;
+  __shared__ __attribute__((aligned(16))) T sQ[KT * LD];
+  __shared__ __attribute__((aligned(16))) T sdO[KT * LD];
+  __shared__ float sL[KT], sD[KT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  const int64_t b = blockIdx.z, h = blockIdx.y;
+  const int k_blk0 = blockIdx.x * (NW * QB);
+  const int key = k_blk0 + wave * QB + (lane & 31);
+  const T* Qg = (const T*)p.Q + b * p.q_sb + h * p.q_sh;
+  const T* Kg = (const T*)p.K + b * p.k_sb + h * p.k_sh;
+  const T* Vg = (const T*)p.V + b * p.v_sb + h * p.v_sh;
+  const T* dOg = (const T*)p.dO + b * p.do_sb + h * p.do_sh;
+  const int64_t cshift = p.Tk - p.Tq;
+
+  Frag<T> fk[D / 16], fv[D / 16];
+  load_row_frags<T, D>(fk, Kg, p.k_st, key, (int)p.Tk, lane);
+  load_row_frags<T, D>(fv, Vg, p.v_st, key, (int)p.Tk, lane);
+  const bool key_masked = key >= p.Tk || (p.kpm && p.kpm[b * p.kpm_stride + key]);
+
+  f32x16 dk[D / 32], dv[D / 32];
+#pragma unroll
+  for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.0f; dv[dt][r] = 0.0f; }
+
+  int64_t qstart = 0;
+  if (p.causal) {
+    qstart = (int64_t)k_blk0 - cshift;  // first query that can see the first key of this block
+    if (qstart < 0) qstart = 0;
+    qstart = (qstart / KT) * KT;
+  }
+  for (int64_t i0 = qstart; i0 < p.Tq; i0 += KT) {
+    const int nq = (int)((p.Tq - i0 < KT) ? (p.Tq - i0) : KT);
+    __syncthreads();
+    load_tile<T, D>(sQ, Qg + i0 * p.q_st, p.q_st, nq, tid);
+    load_tile<T, D>(sdO, dOg + i0 * p.do_st, p.do_st, nq, tid);
+    if (tid < KT) {
+      sL[tid] = tid < nq ? p.lse[(b * p.H + h) * p.Tq + i0 + tid] : -INFINITY;
+      sD[tid] = tid < nq ? p.delta[(b * p.H + h) * p.Tq + i0 + tid] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
+#pragma unroll
+      for (int kk = 0; kk < D / 16; ++kk) {
+        Frag<T> fqr, fdor;
+        frag_load_contig(fqr, sQ + (qs * 32 + (lane & 31)) * LD + kk * 16 + 8 * hi);
+        frag_load_contig(fdor, sdO + (qs * 32 + (lane & 31)) * LD + kk * 16 + 8 * hi);
+        mma16(s, fqr, fk[kk]);     // S[q][key]
+        mma16(dp, fdor, fv[kk]);   // dP[q][key] = dO V^T
+      }
+      f32x16 pr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qr = qs * 32 + acc_row(r, lane);
+        const float l = sL[qr];
+        const bool masked = key_masked || l == -INFINITY || (p.causal && ((int64_t)key > i0 + qr + cshift));
+        const float e = masked ? 0.0f : __expf(s[r] * p.scale - l);
+        pr[r] = e;
+        s[r] = e * (dp[r] - sD[qr]);  // dS[q][key]
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        Frag<T> fp, fds;
+        float x[8], y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { x[j] = pr[8 * t + j]; y[j] = s[8 * t + j]; }
+        frag_from_f32(fp, x);
+        frag_from_f32(fds, y);
+#pragma unroll
+        for (int dt = 0; dt < D / 32; ++dt) {
+          Frag<T> fdot, fqt;
+          frag_gather_rows<T, LD>(fdot, sdO, dt * 32 + (lane & 31), t, hi, qs * 32);
+          frag_gather_rows<T, LD>(fqt, sQ, dt * 32 + (lane & 31), t, hi, qs * 32);
+          mma16(dv[dt], fdot, fp);   // dV^T[d][key] += dO^T P
+          mma16(dk[dt], fqt, fds);   // dK^T[d][key] += Q^T dS
+        }
+      }
+    }
+  }
+  if (key < p.Tk) {
+    T* gk = (T*)p.dK + b * p.dk_sb + h * p.dk_sh + (int64_t)key * p.dk_st;
+    T* gv = (T*)p.dV + b * p.dv_sb + h * p.dv_sh + (int64_t)key * p.dv_st;
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt) {
+      store_dcol<T>(gk, dk[dt], dt * 32, lane, p.scale);
+      store_dcol<T>(gv, dv[dt], dt * 32, lane, 1.0f);
+    }
+  }
+}
+
+int fill_params(const cst_attn_desc* d, AttnParams& p, bool bwd) {
+  CST_REQUIRE(d, "cst_attn: null descriptor");
+  CST_REQUIRE(d->dtype == CST_F32 || d->dtype == CST_BF16, "cst_attn: bad dtype %d", d->dtype);
+  CST_REQUIRE(d->D == 32 || d->D == 64, "cst_attn: head dim %lld not in {32,64}", (long long)d->D);
+  CST_REQUIRE(d->B > 0 && d->H > 0 && d->Tq > 0 && d->Tk > 0, "cst_attn: empty problem");
+  CST_REQUIRE(d->Q && d->K && d->V && d->O && d->lse, "cst_attn: null tensor");
+  CST_REQUIRE(d->H < 65536 && d->B < 65536, "cst_attn: B/H too large for the grid");
+  const int vec = d->dtype == CST_BF16 ? 8 : 4;
+  const int64_t strides[] = {d->q_sb, d->q_sh, d->q_st, d->k_sb, d->k_sh, d->k_st, d->v_sb, d->v_sh, d->v_st};
+  for (int64_t s : strides) CST_REQUIRE(s % vec == 0, "cst_attn: strides must be multiples of %d elements", vec);
+  CST_REQUIRE(((uintptr_t)d->Q % 16 == 0) && ((uintptr_t)d->K % 16 == 0) && ((uintptr_t)d->V % 16 == 0), "cst_attn: Q/K/V must be 16-byte aligned");
+  p.B = d->B; p.H = d->H; p.Tq = d->Tq; p.Tk = d->Tk;
+  p.Q = d->Q; p.K = d->K; p.V = d->V; p.O = d->O;
+  p.q_sb = d->q_sb; p.q_sh = d->q_sh; p.q_st = d->q_st;
+  p.k_sb = d->k_sb; p.k_sh = d->k_sh; p.k_st = d->k_st;
+  p.v_sb = d->v_sb; p.v_sh = d->v_sh; p.v_st = d->v_st;
+  p.o_sb = d->o_sb; p.o_sh = d->o_sh; p.o_st = d->o_st;
+  p.lse = d->lse; p.kpm = d->key_padding_mask; p.kpm_stride = d->kpm_stride;
+  p.causal = d->causal; p.scale = d->scale;
+  p.dO = d->dO; p.do_sb = d->do_sb; p.do_sh = d->do_sh; p.do_st = d->do_st;
+  p.dQ = d->dQ; p.dK = d->dK; p.dV = d->dV;
+  p.dq_sb = d->dq_sb; p.dq_sh = d->dq_sh; p.dq_st = d->dq_st;
+  p.dk_sb = d->dk_sb; p.dk_sh = d->dk_sh; p.dk_st = d->dk_st;
+  p.dv_sb = d->dv_sb; p.dv_sh = d->dv_sh; p.dv_st = d->dv_st;
+  p.delta = d->delta;
+  if (bwd) {
+    CST_REQUIRE(d->dO && d->dQ && d->dK && d->dV && d->delta, "cst_attn_bwd: null gradient tensor");
+    CST_REQUIRE(d->do_sb % vec == 0 && d->do_sh % vec == 0 && d->do_st % vec == 0 && d->o_st % vec == 0 && d->o_sb % vec == 0 && d->o_sh % vec == 0,
+                "cst_attn_bwd: dO/O strides must be multiples of %d", vec);
+    CST_REQUIRE(((uintptr_t)d->dO % 16 == 0) && ((uintptr_t)d->O % 16 == 0), "cst_attn_bwd: dO/O must be 16-byte aligned");
+  }
+  return CST_OK;
+}
+
+double attn_flops(const cst_attn_desc* d, double gemms) {
+  double pairs = (double)d->Tq * (double)d->Tk;
+  if (d->causal) pairs *= 0.5;
+  return gemms * 2.0 * pairs * (double)d->D * (double)d->B * (double)d->H;
+}
+
+}  // namespace
+
+extern "C" int cst_attn_fwd(const cst_attn_desc* d, cst_stream stream) {
+  AttnParams p;
+  int rc = fill_params(d, p, false);
+  if (rc != CST_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)cst_ceil_div(d->Tq, NW * QB), (unsigned)d->H, (unsigned)d->B);
+  CstProfScope prof(CST_K_ATTN_FWD, s, attn_flops(d, 2.0), 0.0);
+#define CST_FWD(T, DD) hipLaunchKernelGGL((attn_fwd_kernel<T, DD>), grid, dim3(NW * 64), 0, s, p)
+  if (d->dtype == CST_BF16) { if (d->D == 64) CST_FWD(bf16_t, 64); else CST_FWD(bf16_t, 32); }
+  else { if (d->D == 64) CST_FWD(float, 64); else CST_FWD(float, 32); }
+#undef CST_FWD
+  return cst_check_launch("cst_attn_fwd");
+}
+
+extern "C" int cst_attn_bwd(const cst_attn_desc* d, cst_stream stream) {
+  AttnParams p;
+  int rc = fill_params(d, p, true);
+  if (rc != CST_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  CstProfScope prof(CST_K_ATTN_BWD, s, attn_flops(d, 5.0), 0.0);
+  const int64_t rows = d->B * d->H * d->Tq;
+  dim3 gq((unsigned)cst_ceil_div(d->Tq, NW * QB), (unsigned)d->H, (unsigned)d->B);
+  dim3 gk((unsigned)cst_ceil_div(d->Tk, NW * QB), (unsigned)d->H, (unsigned)d->B);
+#define CST_BWD(T, DD)                                                                                     \
+  do {                                                                                                     \
+    hipLaunchKernelGGL((attn_delta_kernel<T, DD>), dim3((unsigned)cst_ceil_div(rows, 256)), dim3(256), 0, s, p); \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DD>), gq, dim3(NW * 64), 0, s, p);                            \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DD>), gk, dim3(NW * 64), 0, s, p);                           \
+  } while (0)
+  if (d->dtype == CST_BF16) { if (d->D == 64) CST_BWD(bf16_t, 64); else CST_BWD(bf16_t, 32); }
+  else { if (d->D == 64) CST_BWD(float, 64); else CST_BWD(float, 32); }
+#undef CST_BWD
+  return cst_check_launch("cst_attn_bwd");
+}

@@ -1,0 +1,292 @@
+// conv0.hip — wav2vec2 conv layer 0 (Cin = 1, k = 10, stride 5) fused with GroupNorm(C groups,
+// fp32 statistics) and GELU.  Replaces Conv1d + Fp32GroupNorm + GELU at
+// fairseq/models/wav2vec/wav2vec2.py:697-753 (layer 0) / modules/fp32_group_norm.py:13-25.
+//
+// HBM-bound: the op's floor is "read the wave once, write y once" (512 x L0 outputs per
+// utterance, 98 MB in bf16 for 30 s).  Two tricks keep it at that floor:
+//  (1) GroupNorm statistics WITHOUT materialising the conv output: u[c,t] = sum_j w[c,j] x[s t + j]
+//      is linear in x, so  sum_t u = w_c . m   and  sum_t u^2 = w_c^T G w_c  with the k-vector
+//      m[j] = sum_t x[s t + j] and the k x k Gram matrix G[j,j'] = sum_t x[s t + j] x[s t + j'] of
+//      the utterance — one cheap pass over the 1.9 MB wave instead of a pass over 512 channels.
+//  (2) the normalisation is folded into the filter: y = GELU(sum_j (a_c w[c,j]) x[.] + b_c),
+//      a_c = gamma_c rstd_c, b_c = beta_c - mean_c a_c; output written channels-last [B, L, C]
+//      (one wave stores 1 KiB contiguous per frame) so the next conv is an implicit GEMM.
+// Backward needs ONE pass over dy: per (b,c) it accumulates s1 = sum dz, s2 = sum dz*uhat and
+// r[j] = sum_t dz x[s t + j]; dW/dgamma/dbeta then follow in closed form from (s1, s2, r, m, G).
+#include "cst_common.h"
+
+namespace {
+
+constexpr int KMAX = 16;
+
+// ---- pass A: per-utterance moments m[k], G[k][k] (fp32 atomics of block partials) -------------
+__global__ void conv0_gram_kernel(const float* wav, float* gram, int64_t S, int64_t L, int k, int stride) {
+  const int64_t b = blockIdx.y;
+  const float* x = wav + b * S;
+  float* g = gram + b * (k * k + k);
+  const int nacc = k * k + k;
+  __shared__ float red[KMAX * KMAX + KMAX];
+  for (int i = threadIdx.x; i < nacc; i += blockDim.x) red[i] = 0.0f;
+  __syncthreads();
+  float m[KMAX], G[KMAX * (KMAX + 1) / 2];
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) m[j] = 0.0f;
+#pragma unroll
+  for (int j = 0; j < KMAX * (KMAX + 1) / 2; ++j) G[j] = 0.0f;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < L; t += (int64_t)gridDim.x * blockDim.x) {
+    float xv[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) xv[j] = j < k ? x[t * stride + j] : 0.0f;
+    int idx = 0;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      m[j] += xv[j];
+#pragma unroll
+      for (int j2 = j; j2 < KMAX; ++j2) G[idx++] += xv[j] * xv[j2];
+    }
+  }
+  int idx = 0;
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) {
+    const float mj = wave_sum(m[j]);
+    if ((threadIdx.x & 63) == 0 && j < k) atomicAdd(&red[k * k + j], mj);
+#pragma unroll
+    for (int j2 = j; j2 < KMAX; ++j2) {
+      const float gj = wave_sum(G[idx++]);
+      if ((threadIdx.x & 63) == 0 && j < k && j2 < k) {
+        atomicAdd(&red[j * k + j2], gj);
+        if (j2 != j) atomicAdd(&red[j2 * k + j], gj);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nacc; i += blockDim.x) atomicAdd(&g[i], red[i]);
+}
+
+// ---- pass B: mean/rstd per (b,c) from the moments --------------------------------------------
+template <typename T>
+__global__ void conv0_stats_kernel(const T* w, const float* gram, float* mean, float* rstd, int64_t C, int64_t L, int k, float eps) {
+  const int64_t b = blockIdx.y;
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float* g = gram + b * (k * k + k);
+  double wm = 0.0, wgw = 0.0;
+  for (int j = 0; j < k; ++j) {
+    const double wj = (double)DT<T>::ld(w + c * k + j);
+    wm += wj * (double)g[k * k + j];
+    double row = 0.0;
+    for (int j2 = 0; j2 < k; ++j2) row += (double)g[j * k + j2] * (double)DT<T>::ld(w + c * k + j2);
+    wgw += wj * row;
+  }
+  const double mu = wm / (double)L;
+  double var = wgw / (double)L - mu * mu;
+  if (var < 0.0) var = 0.0;
+  mean[b * C + c] = (float)mu;
+  rstd[b * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// ---- pass C: y = GELU(a_c * conv + b_c), channels-last ---------------------------------------
+// block = 256 threads; lane -> (frame-in-group, 8-channel vector); frames of a block share an LDS copy of the wave span.
+constexpr int C0_TB = 64;  // frames per block
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* wav, const T* w, const T* gamma, const T* beta,
+                                                        const float* mean, const float* rstd, T* y, int64_t S, int64_t L,
+                                                        int C, int k, int stride) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* sw = sm;                 // [k][C] folded filter a_c * w[c][j]
+  float* sb = sw + k * C;         // [C]    b_c
+  float* sx = sb + C;             // [C0_TB*stride + k] wave span
+  const int64_t b = blockIdx.y;
+  const int64_t t0 = (int64_t)blockIdx.x * C0_TB;
+  const int nt = (int)((L - t0 < C0_TB) ? (L - t0) : C0_TB);
+  for (int i = threadIdx.x; i < C; i += blockDim.x) {
+    const float a = DT<T>::ld(gamma + i) * rstd[b * C + i];
+    sb[i] = DT<T>::ld(beta + i) - mean[b * C + i] * a;
+    for (int j = 0; j < k; ++j) sw[j * C + i] = a * DT<T>::ld(w + (int64_t)i * k + j);
+  }
+  const int span = (nt - 1) * stride + k;
+  for (int i = threadIdx.x; i < span; i += blockDim.x) sx[i] = wav[b * S + t0 * stride + i];
+  __syncthreads();
+  const int cvecs = C / 8;
+  for (int item = threadIdx.x; item < nt * cvecs; item += blockDim.x) {
+    const int tl = item / cvecs, cv = item % cvecs;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = sb[cv * 8 + e];
+    for (int j = 0; j < k; ++j) {
+      const float xv = sx[tl * stride + j];
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(sw + j * C + cv * 8);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(sw + j * C + cv * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc[e] += w0[e] * xv; acc[4 + e] += w1[e] * xv; }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = gelu_f(acc[e]);
+    store8(y + (b * L + t0 + tl) * C + cv * 8, acc);
+  }
+}
+
+// ---- backward pass over dy: per (b,c) accumulate s1, s2, r[0..k) --------------------------------
+// acc layout in ws: [B][k+2][C]  (row 0 = s1, row 1 = s2, rows 2.. = r[j])
+constexpr int C0_BWD_TB = 256;  // frames per block
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv0_bwd_kernel(const T* dy, const float* wav, const T* w, const T* gamma,
+                                                        const T* beta, const float* mean, const float* rstd, float* ws,
+                                                        int64_t S, int64_t L, int C, int k, int stride) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* sw = sm;            // [k][C] raw filter
+  float* sa = sw + k * C;    // [C] gamma, [C] beta, [C] mean, [C] rstd
+  float* sx = sa + 4 * C;    // wave span
+  const int64_t b = blockIdx.y;
+  const int64_t t0 = (int64_t)blockIdx.x * C0_BWD_TB;
+  const int nt = (int)((L - t0 < C0_BWD_TB) ? (L - t0) : C0_BWD_TB);
+  for (int i = threadIdx.x; i < C; i += blockDim.x) {
+    sa[i] = DT<T>::ld(gamma + i);
+    sa[C + i] = DT<T>::ld(beta + i);
+    sa[2 * C + i] = mean[b * C + i];
+    sa[3 * C + i] = rstd[b * C + i];
+    for (int j = 0; j < k; ++j) sw[j * C + i] = DT<T>::ld(w + (int64_t)i * k + j);
+  }
+  const int span = (nt - 1) * stride + k;
+  for (int i = threadIdx.x; i < span; i += blockDim.x) sx[i] = wav[b * S + t0 * stride + i];
+  __syncthreads();
+  const int cvecs = C / 8;
+  // thread -> fixed channel vector, strided over frames so partial sums stay in registers
+  const int tpc = blockDim.x / cvecs > 0 ? blockDim.x / cvecs : 1;  // threads per channel vector
+  const int cv = threadIdx.x % cvecs, tsl = threadIdx.x / cvecs;
+  if (tsl >= tpc) return;
+  float s1[8], s2[8], r[KMAX][8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.0f; s2[e] = 0.0f; }
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[j][e] = 0.0f;
+  for (int ccv = cv; ccv < cvecs; ccv += blockDim.x) {  // (runs once: cvecs <= blockDim.x)
+    for (int tl = tsl; tl < nt; tl += tpc) {
+      float d[8], u[8];
+      load8(dy + (b * L + t0 + tl) * C + ccv * 8, d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) u[e] = 0.0f;
+      float xv[KMAX];
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j) {
+        xv[j] = j < k ? sx[tl * stride + j] : 0.0f;
+        if (j < k) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) u[e] += sw[j * C + ccv * 8 + e] * xv[j];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = ccv * 8 + e;
+        const float uh = (u[e] - sa[2 * C + c]) * sa[3 * C + c];
+        const float z = uh * sa[c] + sa[C + c];
+        const float dz = d[e] * dgelu_f(z);
+        s1[e] += dz;
+        s2[e] += dz * uh;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) r[j][e] += dz * xv[j];
+      }
+    }
+    float* o = ws + b * (k + 2) * (int64_t)C + ccv * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      atomicAdd(o + e, s1[e]);
+      atomicAdd(o + C + e, s2[e]);
+    }
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j)
+      if (j < k) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(o + (int64_t)(2 + j) * C + e, r[j][e]);
+      }
+  }
+}
+
+// closed-form finish: dW[c][j], dgamma[c], dbeta[c] summed over utterances.
+//   du = (gamma rstd) (dz - s1/L - uhat s2/L);  dW[c][j] = sum_t du x[s t + j]
+//   sum_t uhat x_j = rstd (sum_j' w[c][j'] G[j'][j] - mean m[j])
+template <typename T>
+__global__ void conv0_bwd_finish_kernel(const float* ws, const float* gram, const T* w, const T* gamma, const float* mean,
+                                        const float* rstd, float* dw, float* dgamma, float* dbeta, int64_t B, int64_t C,
+                                        int64_t L, int k) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double dg = 0.0, db = 0.0, dwj[KMAX];
+  for (int j = 0; j < k; ++j) dwj[j] = 0.0;
+  const double gam = (double)DT<T>::ld(gamma + c);
+  for (int64_t b = 0; b < B; ++b) {
+    const float* a = ws + b * (k + 2) * C;
+    const float* g = gram + b * (k * k + k);
+    const double s1 = a[c], s2 = a[C + c], rs = rstd[b * C + c], mu = mean[b * C + c];
+    dg += s2;
+    db += s1;
+    for (int j = 0; j < k; ++j) {
+      double wg = 0.0;
+      for (int j2 = 0; j2 < k; ++j2) wg += (double)DT<T>::ld(w + c * k + j2) * (double)g[j2 * k + j];
+      const double uhx = rs * (wg - mu * (double)g[k * k + j]);
+      dwj[j] += gam * rs * ((double)a[(2 + j) * C + c] - s1 / (double)L * (double)g[k * k + j] - s2 / (double)L * uhx);
+    }
+  }
+  dgamma[c] = (float)dg;
+  dbeta[c] = (float)db;
+  for (int j = 0; j < k; ++j) dw[c * k + j] = (float)dwj[j];
+}
+
+}  // namespace
+
+extern "C" int cst_conv0_gn_gelu_fwd(const float* wav, const void* w, const void* gamma, const void* beta, void* y,
+                                     float* mean, float* rstd, float* gram, int64_t B, int64_t S, int64_t C, int k,
+                                     int stride, float eps, int dtype, cst_stream stream) {
+  CST_REQUIRE(wav && w && gamma && beta && y && mean && rstd && gram, "cst_conv0_gn_gelu_fwd: null tensor");
+  CST_REQUIRE(k >= 1 && k <= KMAX && stride >= 1 && S >= k, "cst_conv0_gn_gelu_fwd: unsupported k=%d stride=%d S=%lld", k, stride, (long long)S);
+  CST_REQUIRE(C % 8 == 0 && C >= 8 && C / 8 <= 256, "cst_conv0_gn_gelu_fwd: C=%lld must be a multiple of 8 and <= 2048", (long long)C);
+  CST_REQUIRE(dtype == CST_F32 || dtype == CST_BF16, "cst_conv0_gn_gelu_fwd: bad dtype %d", dtype);
+  const int64_t L = (S - k) / stride + 1;
+  hipStream_t s = (hipStream_t)stream;
+  const double bytes = (double)B * S * 4.0 * 2.0 + (double)B * L * C * cst_dtype_size(dtype);
+  CstProfScope prof(CST_K_CONV0, s, 2.0 * (double)B * L * C * k, bytes);
+  if (hipMemsetAsync(gram, 0, sizeof(float) * B * (k * k + k), s) != hipSuccess) { cst_set_error("conv0: memset failed"); return CST_ERR_LAUNCH; }
+  int gb = (int)(cst_ceil_div(L, 256 * 8) < 64 ? cst_ceil_div(L, 256 * 8) : 64);
+  hipLaunchKernelGGL(conv0_gram_kernel, dim3(gb, (unsigned)B), dim3(256), 0, s, wav, gram, S, L, k, stride);
+  const size_t lds = sizeof(float) * ((size_t)k * C + C + (size_t)C0_TB * stride + k);
+  dim3 sg((unsigned)cst_ceil_div(C, 128), (unsigned)B), fg((unsigned)cst_ceil_div(L, C0_TB), (unsigned)B);
+  if (dtype == CST_BF16) {
+    hipLaunchKernelGGL(conv0_stats_kernel<bf16_t>, sg, dim3(128), 0, s, (const bf16_t*)w, gram, mean, rstd, C, L, k, eps);
+    hipLaunchKernelGGL(conv0_fwd_kernel<bf16_t>, fg, dim3(256), lds, s, wav, (const bf16_t*)w, (const bf16_t*)gamma, (const bf16_t*)beta, mean, rstd, (bf16_t*)y, S, L, (int)C, k, stride);
+  } else {
+    hipLaunchKernelGGL(conv0_stats_kernel<float>, sg, dim3(128), 0, s, (const float*)w, gram, mean, rstd, C, L, k, eps);
+    hipLaunchKernelGGL(conv0_fwd_kernel<float>, fg, dim3(256), lds, s, wav, (const float*)w, (const float*)gamma, (const float*)beta, mean, rstd, (float*)y, S, L, (int)C, k, stride);
+  }
+  return cst_check_launch("cst_conv0_gn_gelu_fwd");
+}
+
+extern "C" int64_t cst_conv0_bwd_workspace(int64_t B, int64_t C, int k) { return B * (int64_t)(k + 2) * C * (int64_t)sizeof(float); }
+
+extern "C" int cst_conv0_gn_gelu_bwd(const void* dy, const float* wav, const void* w, const void* gamma, const void* beta,
+                                     const float* mean, const float* rstd, const float* gram, float* dw, float* dgamma,
+                                     float* dbeta, float* workspace, int64_t B, int64_t S, int64_t C, int k, int stride,
+                                     int dtype, cst_stream stream) {
+  CST_REQUIRE(dy && wav && w && gamma && beta && mean && rstd && gram && dw && dgamma && dbeta && workspace, "cst_conv0_gn_gelu_bwd: null tensor");
+  CST_REQUIRE(k >= 1 && k <= KMAX && stride >= 1 && S >= k, "cst_conv0_gn_gelu_bwd: unsupported k=%d stride=%d", k, stride);
+  CST_REQUIRE(C % 8 == 0 && C >= 8 && C / 8 <= 256, "cst_conv0_gn_gelu_bwd: C=%lld must be a multiple of 8 and <= 2048", (long long)C);
+  CST_REQUIRE(dtype == CST_F32 || dtype == CST_BF16, "cst_conv0_gn_gelu_bwd: bad dtype %d", dtype);
+  const int64_t L = (S - k) / stride + 1;
+  hipStream_t s = (hipStream_t)stream;
+  const double bytes = (double)B * S * 4.0 + (double)B * L * C * cst_dtype_size(dtype);
+  CstProfScope prof(CST_K_CONV0, s, 4.0 * (double)B * L * C * k, bytes);
+  if (hipMemsetAsync(workspace, 0, (size_t)cst_conv0_bwd_workspace(B, C, k), s) != hipSuccess) { cst_set_error("conv0 bwd: memset failed"); return CST_ERR_LAUNCH; }
+  const size_t lds = sizeof(float) * ((size_t)k * C + 4 * C + (size_t)C0_BWD_TB * stride + k);
+  dim3 grid((unsigned)cst_ceil_div(L, C0_BWD_TB), (unsigned)B), fg((unsigned)cst_ceil_div(C, 128));
+  if (dtype == CST_BF16) {
+    hipLaunchKernelGGL(conv0_bwd_kernel<bf16_t>, grid, dim3(256), lds, s, (const bf16_t*)dy, wav, (const bf16_t*)w, (const bf16_t*)gamma, (const bf16_t*)beta, mean, rstd, workspace, S, L, (int)C, k, stride);
+    hipLaunchKernelGGL(conv0_bwd_finish_kernel<bf16_t>, fg, dim3(128), 0, s, workspace, gram, (const bf16_t*)w, (const bf16_t*)gamma, mean, rstd, dw, dgamma, dbeta, B, C, L, k);
+  } else {
+    hipLaunchKernelGGL(conv0_bwd_kernel<float>, grid, dim3(256), lds, s, (const float*)dy, wav, (const float*)w, (const float*)gamma, (const float*)beta, mean, rstd, workspace, S, L, (int)C, k, stride);
+    hipLaunchKernelGGL(conv0_bwd_finish_kernel<float>, fg, dim3(128), 0, s, workspace, gram, (const float*)w, (const float*)gamma, mean, rstd, dw, dgamma, dbeta, B, C, L, k);
+  }
+  return cst_check_launch("cst_conv0_gn_gelu_bwd");
+}

@@ -1,0 +1,178 @@
+// cst_common.h — shared device/host helpers for the gfx950 kernels (wave64, MFMA 32x32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <math.h>
+#include "../../include/cst.h"
+
+#define CST_ABI_VERSION 1
+#define CST_WAVE 64
+
+// ---------------------------------------------------------------------------------------
+// host side: error reporting + launch bookkeeping (profiling table)
+// ---------------------------------------------------------------------------------------
+void cst_set_error(const char* fmt, ...);
+struct CstProfScope {
+  int cls; hipStream_t s; int slot;
+  CstProfScope(int cls, hipStream_t s, double flops, double bytes);
+  ~CstProfScope();
+};
+int cst_check_launch(const char* what);
+
+#define CST_REQUIRE(cond, ...)                         \
+  do {                                                 \
+    if (!(cond)) {                                     \
+      cst_set_error(__VA_ARGS__);                      \
+      return CST_ERR_BAD_ARG;                          \
+    }                                                  \
+  } while (0)
+
+static inline int64_t cst_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t cst_dtype_size(int dt) { return dt == CST_BF16 ? 2 : 4; }
+
+// ---------------------------------------------------------------------------------------
+// device side
+// ---------------------------------------------------------------------------------------
+typedef __bf16 bf16_t;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+using u16x8 = __attribute__((ext_vector_type(8))) unsigned short;
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
+  return __uint_as_float(((unsigned int)b) << 16);
+}
+// round-to-nearest-even, NaN preserved (matches torch's float -> bfloat16)
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+template <typename T> struct DT;
+template <> struct DT<float> {
+  static constexpr int VEC = 4;  // elements per 16-byte vector
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct DT<bf16_t> {
+  static constexpr int VEC = 8;
+  __device__ static __forceinline__ float ld(const bf16_t* p) {
+    return bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(p));
+  }
+  __device__ static __forceinline__ void st(bf16_t* p, float v) {
+    *reinterpret_cast<unsigned short*>(p) = f32_to_bf16_bits(v);
+  }
+};
+
+// 8 consecutive elements <-> 8 floats (vectorised: 16 B for bf16, 2 x 16 B for f32)
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+  f32x4 a = *reinterpret_cast<const f32x4*>(p);
+  f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+  v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
+  u32x4 r = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = __uint_as_float(r[i] << 16);
+    v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+  f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+  *reinterpret_cast<f32x4*>(p) = a;
+  *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+  u32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    r[i] = (unsigned int)f32_to_bf16_bits(v[2 * i]) | ((unsigned int)f32_to_bf16_bits(v[2 * i + 1]) << 16);
+  *reinterpret_cast<u32x4*>(p) = r;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// exact GELU (erf form, modules/gelu.py:25) and its derivative
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+__device__ __forceinline__ float act_f(float x, int act) {
+  return act == CST_ACT_RELU ? fmaxf(x, 0.0f) : (act == CST_ACT_GELU ? gelu_f(x) : x);
+}
+__device__ __forceinline__ float dact_f(float z, int act) {
+  return act == CST_ACT_RELU ? (z > 0.0f ? 1.0f : 0.0f) : (act == CST_ACT_GELU ? dgelu_f(z) : 1.0f);
+}
+
+// ---------------------------------------------------------------------------------------
+// MFMA 32x32 step over 16 reduction indices.  A fragment: lane l holds Aop[row = l&31][k0 + 8*(l>>5) .. +8);
+// B fragment: lane l holds Bop[k0 + 8*(l>>5) .. +8)[col = l&31].  C/D: col = l&31,
+// row = (r&3) + 8*(r>>2) + 4*(l>>5) for r in [0,16).
+// bf16: one v_mfma_f32_32x32x16_bf16.  f32: eight v_mfma_f32_32x32x2_f32 (slot j of both half-waves per step;
+// the pairing of k indices differs from the bf16 instruction but the sum over all 16 is the same).
+// ---------------------------------------------------------------------------------------
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> {
+  bf16x8 v;
+};
+template <> struct Frag<float> {
+  float v[8];
+};
+__device__ __forceinline__ void mma16(f32x16& acc, const Frag<bf16_t>& a, const Frag<bf16_t>& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(f32x16& acc, const Frag<float>& a, const Frag<float>& b) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], acc, 0, 0, 0);
+}
+// fragment from 8 contiguous elements in LDS / registers
+__device__ __forceinline__ void frag_load_contig(Frag<bf16_t>& f, const bf16_t* p) {
+  f.v = *reinterpret_cast<const bf16x8*>(p);
+}
+__device__ __forceinline__ void frag_load_contig(Frag<float>& f, const float* p) {
+  f32x4 a = *reinterpret_cast<const f32x4*>(p);
+  f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+  f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+  f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+}
+// fragment from 8 elements `stride` apart (operand whose reduction index is NOT contiguous in LDS)
+__device__ __forceinline__ void frag_load_strided(Frag<bf16_t>& f, const bf16_t* p, int stride) {
+  u16x8 t;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) t[j] = *reinterpret_cast<const unsigned short*>(p + j * stride);
+  f.v = __builtin_bit_cast(bf16x8, t);
+}
+__device__ __forceinline__ void frag_load_strided(Frag<float>& f, const float* p, int stride) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = p[j * stride];
+}
+// fragment from 8 fp32 register values (e.g. softmax probabilities)
+__device__ __forceinline__ void frag_from_f32(Frag<bf16_t>& f, const float (&x)[8]) {
+  u16x8 t;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) t[j] = f32_to_bf16_bits(x[j]);
+  f.v = __builtin_bit_cast(bf16x8, t);
+}
+__device__ __forceinline__ void frag_from_f32(Frag<float>& f, const float (&x)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = x[j];
+}
+// the accumulator row owned by register r of lane `lane`
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }

@@ -1,0 +1,215 @@
+// elementwise.hip — HBM-bound helpers: GLU, activation fwd/bwd, column sums (bias grads),
+// col2im for strided conv1d input gradients, row masking.  All use 16-byte (8-element) vectors
+// and grid-stride loops capped at ~2048 workgroups (cdna guide G11/G13).
+#include "cst_common.h"
+
+namespace {
+
+inline int ew_blocks(int64_t items) {
+  int64_t b = cst_ceil_div(items, 256);
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+template <typename T>
+__global__ void glu_fwd_kernel(const T* z, T* y, int64_t rows, int64_t C) {
+  const int64_t cv = C / 8, total = rows * cv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cv, c = (i % cv) * 8;
+    float a[8], g[8], o[8];
+    load8(z + r * 2 * C + c, a);
+    load8(z + r * 2 * C + C + c, g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = a[e] / (1.0f + __expf(-g[e]));
+    store8(y + r * C + c, o);
+  }
+}
+
+template <typename T>
+__global__ void glu_bwd_kernel(const T* dy, const T* z, T* dz, int64_t rows, int64_t C) {
+  const int64_t cv = C / 8, total = rows * cv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cv, c = (i % cv) * 8;
+    float a[8], g[8], d[8], da[8], dg[8];
+    load8(z + r * 2 * C + c, a);
+    load8(z + r * 2 * C + C + c, g);
+    load8(dy + r * C + c, d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float sg = 1.0f / (1.0f + __expf(-g[e]));
+      da[e] = d[e] * sg;
+      dg[e] = d[e] * a[e] * sg * (1.0f - sg);
+    }
+    store8(dz + r * 2 * C + c, da);
+    store8(dz + r * 2 * C + C + c, dg);
+  }
+}
+
+template <typename T>
+__global__ void act_bwd_kernel(const T* dy, const T* z, T* dx, int64_t n8, int act) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    float d[8], zz[8];
+    load8(dy + i * 8, d);
+    load8(z + i * 8, zz);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d[e] *= dact_f(zz[e], act);
+    store8(dx + i * 8, d);
+  }
+}
+
+template <typename T>
+__global__ void act_fwd_kernel(const T* x, T* y, int64_t n8, int act) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    float v[8];
+    load8(x + i * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = act_f(v[e], act);
+    store8(y + i * 8, v);
+  }
+}
+
+// thread = one 8-column vector, rows chunked over blockIdx.y; fp32 atomics of the chunk partials
+template <typename T>
+__global__ void colsum_kernel(const T* x, int64_t ldx, float* out, int64_t rows, int64_t cols, int64_t rows_per) {
+  const int64_t cv = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (cv * 8 >= cols) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per;
+  const int64_t r1 = r0 + rows_per < rows ? r0 + rows_per : rows;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t r = r0; r < r1; ++r) {
+    float v[8];
+    load8(x + r * ldx + cv * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += v[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) atomicAdd(out + cv * 8 + e, acc[e]);
+}
+
+template <typename T>
+__global__ void col2im1d_kernel(const T* dcol, const T* z, T* dx, int64_t B, int64_t Lin, int64_t Lout, int64_t C, int k,
+                                int stride, int pad, int dact) {
+  const int64_t cv = C / 8, total = B * Lin * cv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = (i % cv) * 8, l = (i / cv) % Lin, b = i / (cv * Lin);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < k; ++j) {
+      const int64_t num = l + pad - j;
+      if (num < 0 || num % stride) continue;
+      const int64_t t = num / stride;
+      if (t >= Lout) continue;
+      float v[8];
+      load8(dcol + ((b * Lout + t) * k + j) * C + c, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += v[e];
+    }
+    if (dact) {
+      float zz[8];
+      load8(z + (b * Lin + l) * C + c, zz);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] *= dact_f(zz[e], dact);
+    }
+    store8(dx + (b * Lin + l) * C + c, acc);
+  }
+}
+
+template <typename T>
+__global__ void mask_rows_kernel(const T* x, const uint8_t* mask, T* y, int64_t rows, int64_t cols) {
+  const int64_t cv = cols / 8, total = rows * cv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cv;
+    float v[8];
+    load8(x + i * 8, v);
+    if (mask[r]) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+    }
+    store8(y + i * 8, v);
+  }
+}
+
+}  // namespace
+
+#define CST_EW_DISPATCH(kern, grid, block, s, dtype, ...)                                        \
+  do {                                                                                           \
+    if (dtype == CST_BF16) hipLaunchKernelGGL(kern<bf16_t>, grid, block, 0, s, __VA_ARGS__);     \
+    else hipLaunchKernelGGL(kern<float>, grid, block, 0, s, __VA_ARGS__);                        \
+  } while (0)
+
+extern "C" int cst_glu_fwd(const void* z, void* y, int64_t rows, int64_t C, int dtype, cst_stream stream) {
+  CST_REQUIRE(z && y && rows > 0 && C > 0 && C % 8 == 0, "cst_glu_fwd: bad args (C=%lld must be a multiple of 8)", (long long)C);
+  CST_REQUIRE(dtype == CST_F32 || dtype == CST_BF16, "cst_glu_fwd: bad dtype");
+  hipStream_t s = (hipStream_t)stream;
+  CstProfScope prof(CST_K_ELEMENTWISE, s, 0.0, 3.0 * rows * C * cst_dtype_size(dtype));
+  if (dtype == CST_BF16) hipLaunchKernelGGL(glu_fwd_kernel<bf16_t>, dim3(ew_blocks(rows * C / 8)), dim3(256), 0, s, (const bf16_t*)z, (bf16_t*)y, rows, C);
+  else hipLaunchKernelGGL(glu_fwd_kernel<float>, dim3(ew_blocks(rows * C / 8)), dim3(256), 0, s, (const float*)z, (float*)y, rows, C);
+  return cst_check_launch("cst_glu_fwd");
+}
+
+extern "C" int cst_glu_bwd(const void* dy, const void* z, void* dz, int64_t rows, int64_t C, int dtype, cst_stream stream) {
+  CST_REQUIRE(dy && z && dz && rows > 0 && C > 0 && C % 8 == 0, "cst_glu_bwd: bad args");
+  CST_REQUIRE(dtype == CST_F32 || dtype == CST_BF16, "cst_glu_bwd: bad dtype");
+  hipStream_t s = (hipStream_t)stream;
+  CstProfScope prof(CST_K_ELEMENTWISE, s, 0.0, 5.0 * rows * C * cst_dtype_size(dtype));
+  if (dtype == CST_BF16) hipLaunchKernelGGL(glu_bwd_kernel<bf16_t>, dim3(ew_blocks(rows * C / 8)), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)z, (bf16_t*)dz, rows, C);
+  else hipLaunchKernelGGL(glu_bwd_kernel<float>, dim3(ew_blocks(rows * C / 8)), dim3(256), 0, s, (const float*)dy, (const float*)z, (float*)dz, rows, C);
+  return cst_check_launch("cst_glu_bwd");
+}
+
+extern "C" int cst_act_bwd(const void* dy, const void* z, void* dx, int64_t n, int act, int dtype, cst_stream stream) {
+  CST_REQUIRE(dy && z && dx && n > 0 && n % 8 == 0, "cst_act_bwd: n=%lld must be a positive multiple of 8", (long long)n);
+  CST_REQUIRE(dtype == CST_F32 || dtype == CST_BF16, "cst_act_bwd: bad dtype");
+  hipStream_t s = (hipStream_t)stream;
+  CstProfScope prof(CST_K_ELEMENTWISE, s, 0.0, 3.0 * n * cst_dtype_size(dtype));
+  if (dtype == CST_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(ew_blocks(n / 8)), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)z, (bf16_t*)dx, n / 8, act);
+  else hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(ew_blocks(n / 8)), dim3(256), 0, s, (const float*)dy, (const float*)z, (float*)dx, n / 8, act);
+  return cst_check_launch("cst_act_bwd");
+}
+
+extern "C" int cst_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, cst_stream stream) {
+  CST_REQUIRE(x && y && n > 0 && n % 8 == 0, "cst_act_fwd: n=%lld must be a positive multiple of 8", (long long)n);
+  CST_REQUIRE(dtype == CST_F32 || dtype == CST_BF16, "cst_act_fwd: bad dtype");
+  hipStream_t s = (hipStream_t)stream;
+  CstProfScope prof(CST_K_ELEMENTWISE, s, 0.0, 2.0 * n * cst_dtype_size(dtype));
+  if (dtype == CST_BF16) hipLaunchKernelGGL(act_fwd_kernel<bf16_t>, dim3(ew_blocks(n / 8)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, n / 8, act);
+  else hipLaunchKernelGGL(act_fwd_kernel<float>, dim3(ew_blocks(n / 8)), dim3(256), 0, s, (const float*)x, (float*)y, n / 8, act);
+  return cst_check_launch("cst_act_fwd");
+}
+
+extern "C" int cst_colsum(const void* x, int64_t ldx, float* out, int64_t rows, int64_t cols, int dtype, cst_stream stream) {
+  CST_REQUIRE(x && out && rows > 0 && cols > 0 && cols % 8 == 0 && ldx % 8 == 0, "cst_colsum: cols/ldx must be multiples of 8");
+  CST_REQUIRE(dtype == CST_F32 || dtype == CST_BF16, "cst_colsum: bad dtype");
+  hipStream_t s = (hipStream_t)stream;
+  CstProfScope prof(CST_K_ELEMENTWISE, s, 0.0, (double)rows * cols * cst_dtype_size(dtype));
+  if (hipMemsetAsync(out, 0, sizeof(float) * cols, s) != hipSuccess) { cst_set_error("cst_colsum: memset failed"); return CST_ERR_LAUNCH; }
+  int64_t chunks = cst_ceil_div(rows, 128);
+  if (chunks > 1024) chunks = 1024;
+  const int64_t rows_per = cst_ceil_div(rows, chunks);
+  dim3 grid((unsigned)cst_ceil_div(cols / 8, 64), (unsigned)cst_ceil_div(rows, rows_per));
+  if (dtype == CST_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(64), 0, s, (const bf16_t*)x, ldx, out, rows, cols, rows_per);
+  else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(64), 0, s, (const float*)x, ldx, out, rows, cols, rows_per);
+  return cst_check_launch("cst_colsum");
+}
+
+extern "C" int cst_col2im1d(const void* dcol, const void* z, void* dx, int64_t B, int64_t Lin, int64_t Lout, int64_t C, int k,
+                            int stride, int pad, int dact, int dtype, cst_stream stream) {
+  CST_REQUIRE(dcol && dx && B > 0 && Lin > 0 && Lout > 0 && C > 0 && C % 8 == 0 && k >= 1 && stride >= 1 && pad >= 0, "cst_col2im1d: bad args");
+  CST_REQUIRE(!dact || z, "cst_col2im1d: dact needs z");
+  CST_REQUIRE(dtype == CST_F32 || dtype == CST_BF16, "cst_col2im1d: bad dtype");
+  hipStream_t s = (hipStream_t)stream;
+  CstProfScope prof(CST_K_ELEMENTWISE, s, 0.0, ((double)B * Lout * k * C + (double)B * Lin * C * (dact ? 2.0 : 1.0)) * cst_dtype_size(dtype));
+  const int blocks = ew_blocks(B * Lin * C / 8);
+  if (dtype == CST_BF16) hipLaunchKernelGGL(col2im1d_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)dcol, (const bf16_t*)z, (bf16_t*)dx, B, Lin, Lout, C, k, stride, pad, dact);
+  else hipLaunchKernelGGL(col2im1d_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)dcol, (const float*)z, (float*)dx, B, Lin, Lout, C, k, stride, pad, dact);
+  return cst_check_launch("cst_col2im1d");
+}
+
+extern "C" int cst_mask_rows(const void* x, const uint8_t* mask, void* y, int64_t rows, int64_t cols, int dtype, cst_stream stream) {
+  CST_REQUIRE(x && mask && y && rows > 0 && cols > 0 && cols % 8 == 0, "cst_mask_rows: bad args");
+  CST_REQUIRE(dtype == CST_F32 || dtype == CST_BF16, "cst_mask_rows: bad dtype");
+  hipStream_t s = (hipStream_t)stream;
+  CstProfScope prof(CST_K_ELEMENTWISE, s, 0.0, 2.0 * rows * cols * cst_dtype_size(dtype));
+  const int blocks = ew_blocks(rows * cols / 8);
+  if (dtype == CST_BF16) hipLaunchKernelGGL(mask_rows_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, mask, (bf16_t*)y, rows, cols);
+  else hipLaunchKernelGGL(mask_rows_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, mask, (float*)y, rows, cols);
+  return cst_check_launch("cst_mask_rows");
+}

@@ -1,0 +1,369 @@
+// gemm.hip — MFMA GEMM for gfx950 (wave64, v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x2_f32).
+//
+// One kernel family serves every dense contraction of the Chimera hot path (see include/cst.h):
+// Linear fwd (A k-major, B k-major), dX (A k-major, B mn-major), dW (A mn-major, B mn-major),
+// the wav2vec2 conv stack / subsampler as implicit GEMM (lda < K: overlapping channels-last rows)
+// and the grouped pos-conv (segmented K addressing + two batch levels).
+//
+// Tile: 128 x 128 x BK (BK = 64 bf16 / 32 f32 -> always 8 16-byte vectors per k-major row),
+// 256 threads = 4 waves in 2x2, each wave 64x64 = 2x2 MFMA 32x32 accumulators (64 acc VGPRs).
+// Global -> registers -> LDS staging, double-buffered LDS, one barrier per K tile; the next
+// tile's global loads are issued before the current tile's MFMAs (latency hidden under MFMA).
+// LDS images: k-major tiles [128][BK + VEC] (16-B row pad -> conflict-free ds_read_b128),
+// mn-major tiles [BK][128 + VEC] read with per-element strided gathers (half-wave = 32
+// consecutive mn -> conflict-free).
+// Workgroup -> tile map is XCD-aware (bijective remap so each XCD's L2 sees a contiguous
+// band of tiles sharing A rows).
+#include "cst_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, NTHREADS = 256;
+
+struct GemmParams {
+  int64_t M, N, K;
+  const void* A; int64_t lda, a_seg, a_seg_stride;
+  const void* B; int64_t ldb, b_seg, b_seg_stride;
+  void* C; int64_t ldc;
+  const void* bias; int bias_mode; int64_t sbias0, sbias1;
+  int act;
+  void* aux_out; int64_t ld_aux_out;
+  int dact;
+  const void* aux_in; int64_t ld_aux_in;
+  const void* resid; int64_t ld_resid;
+  float alpha;
+  int64_t batch1;
+  int64_t sa0, sa1, sb0, sb1, sc0, sc1;
+  int splits;
+  float* ws;  // split-K partials [batch][split][M][N]
+  int c_f32;
+  int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ int64_t segaddr(int64_t c, int64_t seg, int64_t seg_stride) {
+  return seg ? (c / seg) * seg_stride + (c % seg) : c;
+}
+
+template <typename T>
+__device__ __forceinline__ void epilogue_store(const GemmParams& p, int64_t cofs, int64_t bofs, int64_t row, int64_t col, float v) {
+  v *= p.alpha;
+  if (p.bias_mode == CST_BIAS_COL) v += DT<T>::ld((const T*)p.bias + bofs + col);
+  else if (p.bias_mode == CST_BIAS_ROW) v += DT<T>::ld((const T*)p.bias + bofs + row);
+  if (p.aux_out) DT<T>::st((T*)p.aux_out + cofs + row * p.ld_aux_out + col, v);
+  v = act_f(v, p.act);
+  if (p.dact) v *= dact_f(DT<T>::ld((const T*)p.aux_in + cofs + row * p.ld_aux_in + col), p.dact);
+  if (p.resid) v += DT<T>::ld((const T*)p.resid + cofs + row * p.ld_resid + col);
+  if (p.c_f32) ((float*)p.C)[cofs + row * p.ldc + col] = v;
+  else DT<T>::st((T*)p.C + cofs + row * p.ldc + col, v);
+}
+
+template <typename T, bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
+  constexpr int VEC = DT<T>::VEC;
+  constexpr int BK = 8 * VEC;
+  constexpr int LDK = BK + VEC;    // k-major LDS row stride (elements)
+  constexpr int LDM = 128 + VEC;   // mn-major LDS row stride
+  constexpr int A_ELEMS = A_KMAJOR ? BM * LDK : BK * LDM;
+  constexpr int B_ELEMS = B_KMAJOR ? BN * LDK : BK * LDM;
+  constexpr int MVECS = 128 / VEC;  // vectors per mn-major row
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  T* lds_a[2] = {smem, smem + A_ELEMS + B_ELEMS};
+  T* lds_b[2] = {smem + A_ELEMS, smem + 2 * A_ELEMS + B_ELEMS};
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- XCD-aware tile id (bijective) ----
+  const int ntiles = p.tiles_m * p.tiles_n;
+  int id = blockIdx.x;
+  {
+    const int q = ntiles / 8, r = ntiles % 8, xcd = id % 8, loc = id / 8;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tm = id / p.tiles_n, tn = id % p.tiles_n;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+
+  const int z = blockIdx.z;
+  const int split = z % p.splits;
+  const int64_t bidx = z / p.splits;
+  const int64_t b0 = bidx / p.batch1, b1 = bidx % p.batch1;
+  const T* A = (const T*)p.A + b0 * p.sa0 + b1 * p.sa1;
+  const T* B = (const T*)p.B + b0 * p.sb0 + b1 * p.sb1;
+  const int64_t cofs = b0 * p.sc0 + b1 * p.sc1;
+  const int64_t bofs = b0 * p.sbias0 + b1 * p.sbias1;
+
+  const int64_t ktiles = (p.K + BK - 1) / BK;
+  const int64_t per = (ktiles + p.splits - 1) / p.splits;
+  const int64_t kt0 = split * per;
+  const int64_t kt1 = (kt0 + per < ktiles) ? kt0 + per : ktiles;
+
+  // ---- per-thread staging descriptors: 4 vectors of A and 4 of B per K tile ----
+  u32x4 ra[4], rb[4];
+  // k-major: v = tid + 256 i -> row = v>>3, kvec = v&7; mn-major: krow = v / MVECS, mvec = v % MVECS
+  int64_t a_rowoff[4], b_rowoff[4];  // fixed part of the global offset
+  bool a_ok[4], b_ok[4];             // fixed validity (row / mn bound)
+  int a_q[4], a_r[4], b_q[4], b_r[4];  // running segmented-k state (k-major only)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int v = tid + NTHREADS * i;
+    if (A_KMAJOR) {
+      const int64_t row = m0 + (v >> 3);
+      a_ok[i] = row < p.M;
+      a_rowoff[i] = row * p.lda;
+      const int64_t c = kt0 * BK + (v & 7) * VEC;
+      a_q[i] = p.a_seg ? (int)(c / p.a_seg) : 0;
+      a_r[i] = p.a_seg ? (int)(c % p.a_seg) : (int)c;
+    } else {
+      const int64_t m = m0 + (int64_t)(v % MVECS) * VEC;
+      a_ok[i] = m < p.M;  // M % VEC == 0 is required for mn-major operands
+      a_rowoff[i] = segaddr(m, p.a_seg, p.a_seg_stride);
+      a_q[i] = v / MVECS; a_r[i] = 0;
+    }
+    if (B_KMAJOR) {
+      const int64_t row = n0 + (v >> 3);
+      b_ok[i] = row < p.N;
+      b_rowoff[i] = row * p.ldb;
+      const int64_t c = kt0 * BK + (v & 7) * VEC;
+      b_q[i] = p.b_seg ? (int)(c / p.b_seg) : 0;
+      b_r[i] = p.b_seg ? (int)(c % p.b_seg) : (int)c;
+    } else {
+      const int64_t n = n0 + (int64_t)(v % MVECS) * VEC;
+      b_ok[i] = n < p.N;
+      b_rowoff[i] = segaddr(n, p.b_seg, p.b_seg_stride);
+      b_q[i] = v / MVECS; b_r[i] = 0;
+    }
+  }
+
+  auto load_tile = [&](int64_t kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u32x4 va = {0, 0, 0, 0}, vb = {0, 0, 0, 0};
+      if (A_KMAJOR) {
+        const int64_t k = (p.a_seg ? (int64_t)a_q[i] * p.a_seg + a_r[i] : (int64_t)a_r[i]);
+        if (a_ok[i] && k < p.K)
+          va = *reinterpret_cast<const u32x4*>(A + a_rowoff[i] + (p.a_seg ? (int64_t)a_q[i] * p.a_seg_stride + a_r[i] : k));
+        a_r[i] += BK;
+        if (p.a_seg) while (a_r[i] >= p.a_seg) { a_r[i] -= (int)p.a_seg; ++a_q[i]; }
+      } else {
+        const int64_t k = kt * BK + a_q[i];
+        if (a_ok[i] && k < p.K) va = *reinterpret_cast<const u32x4*>(A + k * p.lda + a_rowoff[i]);
+      }
+      if (B_KMAJOR) {
+        const int64_t k = (p.b_seg ? (int64_t)b_q[i] * p.b_seg + b_r[i] : (int64_t)b_r[i]);
+        if (b_ok[i] && k < p.K)
+          vb = *reinterpret_cast<const u32x4*>(B + b_rowoff[i] + (p.b_seg ? (int64_t)b_q[i] * p.b_seg_stride + b_r[i] : k));
+        b_r[i] += BK;
+        if (p.b_seg) while (b_r[i] >= p.b_seg) { b_r[i] -= (int)p.b_seg; ++b_q[i]; }
+      } else {
+        const int64_t k = kt * BK + b_q[i];
+        if (b_ok[i] && k < p.K) vb = *reinterpret_cast<const u32x4*>(B + k * p.ldb + b_rowoff[i]);
+      }
+      ra[i] = va; rb[i] = vb;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int v = tid + NTHREADS * i;
+      T* da = A_KMAJOR ? lds_a[buf] + (v >> 3) * LDK + (v & 7) * VEC : lds_a[buf] + (v / MVECS) * LDM + (v % MVECS) * VEC;
+      T* db = B_KMAJOR ? lds_b[buf] + (v >> 3) * LDK + (v & 7) * VEC : lds_b[buf] + (v / MVECS) * LDM + (v % MVECS) * VEC;
+      *reinterpret_cast<u32x4*>(da) = ra[i];
+      *reinterpret_cast<u32x4*>(db) = rb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  if (kt0 < kt1) {
+    load_tile(kt0);
+    store_tile(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  const int lrow = lane & 31, lk = 8 * (lane >> 5);
+  for (int64_t kt = kt0; kt < kt1; ++kt) {
+    const bool more = kt + 1 < kt1;
+    if (more) load_tile(kt + 1);
+    const T* sa = lds_a[cur];
+    const T* sb = lds_b[cur];
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 16) {
+      Frag<T> fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (A_KMAJOR) frag_load_contig(fa[i], sa + (wm * 64 + i * 32 + lrow) * LDK + kk + lk);
+        else frag_load_strided(fa[i], sa + (kk + lk) * LDM + wm * 64 + i * 32 + lrow, LDM);
+        if (B_KMAJOR) frag_load_contig(fb[i], sb + (wn * 64 + i * 32 + lrow) * LDK + kk + lk);
+        else frag_load_strided(fb[i], sb + (kk + lk) * LDM + wn * 64 + i * 32 + lrow, LDM);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mma16(acc[i][j], fa[i], fb[j]);
+    }
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue ----
+  if (p.splits > 1) {
+    float* ws = p.ws + ((int64_t)z) * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int64_t col = n0 + wn * 64 + j * 32 + lrow;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = m0 + wm * 64 + i * 32 + acc_row(r, lane);
+          if (row < p.M && col < p.N) ws[row * p.N + col] = acc[i][j][r];
+        }
+      }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t col = n0 + wn * 64 + j * 32 + lrow;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * 64 + i * 32 + acc_row(r, lane);
+        if (row < p.M && col < p.N) epilogue_store<T>(p, cofs, bofs, row, col, acc[i][j][r]);
+      }
+    }
+}
+
+template <typename T>
+__global__ void splitk_reduce_kernel(GemmParams p) {
+  const int64_t total = p.M * p.N;
+  const int64_t bidx = blockIdx.y;
+  const int64_t b0 = bidx / p.batch1, b1 = bidx % p.batch1;
+  const int64_t cofs = b0 * p.sc0 + b1 * p.sc1;
+  const int64_t bofs = b0 * p.sbias0 + b1 * p.sbias1;
+  const float* ws = p.ws + bidx * p.splits * total;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = 0.0f;
+    for (int s = 0; s < p.splits; ++s) v += ws[s * total + i];
+    epilogue_store<T>(p, cofs, bofs, i / p.N, i % p.N, v);
+  }
+}
+
+template <typename T, bool AK, bool BK_>
+int launch(const GemmParams& p, int64_t nbatch, hipStream_t s) {
+  constexpr int VEC = DT<T>::VEC;
+  constexpr int BKc = 8 * VEC, LDK = BKc + VEC, LDM = 128 + VEC;
+  constexpr int A_ELEMS = AK ? BM * LDK : BKc * LDM;
+  constexpr int B_ELEMS = BK_ ? BN * LDK : BKc * LDM;
+  const size_t lds = 2 * (size_t)(A_ELEMS + B_ELEMS) * sizeof(T);
+  static bool attr_set = false;  // LDS > 64 KiB needs the opt-in attribute (160 KiB/CU on gfx950)
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, AK, BK_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(p.tiles_m * p.tiles_n, 1, (unsigned)(nbatch * p.splits));
+  hipLaunchKernelGGL((gemm_kernel<T, AK, BK_>), grid, dim3(NTHREADS), lds, s, p);
+  return cst_check_launch("cst_gemm");
+}
+
+int choose_splits(const cst_gemm_desc* d) {
+  if (d->split_k > 1) return d->split_k;
+  if (d->split_k == 0 || d->split_k == 1) return 1;
+  const int64_t tiles = cst_ceil_div(d->M, BM) * cst_ceil_div(d->N, BN) * d->batch0 * d->batch1;
+  const int bk = d->dtype == CST_BF16 ? 64 : 32;
+  const int64_t ktiles = cst_ceil_div(d->K, bk);
+  if (tiles >= 256 || ktiles < 16) return 1;
+  int64_t s = cst_ceil_div(512, tiles);
+  if (s > ktiles / 8) s = ktiles / 8;
+  if (s > 32) s = 32;
+  return s < 1 ? 1 : (int)s;
+}
+
+}  // namespace
+
+extern "C" int64_t cst_gemm_workspace(const cst_gemm_desc* d) {
+  const int s = choose_splits(d);
+  if (s <= 1) return 0;
+  return (int64_t)s * d->M * d->N * d->batch0 * d->batch1 * (int64_t)sizeof(float);
+}
+
+extern "C" int cst_gemm(const cst_gemm_desc* d, cst_stream stream) {
+  CST_REQUIRE(d && d->A && d->B && d->C, "cst_gemm: null operand");
+  CST_REQUIRE(d->dtype == CST_F32 || d->dtype == CST_BF16, "cst_gemm: bad dtype %d", d->dtype);
+  CST_REQUIRE(d->c_dtype == d->dtype || d->c_dtype == CST_F32, "cst_gemm: c_dtype must be dtype or f32");
+  CST_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "cst_gemm: empty problem M=%lld N=%lld K=%lld", (long long)d->M,
+              (long long)d->N, (long long)d->K);
+  const int vec = d->dtype == CST_BF16 ? 8 : 4;
+  if (d->a_kmajor) CST_REQUIRE(d->K % vec == 0 && d->lda % vec == 0, "cst_gemm: k-major A needs K,lda %% %d == 0 (K=%lld lda=%lld)", vec, (long long)d->K, (long long)d->lda);
+  else CST_REQUIRE(d->M % vec == 0 && d->lda % vec == 0, "cst_gemm: mn-major A needs M,lda %% %d == 0 (M=%lld lda=%lld)", vec, (long long)d->M, (long long)d->lda);
+  if (d->b_kmajor) CST_REQUIRE(d->K % vec == 0 && d->ldb % vec == 0, "cst_gemm: k-major B needs K,ldb %% %d == 0 (K=%lld ldb=%lld)", vec, (long long)d->K, (long long)d->ldb);
+  else CST_REQUIRE(d->N % vec == 0 && d->ldb % vec == 0, "cst_gemm: mn-major B needs N,ldb %% %d == 0 (N=%lld ldb=%lld)", vec, (long long)d->N, (long long)d->ldb);
+  CST_REQUIRE(d->a_seg % vec == 0 && d->b_seg % vec == 0 && d->a_seg_stride % vec == 0 && d->b_seg_stride % vec == 0,
+              "cst_gemm: segment sizes must be multiples of %d", vec);
+  CST_REQUIRE(((uintptr_t)d->A % 16 == 0) && ((uintptr_t)d->B % 16 == 0), "cst_gemm: A/B must be 16-byte aligned");
+  CST_REQUIRE(d->sa0 % vec == 0 && d->sa1 % vec == 0 && d->sb0 % vec == 0 && d->sb1 % vec == 0, "cst_gemm: batch strides of A/B must be multiples of %d", vec);
+  CST_REQUIRE(d->batch0 >= 1 && d->batch1 >= 1, "cst_gemm: batch counts must be >= 1");
+  CST_REQUIRE(!d->dact || d->aux_in, "cst_gemm: dact needs aux_in");
+
+  GemmParams p;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.A = d->A; p.lda = d->lda; p.a_seg = d->a_seg; p.a_seg_stride = d->a_seg_stride;
+  p.B = d->B; p.ldb = d->ldb; p.b_seg = d->b_seg; p.b_seg_stride = d->b_seg_stride;
+  p.C = d->C; p.ldc = d->ldc;
+  p.bias = d->bias; p.bias_mode = d->bias ? d->bias_mode : CST_BIAS_NONE; p.sbias0 = d->sbias0; p.sbias1 = d->sbias1;
+  p.act = d->act;
+  p.aux_out = d->aux_out; p.ld_aux_out = d->ld_aux_out;
+  p.dact = d->dact; p.aux_in = d->aux_in; p.ld_aux_in = d->ld_aux_in;
+  p.resid = d->resid; p.ld_resid = d->ld_resid;
+  p.alpha = d->alpha;
+  p.batch1 = d->batch1;
+  p.sa0 = d->sa0; p.sa1 = d->sa1; p.sb0 = d->sb0; p.sb1 = d->sb1; p.sc0 = d->sc0; p.sc1 = d->sc1;
+  p.c_f32 = (d->c_dtype == CST_F32 && d->dtype != CST_F32) ? 1 : 0;
+  if (d->dtype == CST_F32) p.c_f32 = 0;  // T == float already stores fp32
+  p.tiles_m = (int)cst_ceil_div(d->M, BM);
+  p.tiles_n = (int)cst_ceil_div(d->N, BN);
+  p.splits = choose_splits(d);
+  p.ws = nullptr;
+  const int64_t nbatch = d->batch0 * d->batch1;
+  CST_REQUIRE((int64_t)p.tiles_m * p.tiles_n < (1ll << 31) && nbatch * p.splits < 65536, "cst_gemm: grid too large");
+  if (p.splits > 1) {
+    const int64_t need = (int64_t)p.splits * d->M * d->N * nbatch * (int64_t)sizeof(float);
+    if (!d->workspace || d->workspace_bytes < need) {
+      cst_set_error("cst_gemm: split_k=%d needs %lld workspace bytes, got %lld", p.splits, (long long)need,
+                    (long long)d->workspace_bytes);
+      return CST_ERR_WORKSPACE;
+    }
+    p.ws = (float*)d->workspace;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const double flops = 2.0 * (double)d->M * (double)d->N * (double)d->K * (double)nbatch;
+  const double esz = (double)cst_dtype_size(d->dtype);
+  const double bytes = ((double)d->M * d->K + (double)d->N * d->K) * esz * nbatch + (double)d->M * d->N * cst_dtype_size(d->c_dtype) * nbatch;
+  CstProfScope prof(CST_K_GEMM, s, flops, bytes);
+  int rc;
+  const bool ak = d->a_kmajor != 0, bk = d->b_kmajor != 0;
+#define CST_GEMM_DISPATCH(T)                                         \
+  (ak ? (bk ? launch<T, true, true>(p, nbatch, s) : launch<T, true, false>(p, nbatch, s)) \
+      : (bk ? launch<T, false, true>(p, nbatch, s) : launch<T, false, false>(p, nbatch, s)))
+  if (d->dtype == CST_BF16) rc = CST_GEMM_DISPATCH(bf16_t);
+  else rc = CST_GEMM_DISPATCH(float);
+#undef CST_GEMM_DISPATCH
+  if (rc != CST_OK) return rc;
+  if (p.splits > 1) {
+    const int64_t total = d->M * d->N;
+    int blocks = (int)(cst_ceil_div(total, 256) < 2048 ? cst_ceil_div(total, 256) : 2048);
+    dim3 grid(blocks, (unsigned)nbatch);
+    if (d->dtype == CST_BF16) hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<float>, grid, dim3(256), 0, s, p);
+    rc = cst_check_launch("cst_gemm split-k reduce");
+  }
+  return rc;
+}

@@ -1,0 +1,201 @@
+// layernorm.hip — LayerNorm forward/backward for gfx950 (HBM-bound; one wave64 per row,
+// 16-byte vector loads, wave-level shuffles for the row statistics, fp32 statistics).
+// Replaces torch.nn.LayerNorm / apex FusedLayerNorm at fairseq/modules/layer_norm.py:11-35.
+// Fusions: optional residual add in front (s = x + res, optionally written back) and an optional
+// extra upstream gradient added to dx in backward (the residual branch), so a pre-/post-norm
+// Transformer block needs no separate add kernels.
+#include "cst_common.h"
+
+namespace {
+
+constexpr int LN_MAXV = 4;       // 8-element vectors per lane -> cols <= 2048
+constexpr int LN_WAVES = 4;      // rows per block iteration
+
+template <typename T>
+__global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(const T* x, const T* res, const T* gamma, const T* beta,
+                                                              T* y, T* sum_out, float* mean, float* rstd,
+                                                              int64_t rows, int cols, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nvec = cols / 8;
+  for (int64_t row = (int64_t)blockIdx.x * LN_WAVES + wave; row < rows; row += (int64_t)gridDim.x * LN_WAVES) {
+    float v[LN_MAXV][8];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int vi = lane + 64 * i;
+      if (vi < nvec) {
+        load8(x + row * cols + vi * 8, v[i]);
+        if (res) {
+          float r[8];
+          load8(res + row * cols + vi * 8, r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[i][e] += r[e];
+        }
+        if (sum_out) store8(sum_out + row * cols + vi * 8, v[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[i][e];
+      }
+    }
+    const float mu = wave_sum(s) / (float)cols;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i)
+      if (lane + 64 * i < nvec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mu; q += d * d; }
+      }
+    const float rs = rsqrtf(wave_sum(q) / (float)cols + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int vi = lane + 64 * i;
+      if (vi < nvec) {
+        float g[8], b[8], o[8];
+        load8(gamma + vi * 8, g);
+        load8(beta + vi * 8, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mu) * rs * g[e] + b[e];
+        store8(y + row * cols + vi * 8, o);
+      }
+    }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma;  partial dgamma/dbeta per block.
+template <typename T>
+__global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(const T* dy, const T* s, const T* gamma, const float* mean,
+                                                              const float* rstd, const T* dres, T* dx, float* part,
+                                                              int64_t rows, int cols) {
+  __shared__ float red[LN_WAVES][64 * 8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nvec = cols / 8;
+  float dg[LN_MAXV][8], db[LN_MAXV][8], gm[LN_MAXV][8];
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dg[i][e] = 0.0f; db[i][e] = 0.0f; gm[i][e] = 0.0f; }
+    if (lane + 64 * i < nvec) load8(gamma + (lane + 64 * i) * 8, gm[i]);
+  }
+  for (int64_t row = (int64_t)blockIdx.x * LN_WAVES + wave; row < rows; row += (int64_t)gridDim.x * LN_WAVES) {
+    const float mu = mean[row], rs = rstd[row];
+    float g[LN_MAXV][8], xh[LN_MAXV][8];
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int vi = lane + 64 * i;
+      if (vi < nvec) {
+        float d[8], xs[8];
+        load8(dy + row * cols + vi * 8, d);
+        load8(s + row * cols + vi * 8, xs);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[i][e] = (xs[e] - mu) * rs;
+          g[i][e] = d[e] * gm[i][e];
+          s1 += g[i][e];
+          s2 += g[i][e] * xh[i][e];
+          dg[i][e] += d[e] * xh[i][e];
+          db[i][e] += d[e];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)cols;
+    s2 = wave_sum(s2) / (float)cols;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int vi = lane + 64 * i;
+      if (vi < nvec) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rs * (g[i][e] - s1 - xh[i][e] * s2);
+        if (dres) {
+          float r[8];
+          load8(dres + row * cols + vi * 8, r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += r[e];
+        }
+        store8(dx + row * cols + vi * 8, o);
+      }
+    }
+  }
+  // block reduction of the per-wave partials, one vector slot at a time
+  float* pg = part + (int64_t)blockIdx.x * 2 * cols;
+  float* pb = pg + cols;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    for (int pass = 0; pass < 2; ++pass) {
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[wave][lane * 8 + e] = pass ? db[i][e] : dg[i][e];
+      __syncthreads();
+      if (wave == 0 && lane + 64 * i < nvec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float a = 0.0f;
+#pragma unroll
+          for (int w = 0; w < LN_WAVES; ++w) a += red[w][lane * 8 + e];
+          (pass ? pb : pg)[(lane + 64 * i) * 8 + e] = a;
+        }
+      }
+    }
+  }
+}
+
+__global__ void ln_bwd_reduce_kernel(const float* part, float* dgamma, float* dbeta, int nblocks, int cols) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float a = 0.0f, b = 0.0f;
+  for (int i = 0; i < nblocks; ++i) {
+    a += part[(int64_t)i * 2 * cols + c];
+    b += part[(int64_t)i * 2 * cols + cols + c];
+  }
+  dgamma[c] = a;
+  dbeta[c] = b;
+}
+
+int ln_blocks(int64_t rows) {
+  int64_t b = cst_ceil_div(rows, LN_WAVES);
+  return (int)(b < 1024 ? b : 1024);
+}
+
+}  // namespace
+
+extern "C" int cst_layernorm_fwd(const void* x, const void* res, const void* gamma, const void* beta, void* y,
+                                 void* sum_out, float* mean, float* rstd, int64_t rows, int64_t cols, float eps,
+                                 int dtype, cst_stream stream) {
+  CST_REQUIRE(x && gamma && beta && y && mean && rstd, "cst_layernorm_fwd: null tensor");
+  CST_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 8 * 64 * LN_MAXV, "cst_layernorm_fwd: cols=%lld must be a multiple of 8 and <= %d", (long long)cols, 8 * 64 * LN_MAXV);
+  hipStream_t s = (hipStream_t)stream;
+  const double bytes = (double)rows * cols * cst_dtype_size(dtype) * (2.0 + (res ? 1.0 : 0.0) + (sum_out ? 1.0 : 0.0));
+  CstProfScope prof(CST_K_LAYERNORM, s, 0.0, bytes);
+  dim3 grid(ln_blocks(rows));
+  if (dtype == CST_BF16)
+    hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, dim3(LN_WAVES * 64), 0, s, (const bf16_t*)x, (const bf16_t*)res, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y, (bf16_t*)sum_out, mean, rstd, rows, (int)cols, eps);
+  else if (dtype == CST_F32)
+    hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, dim3(LN_WAVES * 64), 0, s, (const float*)x, (const float*)res, (const float*)gamma, (const float*)beta, (float*)y, (float*)sum_out, mean, rstd, rows, (int)cols, eps);
+  else CST_REQUIRE(false, "cst_layernorm_fwd: bad dtype %d", dtype);
+  return cst_check_launch("cst_layernorm_fwd");
+}
+
+extern "C" int64_t cst_layernorm_bwd_workspace(int64_t rows, int64_t cols) {
+  return (int64_t)ln_blocks(rows) * 2 * cols * (int64_t)sizeof(float);
+}
+
+extern "C" int cst_layernorm_bwd(const void* dy, const void* sx, const void* gamma, const float* mean, const float* rstd,
+                                 const void* dres, void* dx, float* dgamma, float* dbeta, void* workspace, int64_t rows,
+                                 int64_t cols, int dtype, cst_stream stream) {
+  CST_REQUIRE(dy && sx && gamma && mean && rstd && dx && dgamma && dbeta && workspace, "cst_layernorm_bwd: null tensor");
+  CST_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 8 * 64 * LN_MAXV, "cst_layernorm_bwd: cols=%lld must be a multiple of 8 and <= %d", (long long)cols, 8 * 64 * LN_MAXV);
+  hipStream_t s = (hipStream_t)stream;
+  const double bytes = (double)rows * cols * cst_dtype_size(dtype) * (3.0 + (dres ? 1.0 : 0.0));
+  CstProfScope prof(CST_K_LAYERNORM, s, 0.0, bytes);
+  const int nb = ln_blocks(rows);
+  if (dtype == CST_BF16)
+    hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(nb), dim3(LN_WAVES * 64), 0, s, (const bf16_t*)dy, (const bf16_t*)sx, (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, (float*)workspace, rows, (int)cols);
+  else if (dtype == CST_F32)
+    hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(LN_WAVES * 64), 0, s, (const float*)dy, (const float*)sx, (const float*)gamma, mean, rstd, (const float*)dres, (float*)dx, (float*)workspace, rows, (int)cols);
+  else CST_REQUIRE(false, "cst_layernorm_bwd: bad dtype %d", dtype);
+  int rc = cst_check_launch("cst_layernorm_bwd");
+  if (rc != CST_OK) return rc;
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)cst_ceil_div(cols, 256)), dim3(256), 0, s, (const float*)workspace, dgamma, dbeta, nb, (int)cols);
+  return cst_check_launch("cst_layernorm_bwd reduce");
+}

@@ -1,0 +1,278 @@
+"""Raw (non-autograd) wrappers: torch tensors in, C-ABI calls out.  Torch only supplies device
+memory and the current HIP stream here; every arithmetic op is a kernel of libcst_hip.so."""
+import ctypes
+
+import torch
+
+from . import lib as L
+
+_ws = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only scratch buffer, stream-ordered reuse (all product kernels run on the current stream)."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    t = _ws.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = t
+    return t
+
+
+def _2d(t):
+    assert t.dim() == 2 and t.stride(1) == 1, "expected a row-major 2-D tensor, got %s / %s" % (tuple(t.shape), t.stride())
+    return t
+
+
+# ------------------------------------------------------------------------------------------------
+def gemm(A, B, C, M, N, K, *, a_kmajor, b_kmajor, lda, ldb, ldc, bias=None, bias_mode=L.BIAS_COL, act=L.ACT_NONE,
+         aux_out=None, ld_aux_out=0, dact=L.ACT_NONE, aux_in=None, ld_aux_in=0, resid=None, ld_resid=0, alpha=1.0,
+         batch0=1, batch1=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), sbias=(0, 0), a_seg=0, a_seg_stride=0, b_seg=0,
+         b_seg_stride=0, split_k=-1, a_off=0, b_off=0, c_off=0):
+    """C = epilogue(alpha * Aop @ Bop); see include/cst.h.  Offsets *_off are in elements."""
+    lib = L.load()
+    d = L.GemmDesc()
+    d.dtype = L.dtype_code(A.dtype)
+    assert B.dtype == A.dtype, "A/B dtype mismatch"
+    d.c_dtype = L.dtype_code(C.dtype)
+    d.a_kmajor, d.b_kmajor = int(a_kmajor), int(b_kmajor)
+    d.M, d.N, d.K = M, N, K
+    es = A.element_size()
+    d.A = A.data_ptr() + a_off * es
+    d.lda, d.a_seg, d.a_seg_stride = lda, a_seg, a_seg_stride
+    d.B = B.data_ptr() + b_off * es
+    d.ldb, d.b_seg, d.b_seg_stride = ldb, b_seg, b_seg_stride
+    d.C = C.data_ptr() + c_off * C.element_size()
+    d.ldc = ldc
+    if bias is not None:
+        assert bias.dtype == A.dtype
+        d.bias, d.bias_mode = bias.data_ptr(), bias_mode
+    else:
+        d.bias, d.bias_mode = None, L.BIAS_NONE
+    d.sbias0, d.sbias1 = sbias
+    d.act = act
+    d.aux_out = None if aux_out is None else aux_out.data_ptr() + c_off * es
+    d.ld_aux_out = ld_aux_out
+    d.dact = dact
+    d.aux_in = None if aux_in is None else aux_in.data_ptr() + c_off * es
+    d.ld_aux_in = ld_aux_in
+    d.resid = None if resid is None else resid.data_ptr() + c_off * es
+    d.ld_resid = ld_resid
+    d.alpha = alpha
+    d.batch0, d.batch1 = batch0, batch1
+    d.sa0, d.sa1 = sa
+    d.sb0, d.sb1 = sb
+    d.sc0, d.sc1 = sc
+    d.split_k = split_k
+    need = lib.cst_gemm_workspace(ctypes.byref(d))
+    if need > 0:
+        ws = workspace(need, A.device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    else:
+        d.workspace, d.workspace_bytes = None, 0
+    L.check(lib.cst_gemm(ctypes.byref(d), L.stream_ptr()), "cst_gemm")
+    return C
+
+
+def layernorm_fwd(x, res, gamma, beta, eps, want_sum=False):
+    x = _2d(x)
+    rows, cols = x.shape
+    y = torch.empty_like(x)
+    s = torch.empty_like(x) if (want_sum and res is not None) else None
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    L.check(L.load().cst_layernorm_fwd(L.ptr(x), L.ptr(res), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(s), L.ptr(mean),
+                                       L.ptr(rstd), rows, cols, eps, L.dtype_code(x.dtype), L.stream_ptr()), "cst_layernorm_fwd")
+    return y, s, mean, rstd
+
+
+def layernorm_bwd(dy, s, gamma, mean, rstd, dres=None):
+    dy, s = _2d(dy), _2d(s)
+    rows, cols = s.shape
+    lib = L.load()
+    dx = torch.empty_like(s)
+    dg = torch.empty(cols, dtype=torch.float32, device=s.device)
+    db = torch.empty(cols, dtype=torch.float32, device=s.device)
+    ws = workspace(lib.cst_layernorm_bwd_workspace(rows, cols), s.device)
+    L.check(lib.cst_layernorm_bwd(L.ptr(dy), L.ptr(s), L.ptr(gamma), L.ptr(mean), L.ptr(rstd), L.ptr(dres), L.ptr(dx), L.ptr(dg),
+                                  L.ptr(db), L.ptr(ws), rows, cols, L.dtype_code(s.dtype), L.stream_ptr()), "cst_layernorm_bwd")
+    return dx, dg, db
+
+
+def _bhtd_strides(t, layout):
+    """Element strides (sb, sh, st) of a [B,T,H*D]-shaped ("bthd") or [T,B,H*D] ("tbhd") activation; d contiguous."""
+    assert t.stride(-1) == 1
+    if layout == "bt":  # tensor is [B, T, C]
+        return t.stride(0), None, t.stride(1)
+    return t.stride(1), None, t.stride(0)  # [T, B, C]
+
+
+def attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, layout_q="bt", layout_kv="bt"):
+    """q,o: [B,Tq,H*D] (layout "bt") or [Tq,B,H*D] ("tb"); k,v likewise with Tk.  Head h at channel offset h*D."""
+    d = L.AttnDesc()
+    d.dtype = L.dtype_code(q.dtype)
+    if layout_q == "bt":
+        B, Tq = q.shape[0], q.shape[1]
+    else:
+        Tq, B = q.shape[0], q.shape[1]
+    Tk = k.shape[1] if layout_kv == "bt" else k.shape[0]
+    d.B, d.H, d.Tq, d.Tk, d.D = B, H, Tq, Tk, D
+
+    def st(t, lay):
+        sb, _, stt = _bhtd_strides(t, lay)
+        return sb, D, stt
+
+    d.Q = q.data_ptr(); d.q_sb, d.q_sh, d.q_st = st(q, layout_q)
+    d.K = k.data_ptr(); d.k_sb, d.k_sh, d.k_st = st(k, layout_kv)
+    d.V = v.data_ptr(); d.v_sb, d.v_sh, d.v_st = st(v, layout_kv)
+    d.O = o.data_ptr(); d.o_sb, d.o_sh, d.o_st = st(o, layout_q)
+    d.lse = lse.data_ptr()
+    if kpm is not None:
+        assert kpm.dtype == torch.uint8 and kpm.stride(1) == 1 and kpm.shape == (B, Tk)
+        d.key_padding_mask, d.kpm_stride = kpm.data_ptr(), kpm.stride(0)
+    else:
+        d.key_padding_mask, d.kpm_stride = None, 0
+    d.causal, d.scale = int(causal), scale
+    return d
+
+
+def attn_fwd(q, k, v, H, D, kpm, causal, scale, layout_q="bt", layout_kv="bt"):
+    o = torch.empty_like(q)
+    if layout_q == "bt":
+        B, Tq = q.shape[0], q.shape[1]
+    else:
+        Tq, B = q.shape[0], q.shape[1]
+    lse = torch.empty(B, H, Tq, dtype=torch.float32, device=q.device)
+    d = attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, layout_q, layout_kv)
+    L.check(L.load().cst_attn_fwd(ctypes.byref(d), L.stream_ptr()), "cst_attn_fwd")
+    return o, lse
+
+
+def attn_bwd(do, q, k, v, o, lse, H, D, kpm, causal, scale, layout_q="bt", layout_kv="bt"):
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    delta = torch.empty_like(lse)
+    d = attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, layout_q, layout_kv)
+
+    def st(t, lay):
+        sb, _, stt = _bhtd_strides(t, lay)
+        return sb, D, stt
+
+    d.dO = do.data_ptr(); d.do_sb, d.do_sh, d.do_st = st(do, layout_q)
+    d.dQ = dq.data_ptr(); d.dq_sb, d.dq_sh, d.dq_st = st(dq, layout_q)
+    d.dK = dk.data_ptr(); d.dk_sb, d.dk_sh, d.dk_st = st(dk, layout_kv)
+    d.dV = dv.data_ptr(); d.dv_sb, d.dv_sh, d.dv_st = st(dv, layout_kv)
+    d.delta = delta.data_ptr()
+    L.check(L.load().cst_attn_bwd(ctypes.byref(d), L.stream_ptr()), "cst_attn_bwd")
+    return dq, dk, dv
+
+
+def conv0_fwd(wav, w, gamma, beta, k, stride, eps=1e-5):
+    """wav [B,S] fp32; w [C,k]; -> y [B,L,C] channels-last, (mean, rstd, gram) saved for backward."""
+    assert wav.dtype == torch.float32 and wav.is_contiguous()
+    B, S = wav.shape
+    C = w.shape[0]
+    Lo = (S - k) // stride + 1
+    y = torch.empty(B, Lo, C, dtype=w.dtype, device=wav.device)
+    mean = torch.empty(B, C, dtype=torch.float32, device=wav.device)
+    rstd = torch.empty(B, C, dtype=torch.float32, device=wav.device)
+    gram = torch.empty(B, k * k + k, dtype=torch.float32, device=wav.device)
+    L.check(L.load().cst_conv0_gn_gelu_fwd(L.ptr(wav), L.ptr(w), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(mean), L.ptr(rstd),
+                                           L.ptr(gram), B, S, C, k, stride, eps, L.dtype_code(w.dtype), L.stream_ptr()),
+            "cst_conv0_gn_gelu_fwd")
+    return y, mean, rstd, gram
+
+
+def conv0_bwd(dy, wav, w, gamma, beta, mean, rstd, gram, k, stride):
+    B, S = wav.shape
+    C = w.shape[0]
+    lib = L.load()
+    dw = torch.empty(C, k, dtype=torch.float32, device=wav.device)
+    dg = torch.empty(C, dtype=torch.float32, device=wav.device)
+    db = torch.empty(C, dtype=torch.float32, device=wav.device)
+    ws = workspace(lib.cst_conv0_bwd_workspace(B, C, k), wav.device)
+    L.check(lib.cst_conv0_gn_gelu_bwd(L.ptr(dy), L.ptr(wav), L.ptr(w), L.ptr(gamma), L.ptr(beta), L.ptr(mean), L.ptr(rstd),
+                                      L.ptr(gram), L.ptr(dw), L.ptr(dg), L.ptr(db), L.ptr(ws), B, S, C, k, stride,
+                                      L.dtype_code(w.dtype), L.stream_ptr()), "cst_conv0_gn_gelu_bwd")
+    return dw, dg, db
+
+
+def glu_fwd(z):
+    z = _2d(z)
+    rows, C2 = z.shape
+    y = torch.empty(rows, C2 // 2, dtype=z.dtype, device=z.device)
+    L.check(L.load().cst_glu_fwd(L.ptr(z), L.ptr(y), rows, C2 // 2, L.dtype_code(z.dtype), L.stream_ptr()), "cst_glu_fwd")
+    return y
+
+
+def glu_bwd(dy, z):
+    dy, z = _2d(dy), _2d(z)
+    rows, C2 = z.shape
+    dz = torch.empty_like(z)
+    L.check(L.load().cst_glu_bwd(L.ptr(dy), L.ptr(z), L.ptr(dz), rows, C2 // 2, L.dtype_code(z.dtype), L.stream_ptr()), "cst_glu_bwd")
+    return dz
+
+
+def act_bwd(dy, z, act):
+    assert dy.is_contiguous() and z.is_contiguous()
+    dx = torch.empty_like(z)
+    L.check(L.load().cst_act_bwd(L.ptr(dy), L.ptr(z), L.ptr(dx), z.numel(), act, L.dtype_code(z.dtype), L.stream_ptr()), "cst_act_bwd")
+    return dx
+
+
+def act_fwd(x, act):
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    L.check(L.load().cst_act_fwd(L.ptr(x), L.ptr(y), x.numel(), act, L.dtype_code(x.dtype), L.stream_ptr()), "cst_act_fwd")
+    return y
+
+
+def colsum(x):
+    x = _2d(x)
+    rows, cols = x.shape
+    out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    L.check(L.load().cst_colsum(L.ptr(x), x.stride(0), L.ptr(out), rows, cols, L.dtype_code(x.dtype), L.stream_ptr()), "cst_colsum")
+    return out
+
+
+def col2im1d(dcol, z, B, Lin, Lout, C, k, stride, pad, dact):
+    dx = torch.empty(B, Lin, C, dtype=dcol.dtype, device=dcol.device)
+    L.check(L.load().cst_col2im1d(L.ptr(dcol), L.ptr(z), L.ptr(dx), B, Lin, Lout, C, k, stride, pad, dact,
+                                  L.dtype_code(dcol.dtype), L.stream_ptr()), "cst_col2im1d")
+    return dx
+
+
+def mask_rows(x, mask_u8):
+    x = _2d(x)
+    y = torch.empty_like(x)
+    L.check(L.load().cst_mask_rows(L.ptr(x), L.ptr(mask_u8), L.ptr(y), x.shape[0], x.shape[1], L.dtype_code(x.dtype),
+                                   L.stream_ptr()), "cst_mask_rows")
+    return y
+
+
+def ls_ce_fwd(logits, target, eps, pad):
+    logits = _2d(logits)
+    rows, V = logits.shape
+    out2 = torch.zeros(2, dtype=torch.float32, device=logits.device)
+    lse = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    L.check(L.load().cst_ls_ce_fwd(L.ptr(logits), L.ptr(target), L.ptr(out2), L.ptr(lse), rows, V, eps, pad,
+                                   L.dtype_code(logits.dtype), L.stream_ptr()), "cst_ls_ce_fwd")
+    return out2, lse
+
+
+def ls_ce_bwd(logits, target, lse, gscale, eps, pad):
+    logits = _2d(logits)
+    rows, V = logits.shape
+    d = torch.empty_like(logits)
+    L.check(L.load().cst_ls_ce_bwd(L.ptr(logits), L.ptr(target), L.ptr(lse), L.ptr(gscale), L.ptr(d), rows, V, eps, pad,
+                                   L.dtype_code(logits.dtype), L.stream_ptr()), "cst_ls_ce_bwd")
+    return d
+
+
+def sumsq(x, out):
+    L.check(L.load().cst_sumsq(L.ptr(x), x.numel(), L.ptr(out), L.dtype_code(x.dtype), L.stream_ptr()), "cst_sumsq")
+
+
+def adam_step(master, m, v, grad, param, lr, beta1, beta2, eps, wd, step, grad_scale):
+    L.check(L.load().cst_adam_step(L.ptr(master), L.ptr(m), L.ptr(v), L.ptr(grad), L.ptr(param), master.numel(), lr, beta1, beta2,
+                                   eps, wd, step, L.ptr(grad_scale), L.dtype_code(grad.dtype), L.dtype_code(param.dtype),
+                                   L.stream_ptr()), "cst_adam_step")

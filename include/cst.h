@@ -1,0 +1,232 @@
+/* cst.h — C ABI of libcst_hip.so: the MI355X (gfx950) hot path of Chimera-ST.
+ *
+ * The reference (Glaciohound/Chimera-ST, a fairseq fork) has NO C ABI on this path: its seam is
+ * nn.Module.forward / torch.autograd.Function calling PyTorch ATen.  Each entry
+ * point below therefore replaces an ATen call site of the reference; the file:line it replaces
+ * is cited per function (paths relative to the reference root).
+ *
+ * Conventions (SURVEY.md §8b "Native (C-ABI) layer"):
+ *   - plain C: raw DEVICE pointers + explicit int64 sizes/strides (in ELEMENTS) + dtype enum +
+ *     a hipStream_t passed as void*; no torch types.
+ *   - ownership: every buffer (inputs, outputs, workspaces, saved-for-backward) is allocated and
+ *     owned by the caller; the library never frees or retains a pointer past return.
+ *   - errors: int return, 0 = ok, negative = cst_status; text via cst_last_error() (thread-local).
+ *     Nothing throws across the boundary.
+ *   - threading: re-entrant; no global mutable state except the optional profiling table.
+ *   - all kernels are asynchronous on the given stream.
+ *   - accumulation is always fp32; `dtype` is the storage type of activations/weights.
+ */
+#ifndef CST_H
+#define CST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { CST_F32 = 0, CST_BF16 = 1 } cst_dtype;
+
+typedef enum {
+  CST_OK = 0,
+  CST_ERR_BAD_ARG = -1,     /* shape / stride / alignment / dtype not supported */
+  CST_ERR_LAUNCH = -2,      /* hipLaunch / hipGetLastError failure */
+  CST_ERR_WORKSPACE = -3,   /* caller workspace too small */
+  CST_ERR_UNSUPPORTED = -4
+} cst_status;
+
+typedef void* cst_stream; /* hipStream_t */
+
+const char* cst_last_error(void);
+int cst_version(void);            /* ABI version, bumps on any signature change */
+int cst_device_arch_ok(void);     /* 1 if the current device is gfx950, 0 otherwise */
+
+/* ------------------------------------------------------------------------------------------
+ * Profiling table (bench.py roofline leg): when enabled every launch below is bracketed with
+ * hipEvents on its own stream and its algorithmic flops/bytes are recorded per kernel class.
+ * ------------------------------------------------------------------------------------------ */
+typedef enum {
+  CST_K_GEMM = 0, CST_K_ATTN_FWD, CST_K_ATTN_BWD, CST_K_LAYERNORM, CST_K_CONV0, CST_K_ELEMENTWISE,
+  CST_K_LOSS, CST_K_OPTIM, CST_K_NUM
+} cst_kernel_class;
+void cst_prof_enable(int on);     /* clears the table when switching on */
+/* synchronises the recorded events; returns launches; outputs total ms / flops / bytes */
+int64_t cst_prof_query(int kernel_class, double* total_ms, double* flops, double* bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm (eps, affine) — replaces torch.nn.LayerNorm at fairseq/modules/layer_norm.py:30-35
+ * (apex FusedLayerNorm seam, :11-28) and Fp32LayerNorm (:38-50).
+ *   s = x (+ res);  y = (s - mean) * rstd * gamma + beta
+ * x,res,y,sum_out: [rows, cols] row-major contiguous; gamma/beta [cols]; mean/rstd fp32 [rows].
+ * res and sum_out may be NULL.  cols % 8 == 0, cols <= 2048.
+ * ------------------------------------------------------------------------------------------ */
+int cst_layernorm_fwd(const void* x, const void* res, const void* gamma, const void* beta,
+                      void* y, void* sum_out, float* mean, float* rstd,
+                      int64_t rows, int64_t cols, float eps, int dtype, cst_stream stream);
+/* dx = LN backward w.r.t. s (s = x + res is what `s` points to); dgamma/dbeta fp32 [cols]
+ * (overwritten).  dres (optional extra upstream gradient on s, e.g. the residual branch) is
+ * added into dx when non-NULL.  workspace: cst_layernorm_bwd_workspace() bytes. */
+int64_t cst_layernorm_bwd_workspace(int64_t rows, int64_t cols);
+int cst_layernorm_bwd(const void* dy, const void* s, const void* gamma, const float* mean,
+                      const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                      void* workspace, int64_t rows, int64_t cols, int dtype, cst_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM on MFMA tiles — replaces F.linear / nn.Conv1d call sites:
+ *   q/k/v/out projections  modules/multihead_attention.py:205-224,370
+ *   fc1/fc2                modules/transformer_layer.py:144-148,404-408; models/wav2vec/wav2vec2.py:949-953
+ *   conv layers 1..6       models/wav2vec/wav2vec2.py:707 (implicit GEMM on channels-last rows)
+ *   pos_conv               models/wav2vec/wav2vec2.py:773-779 (grouped; segmented-K implicit GEMM)
+ *   subsampler convs       models/speech_to_text/s2t_transformer.py:53-74
+ *   post_extract_proj      models/wav2vec/wav2vec2.py:550-551
+ *   vocab projection       models/transformer.py:830-836
+ * and their autograd backward GEMMs.
+ *
+ *   C[M,N] = epilogue( alpha * sum_k Aop[m,k] * Bop[k,n] )
+ * Operand storage ("k-major" = the reduction index is the contiguous one):
+ *   a_kmajor=1: Aop[m,k] at A[m*lda + segaddr_a(k)]      a_kmajor=0: Aop[m,k] at A[k*lda + segaddr_a(m)]
+ *   b_kmajor=1: Bop[k,n] at B[n*ldb + segaddr_b(k)]      b_kmajor=0: Bop[k,n] at B[k*ldb + segaddr_b(n)]
+ *   segaddr(c) = (c / seg) * seg_stride + c % seg   (seg = 0 means plain c).  seg % 8 == 0.
+ * lda/ldb may be SMALLER than the contiguous extent (overlapping rows = implicit-GEMM conv1d).
+ * Epilogue, in order:  v = alpha*acc;  v += bias;  [aux_out = v];  v = act(v);
+ *                      [v *= act'(aux_in)];  v += resid;  C = v
+ * Batching: two batch levels (e.g. utterance x group); offsets in elements.
+ * split_k > 1: partial sums go through `workspace` (cst_gemm_workspace bytes) and are reduced
+ * into C by a second kernel (bias/act/resid are applied there).
+ * ------------------------------------------------------------------------------------------ */
+typedef enum { CST_ACT_NONE = 0, CST_ACT_RELU = 1, CST_ACT_GELU = 2 } cst_act;
+typedef enum { CST_BIAS_NONE = 0, CST_BIAS_COL = 1, CST_BIAS_ROW = 2 } cst_bias_mode;
+
+typedef struct {
+  int dtype;              /* storage dtype of A, B, bias, resid, aux (cst_dtype) */
+  int c_dtype;            /* storage dtype of C (cst_dtype; fp32 allowed with bf16 inputs) */
+  int a_kmajor, b_kmajor;
+  int64_t M, N, K;
+  const void* A; int64_t lda, a_seg, a_seg_stride;
+  const void* B; int64_t ldb, b_seg, b_seg_stride;
+  void* C; int64_t ldc;
+  const void* bias; int bias_mode;   /* dtype `dtype`; [N] or [M] */
+  int64_t sbias0, sbias1;            /* batch strides of bias (0 = shared; grouped conv: per group) */
+  int act;                           /* cst_act applied after bias */
+  void* aux_out; int64_t ld_aux_out; /* optional pre-activation copy, dtype `dtype` */
+  int dact;                          /* cst_act whose derivative (at aux_in) multiplies v */
+  const void* aux_in; int64_t ld_aux_in;
+  const void* resid; int64_t ld_resid;
+  float alpha;
+  int64_t batch0, batch1;            /* >= 1 */
+  int64_t sa0, sa1, sb0, sb1, sc0, sc1; /* batch strides (elements) for A, B, C(+aux/resid) */
+  int split_k;                       /* 0/1 = none; >1 explicit; -1 = let the library choose */
+  void* workspace; int64_t workspace_bytes;
+} cst_gemm_desc;
+
+int64_t cst_gemm_workspace(const cst_gemm_desc* d);
+int cst_gemm(const cst_gemm_desc* d, cst_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused attention (flash-style, scores never reach HBM) — replaces
+ * F.multi_head_attention_forward (modules/multihead_attention.py:155-187) and the in-tree
+ * bmm/softmax/bmm branch (:326-361):  O = softmax(scale * Q K^T + masks) V, softmax in fp32.
+ * Modes covered by the descriptor: padded self-attention (key_padding_mask), memory attention
+ * (Tq = M slots, Tk = encoder frames: the column mask of w2v2_transformer_interlingua.py:284-288
+ * is "keys = first Tk columns"), causal decoder self-attention, cross-attention, and
+ * single-query incremental decode (Tq = 1, Tk = cache length).
+ * Q,K,V,O element (b,h,t,d) at ptr[b*sb + h*sh + t*st + d]; D in {32, 64}; d contiguous.
+ * key_padding_mask: uint8 [B, Tk] (1 = pad -> -inf), row stride kpm_stride; may be NULL.
+ * lse: fp32 [B,H,Tq] log-sum-exp of the scaled masked scores (saved for backward).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int dtype;
+  int64_t B, H, Tq, Tk, D;
+  const void* Q; int64_t q_sb, q_sh, q_st;
+  const void* K; int64_t k_sb, k_sh, k_st;
+  const void* V; int64_t v_sb, v_sh, v_st;
+  void* O; int64_t o_sb, o_sh, o_st;
+  float* lse;
+  const uint8_t* key_padding_mask; int64_t kpm_stride;
+  int causal;
+  float scale;
+  /* backward only */
+  const void* dO; int64_t do_sb, do_sh, do_st;
+  void* dQ; int64_t dq_sb, dq_sh, dq_st;
+  void* dK; int64_t dk_sb, dk_sh, dk_st;
+  void* dV; int64_t dv_sb, dv_sh, dv_st;
+  float* delta;  /* fp32 [B,H,Tq] workspace: rowsum(dO * O) */
+} cst_attn_desc;
+
+int cst_attn_fwd(const cst_attn_desc* d, cst_stream stream);
+int cst_attn_bwd(const cst_attn_desc* d, cst_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * wav2vec2 conv layer 0 (Cin = 1) fused with GroupNorm(C groups) and GELU — replaces
+ * Conv1d + Fp32GroupNorm + GELU at models/wav2vec/wav2vec2.py:697-753 (layer 0) and
+ * modules/fp32_group_norm.py:13-25.  The pre-norm conv output is never written to HBM
+ * (two-phase: statistics, then normalise+GELU+store), backward recomputes it from the wave.
+ *   wav [B,S] fp32 (the raw samples as the collater hands them over; never down-cast);
+ *   w [C,k], gamma, beta [C] in `dtype`;  y [B,L,C] channels-last in `dtype`;
+ *   mean,rstd fp32 [B,C];  gram fp32 [B, k*k + k] (per-utterance lag moments, saved for backward);
+ *   L = (S-k)/stride + 1;  k <= 16;  C % 8 == 0.
+ * ------------------------------------------------------------------------------------------ */
+int cst_conv0_gn_gelu_fwd(const float* wav, const void* w, const void* gamma, const void* beta,
+                          void* y, float* mean, float* rstd, float* gram, int64_t B, int64_t S,
+                          int64_t C, int k, int stride, float eps, int dtype, cst_stream stream);
+/* dw [C,k], dgamma [C], dbeta [C] are fp32 and overwritten.
+ * workspace: cst_conv0_bwd_workspace() bytes (zeroed by the call). */
+int64_t cst_conv0_bwd_workspace(int64_t B, int64_t C, int k);
+int cst_conv0_gn_gelu_bwd(const void* dy, const float* wav, const void* w, const void* gamma,
+                          const void* beta, const float* mean, const float* rstd, const float* gram,
+                          float* dw, float* dgamma, float* dbeta, float* workspace,
+                          int64_t B, int64_t S, int64_t C, int k, int stride, int dtype,
+                          cst_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Elementwise / reduction helpers (HBM-bound)
+ * ------------------------------------------------------------------------------------------ */
+/* GLU over the channel pairs (c, c+C) of z [rows, 2C] -> y [rows, C]  (F.glu, s2t_transformer.py:74) */
+int cst_glu_fwd(const void* z, void* y, int64_t rows, int64_t C, int dtype, cst_stream stream);
+int cst_glu_bwd(const void* dy, const void* z, void* dz, int64_t rows, int64_t C, int dtype, cst_stream stream);
+/* dx = dy * act'(z)  (GELU: modules/gelu.py:25; ReLU) */
+int cst_act_bwd(const void* dy, const void* z, void* dx, int64_t n, int act, int dtype, cst_stream stream);
+/* y = act(x) */
+int cst_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, cst_stream stream);
+/* out[c] = sum_r x[r, c]  (bias gradients); out fp32 [cols], overwritten */
+int cst_colsum(const void* x, int64_t ldx, float* out, int64_t rows, int64_t cols, int dtype, cst_stream stream);
+/* gradient of a strided conv1d input from the column-gradient rows of the implicit GEMM:
+ * dx[b, l, c] = sum_{t,j : t*stride + j = l} dcol[b, t, j*C + c];  optionally multiplied by
+ * act'(z[b,l,c]) (GELU of the previous conv layer).  dcol [B, Lout, k*C]; dx/z [B, Lin, C]. */
+int cst_col2im1d(const void* dcol, const void* z, void* dx, int64_t B, int64_t Lin, int64_t Lout,
+                 int64_t C, int k, int stride, int pad, int dact, int dtype, cst_stream stream);
+/* y[r,:] = mask[r] ? 0 : x[r,:]   (x[padding_mask] = 0, wav2vec2.py:820-821) */
+int cst_mask_rows(const void* x, const uint8_t* mask, void* y, int64_t rows, int64_t cols, int dtype, cst_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Label-smoothed cross entropy over vocabulary logits — replaces fp32 log_softmax
+ * (models/fairseq_decoder.py:75-79 -> utils.py:469-473) + label_smoothed_nll_loss
+ * (criterions/label_smoothed_cross_entropy.py:13-30), reduce=True, ignore_index=pad.
+ *   logits [rows, V] (dtype), target int64 [rows];  out fp32[2] += {loss_sum, nll_sum} (caller zeroes);
+ *   lse fp32 [rows] saved for backward.
+ * bwd: dlogits = gscale * d loss / d logits  (gscale = upstream grad of the summed loss).
+ * ------------------------------------------------------------------------------------------ */
+int cst_ls_ce_fwd(const void* logits, const int64_t* target, float* out2, float* lse,
+                  int64_t rows, int64_t V, float eps, int64_t pad_idx, int dtype, cst_stream stream);
+int cst_ls_ce_bwd(const void* logits, const int64_t* target, const float* lse, const float* gscale,
+                  void* dlogits, int64_t rows, int64_t V, float eps, int64_t pad_idx, int dtype,
+                  cst_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimizer path — replaces FP16Optimizer's flat-copy / unscale / clip / Adam / copy-back chain
+ * (optim/fp16_optimizer.py:16-300; utils.py:323-364; optim/adam.py:146-226).
+ * ------------------------------------------------------------------------------------------ */
+/* out[0] += sum(x^2) (fp32 atomics; caller zeroes) */
+int cst_sumsq(const void* x, int64_t n, float* out, int dtype, cst_stream stream);
+/* One fused pass over flat buffers: g = grad * (*grad_scale); Adam (fairseq semantics: bias
+ * correction folded into the step size, decoupled weight decay); master fp32 -> model dtype.
+ * grad_scale is a DEVICE fp32 scalar (e.g. clip coefficient / sample_size) so no host sync. */
+int cst_adam_step(float* master, float* exp_avg, float* exp_avg_sq, const void* grad, void* model_param,
+                  int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  int64_t step, const float* grad_scale, int grad_dtype, int param_dtype,
+                  cst_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CST_H */

@@ -1,0 +1,357 @@
+"""Kernel-level parity on a real MI355X: every C-ABI entry point against a plain torch fp32
+restatement of the same op on the same (dtype-rounded) inputs.
+
+Tolerances (stated per dtype):
+  f32 : rtol 2e-4, atol 2e-4 * scale   (fp32 products, different summation order)
+  bf16: rtol 2e-2, atol 2e-2 * scale   (inputs identical bf16 values; fp32 accumulate; one bf16
+        rounding of the output (2^-8) plus, in attention, bf16 rounding of P / dS like the reference's
+        half-precision path)
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_pkg
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def tol(dt):
+    return (2e-4, 2e-4) if dt == torch.float32 else (2e-2, 2e-2)
+
+
+def check(got, ref, dt, what, scale=None):
+    rt, at = tol(dt)
+    got, ref = got.float(), ref.float()
+    s = float(ref.abs().max()) if scale is None else scale
+    err = (got - ref).abs()
+    bound = at * max(s, 1e-6) + rt * ref.abs()
+    bad = (err > bound)
+    assert not torch.isnan(got).any(), what + ": NaN in output"
+    assert not bad.any(), "%s: max err %.3e (ref max %.3e), %d/%d out of tolerance" % (
+        what, float(err.max()), s, int(bad.sum()), bad.numel())
+
+
+@pytest.fixture(scope="module")
+def K():
+    pkg = load_pkg()
+    from importlib import import_module
+    return import_module("chimera-st_amd.kernels"), import_module("chimera-st_amd.lib")
+
+
+def rnd(*shape, dt, dev="cuda", scale=1.0, seed=None):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed if seed is not None else (hash(shape) % 100000))
+    return (torch.randn(*shape, generator=g) * scale).to(dt).to(dev)
+
+
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("ak,bk", [(1, 1), (1, 0), (0, 1), (0, 0)])
+@pytest.mark.parametrize("M,N,K_", [(128, 128, 64), (304, 200, 136), (1000, 520, 264), (64, 48, 2056)])
+def test_gemm_layouts(K, dt, ak, bk, M, N, K_):
+    k, L = K
+    # asymmetric operands (transposes are detectable)
+    A = rnd(M, K_, dt=dt, seed=1) if ak else rnd(K_, M, dt=dt, seed=1)
+    B = rnd(N, K_, dt=dt, seed=2) if bk else rnd(K_, N, dt=dt, seed=2)
+    Aop = A.float() if ak else A.float().t()
+    Bop = B.float().t() if bk else B.float()
+    ref = Aop @ Bop
+    C = torch.empty(M, N, dtype=dt, device="cuda")
+    k.gemm(A, B, C, M, N, K_, a_kmajor=ak, b_kmajor=bk, lda=A.stride(0), ldb=B.stride(0), ldc=N, split_k=1)
+    check(C, ref, dt, "gemm %d%d %dx%dx%d" % (ak, bk, M, N, K_))
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_epilogue_bias_gelu_aux_resid(K, dt):
+    k, L = K
+    M, N, K_ = 260, 192, 128
+    A, B = rnd(M, K_, dt=dt, seed=3), rnd(N, K_, dt=dt, seed=4, scale=0.1)
+    bias, resid = rnd(N, dt=dt, seed=5), rnd(M, N, dt=dt, seed=6)
+    C = torch.empty(M, N, dtype=dt, device="cuda")
+    Z = torch.empty(M, N, dtype=dt, device="cuda")
+    k.gemm(A, B, C, M, N, K_, a_kmajor=1, b_kmajor=1, lda=K_, ldb=K_, ldc=N, bias=bias, act=L.ACT_GELU, aux_out=Z,
+           ld_aux_out=N, resid=resid, ld_resid=N, alpha=0.5, split_k=1)
+    z = 0.5 * (A.float() @ B.float().t()) + bias.float()
+    check(Z, z, dt, "aux_out")
+    check(C, F.gelu(z) + resid.float(), dt, "bias+gelu+resid")
+    # relu + row bias + dact epilogue
+    rb = rnd(M, dt=dt, seed=7)
+    zin = rnd(M, N, dt=dt, seed=8)
+    k.gemm(A, B, C, M, N, K_, a_kmajor=1, b_kmajor=1, lda=K_, ldb=K_, ldc=N, bias=rb, bias_mode=L.BIAS_ROW, act=L.ACT_RELU,
+           dact=L.ACT_GELU, aux_in=zin, ld_aux_in=N, split_k=1)
+    zz = zin.float()
+    dgelu = 0.5 * (1 + torch.erf(zz / math.sqrt(2))) + zz * torch.exp(-0.5 * zz * zz) / math.sqrt(2 * math.pi)
+    check(C, torch.relu(A.float() @ B.float().t() + rb.float()[:, None]) * dgelu, dt, "rowbias+relu+dgelu")
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_splitk_and_f32_out(K, dt):
+    k, L = K
+    M, N, K_ = 96, 160, 4096
+    A, B = rnd(K_, M, dt=dt, seed=9, scale=0.3), rnd(K_, N, dt=dt, seed=10, scale=0.3)
+    ref = A.float().t() @ B.float()
+    for sk in (-1, 4, 7):
+        C = torch.empty(M, N, dtype=torch.float32, device="cuda")
+        k.gemm(A, B, C, M, N, K_, a_kmajor=0, b_kmajor=0, lda=M, ldb=N, ldc=N, split_k=sk)
+        check(C, ref, dt, "split_k=%d f32 out" % sk)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_batched(K, dt):
+    k, L = K
+    b0, b1, M, N, K_ = 3, 2, 70, 40, 72
+    A = rnd(b0, b1, M, K_, dt=dt, seed=11)
+    B = rnd(b1, N, K_, dt=dt, seed=12)
+    C = torch.empty(b0, b1, M, N, dtype=dt, device="cuda")
+    bias = rnd(b1, N, dt=dt, seed=13)
+    k.gemm(A, B, C, M, N, K_, a_kmajor=1, b_kmajor=1, lda=K_, ldb=K_, ldc=N, batch0=b0, batch1=b1, sa=(b1 * M * K_, M * K_),
+           sb=(0, N * K_), sc=(b1 * M * N, M * N), bias=bias, sbias=(0, N), split_k=1)
+    ref = torch.einsum("xymk,ynk->xymn", A.float(), B.float()) + bias.float()[None, :, None, :]
+    check(C, ref, dt, "batched gemm")
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("k_,s_", [(3, 2), (2, 2), (5, 2)])
+def test_gemm_implicit_conv1d(K, dt, k_, s_):
+    """channels-last conv1d as a GEMM over overlapping rows (lda = stride*Cin < K = k*Cin)."""
+    k, L = K
+    B_, Lin, Cin, Cout = 3, 61, 32, 48
+    x = rnd(B_, Lin, Cin, dt=dt, seed=14)
+    w = rnd(Cout, Cin, k_, dt=dt, seed=15, scale=0.2)
+    Lout = (Lin - k_) // s_ + 1
+    ref = F.conv1d(x.float().transpose(1, 2), w.float(), stride=s_).transpose(1, 2)
+    wcl = w.permute(0, 2, 1).contiguous().view(Cout, k_ * Cin)
+    y = torch.empty(B_, Lout, Cout, dtype=dt, device="cuda")
+    k.gemm(x, wcl, y, Lout, Cout, k_ * Cin, a_kmajor=1, b_kmajor=1, lda=s_ * Cin, ldb=k_ * Cin, ldc=Cout, batch0=B_,
+           sa=(Lin * Cin, 0), sc=(Lout * Cout, 0), split_k=1)
+    check(y, ref, dt, "implicit conv k%d s%d" % (k_, s_))
+    # weight gradient: dW[co, (j,ci)] = sum_t dy[t,co] x[t*s + j, ci]   (both operands mn-major, overlapping B rows)
+    dy = rnd(B_, Lout, Cout, dt=dt, seed=16)
+    dw = torch.empty(B_, Cout, k_ * Cin, dtype=torch.float32, device="cuda")
+    k.gemm(dy, x, dw, Cout, k_ * Cin, Lout, a_kmajor=0, b_kmajor=0, lda=Cout, ldb=s_ * Cin, ldc=k_ * Cin, batch0=B_,
+           sa=(Lout * Cout, 0), sb=(Lin * Cin, 0), sc=(Cout * k_ * Cin, 0), split_k=1)
+    xr = x.float().transpose(1, 2).detach().requires_grad_(False)
+    wref = w.float().detach().requires_grad_(True)
+    out = F.conv1d(xr, wref, stride=s_)
+    out.backward(dy.float().transpose(1, 2))
+    check(dw.sum(0).view(Cout, k_, Cin).permute(0, 2, 1), wref.grad, dt, "implicit conv dW k%d s%d" % (k_, s_))
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_grouped_posconv(K, dt):
+    """wav2vec2 pos_conv (grouped, k=16 here) as segmented-K implicit GEMM with fused bias+GELU+residual."""
+    k, L = K
+    B_, T, C, G, Kp = 2, 37, 64, 4, 16
+    cg = C // G
+    x = rnd(B_, T, C, dt=dt, seed=17)
+    w = rnd(C, cg, Kp, dt=dt, seed=18, scale=0.1)  # [Cout, Cin/g, k]
+    bias = rnd(C, dt=dt, seed=19)
+    ref = F.conv1d(x.float().transpose(1, 2), w.float(), bias.float(), padding=Kp // 2, groups=G)[:, :, :-1]
+    ref = x.float() + F.gelu(ref).transpose(1, 2)
+    xp = torch.zeros(B_, T + Kp, C, dtype=dt, device="cuda")
+    xp[:, Kp // 2:Kp // 2 + T] = x
+    wg = w.view(G, cg, cg, Kp).permute(0, 1, 3, 2).contiguous()  # [g][co][j][ci]
+    y = torch.empty(B_, T, C, dtype=dt, device="cuda")
+    z = torch.empty(B_, T, C, dtype=dt, device="cuda")
+    k.gemm(xp, wg, y, T, cg, Kp * cg, a_kmajor=1, b_kmajor=1, lda=C, ldb=Kp * cg, ldc=C, a_seg=cg, a_seg_stride=C,
+           batch0=B_, batch1=G, sa=((T + Kp) * C, cg), sb=(0, cg * Kp * cg), sc=(T * C, cg), bias=bias, sbias=(0, cg),
+           act=L.ACT_GELU, aux_out=z, ld_aux_out=C, resid=x, ld_resid=C, split_k=1)
+    check(y, ref, dt, "grouped pos-conv")
+
+
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("rows,cols", [(7, 64), (1000, 512), (333, 768), (50, 1024)])
+def test_layernorm(K, dt, rows, cols):
+    k, L = K
+    x, res = rnd(rows, cols, dt=dt, seed=20), rnd(rows, cols, dt=dt, seed=21)
+    g, b = (1 + 0.1 * torch.randn(cols)).to(dt).cuda(), (0.1 * torch.randn(cols)).to(dt).cuda()
+    y, s, mean, rstd = k.layernorm_fwd(x, res, g, b, 1e-5, want_sum=True)
+    sr = (x.float() + res.float())
+    check(s, sr, dt, "ln sum")
+    sref = s.float().detach().requires_grad_(True)  # the kernel normalises the rounded sum it wrote
+    gr, br = g.float().requires_grad_(True), b.float().requires_grad_(True)
+    yr = F.layer_norm(sref, (cols,), gr, br, 1e-5)
+    check(y, yr, dt, "ln fwd")
+    dy, dres = rnd(rows, cols, dt=dt, seed=22), rnd(rows, cols, dt=dt, seed=23)
+    yr.backward(dy.float())
+    dx, dg, db = k.layernorm_bwd(dy, s, g, mean, rstd, dres)
+    check(dx, sref.grad + dres.float(), dt, "ln dx")
+    check(dg, gr.grad, dt, "ln dgamma")
+    check(db, br.grad, dt, "ln dbeta")
+
+
+# --------------------------------------------------------------------------------------------
+def attn_ref(q, k, v, H, kpm, causal, scale):
+    """[B,T,C] fp32 reference written like modules/multihead_attention.py:326-361."""
+    B, Tq, C = q.shape
+    Tk = k.shape[1]
+    D = C // H
+    qh = q.view(B, Tq, H, D).transpose(1, 2)
+    kh = k.view(B, Tk, H, D).transpose(1, 2)
+    vh = v.view(B, Tk, H, D).transpose(1, 2)
+    w = (qh @ kh.transpose(-1, -2)) * scale
+    if causal:
+        w = w + torch.triu(torch.full((Tq, Tk), float("-inf"), device=q.device), 1 + Tk - Tq)
+    if kpm is not None:
+        w = w.masked_fill(kpm.bool()[:, None, None, :], float("-inf"))
+    p = torch.softmax(w, dim=-1)
+    return (p @ vh).transpose(1, 2).reshape(B, Tq, C)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,H,D,Tq,Tk,causal,pad,layout", [
+    (2, 2, 32, 40, 40, False, True, "bt"),
+    (2, 3, 64, 200, 200, False, True, "bt"),
+    (1, 2, 64, 150, 150, True, False, "tb"),
+    (2, 2, 64, 8, 77, False, False, "bt"),      # memory slots -> encoder frames
+    (3, 4, 64, 33, 64, False, True, "tb"),      # decoder cross-attention
+    (2, 2, 64, 1, 19, False, False, "bt"),      # incremental decode step
+    (2, 8, 64, 128, 128, True, True, "bt"),
+])
+def test_attention_fwd_bwd(K, dt, B, H, D, Tq, Tk, causal, pad, layout):
+    k, L = K
+    C = H * D
+    q, kk, v = rnd(B, Tq, C, dt=dt, seed=30), rnd(B, Tk, C, dt=dt, seed=31), rnd(B, Tk, C, dt=dt, seed=32)
+    kpm = None
+    if pad:
+        lens = torch.tensor([Tk - (3 * i + 1) % max(Tk // 2, 1) for i in range(B)])
+        kpm = (torch.arange(Tk)[None] >= lens[:, None]).to(torch.uint8).cuda()
+    scale = D ** -0.5
+    qr, kr, vr = (t.float().detach().requires_grad_(True) for t in (q, kk, v))
+    ref = attn_ref(qr, kr, vr, H, kpm, causal, scale)
+    do = rnd(B, Tq, C, dt=dt, seed=33)
+    ref.backward(do.float())
+    if layout == "tb":
+        qx, kx, vx, dox = (t.transpose(0, 1).contiguous() for t in (q, kk, v, do))
+    else:
+        qx, kx, vx, dox = q, kk, v, do
+    o, lse = k.attn_fwd(qx, kx, vx, H, D, kpm, causal, scale, layout, layout)
+    dq, dk, dv = k.attn_bwd(dox, qx, kx, vx, o, lse, H, D, kpm, causal, scale, layout, layout)
+    if layout == "tb":
+        o, dq, dk, dv = (t.transpose(0, 1) for t in (o, dq, dk, dv))
+    check(o, ref, dt, "attn fwd")
+    check(dq, qr.grad, dt, "attn dq")
+    check(dk, kr.grad, dt, "attn dk")
+    check(dv, vr.grad, dt, "attn dv")
+
+
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,S,C", [(2, 4000, 32), (2, 16000, 512)])
+def test_conv0_gn_gelu(K, dt, B, S, C):
+    k, L = K
+    kk, st = 10, 5
+    wav = (0.1 * torch.randn(B, S, generator=torch.Generator().manual_seed(40))).cuda()
+    w = rnd(C, kk, dt=dt, seed=41, scale=0.5)
+    g, b = (1 + 0.1 * torch.randn(C)).to(dt).cuda(), (0.1 * torch.randn(C)).to(dt).cuda()
+    wr, gr, br = w.float().requires_grad_(True), g.float().requires_grad_(True), b.float().requires_grad_(True)
+    u = F.conv1d(wav[:, None], wr[:, None], stride=st)
+    ref = F.gelu(F.group_norm(u, C, gr, br, 1e-5)).transpose(1, 2)
+    y, mean, rstd, gram = k.conv0_fwd(wav, w, g, b, kk, st)
+    check(y, ref, dt, "conv0 fwd")
+    dy = rnd(B, ref.shape[1], C, dt=dt, seed=42)
+    ref.backward(dy.float())
+    dw, dg, db = k.conv0_bwd(dy, wav, w, g, b, mean, rstd, gram, kk, st)
+    # bf16: backward recomputes z from bf16 weights exactly like forward; tolerance is on reductions over B*L terms
+    check(dw, wr.grad, dt, "conv0 dW", scale=float(wr.grad.abs().max()))
+    check(dg, gr.grad, dt, "conv0 dgamma")
+    check(db, br.grad, dt, "conv0 dbeta")
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_elementwise(K, dt):
+    k, L = K
+    z = rnd(77, 128, dt=dt, seed=50)
+    dy = rnd(77, 64, dt=dt, seed=51)
+    zr = z.float().requires_grad_(True)
+    yr = F.glu(zr, dim=1)
+    yr.backward(dy.float())
+    check(k.glu_fwd(z), yr, dt, "glu fwd")
+    check(k.glu_bwd(dy, z), zr.grad, dt, "glu bwd")
+    for act, fn in ((L.ACT_GELU, F.gelu), (L.ACT_RELU, torch.relu)):
+        x = rnd(40, 64, dt=dt, seed=52)
+        xr = x.float().requires_grad_(True)
+        o = fn(xr)
+        g = rnd(40, 64, dt=dt, seed=53)
+        o.backward(g.float())
+        check(k.act_fwd(x, act), o, dt, "act fwd")
+        check(k.act_bwd(g, x, act), xr.grad, dt, "act bwd")
+    x = rnd(1234, 72, dt=dt, seed=54)
+    check(k.colsum(x), x.float().sum(0), dt, "colsum")
+    m = (torch.arange(1234) % 3 == 0).to(torch.uint8).cuda()
+    check(k.mask_rows(x, m), x.float() * (1 - m.float())[:, None], dt, "mask_rows")
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("k_,s_,pad", [(3, 2, 0), (2, 2, 0), (5, 2, 2)])
+def test_col2im(K, dt, k_, s_, pad):
+    k, L = K
+    B_, Lin, C = 2, 41, 16
+    Lout = (Lin + 2 * pad - k_) // s_ + 1
+    dcol = rnd(B_, Lout, k_ * C, dt=dt, seed=55)
+    z = rnd(B_, Lin, C, dt=dt, seed=56)
+    ref = torch.zeros(B_, Lin + 2 * pad, C, device="cuda")
+    d4 = dcol.float().view(B_, Lout, k_, C)
+    for t in range(Lout):
+        for j in range(k_):
+            ref[:, t * s_ + j] += d4[:, t, j]
+    ref = ref[:, pad:pad + Lin]
+    check(k.col2im1d(dcol, None, B_, Lin, Lout, C, k_, s_, pad, 0), ref, dt, "col2im")
+    zz = z.float()
+    dg = 0.5 * (1 + torch.erf(zz / math.sqrt(2))) + zz * torch.exp(-0.5 * zz * zz) / math.sqrt(2 * math.pi)
+    check(k.col2im1d(dcol, z, B_, Lin, Lout, C, k_, s_, pad, L.ACT_GELU), ref * dg, dt, "col2im+dgelu")
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("rows,V", [(37, 60), (300, 10000)])
+def test_label_smoothed_ce(K, dt, rows, V):
+    k, L = K
+    logits = rnd(rows, V, dt=dt, seed=60, scale=2.0)
+    tgt = torch.randint(4, V, (rows,), generator=torch.Generator().manual_seed(61))
+    tgt[::5] = 1
+    tgt = tgt.cuda()
+    lr = logits.float().requires_grad_(True)
+    lp = torch.log_softmax(lr, -1)
+    nll = -lp.gather(1, tgt[:, None]).squeeze(1)
+    sm = -lp.sum(-1)
+    padm = tgt.eq(1)
+    nll_s = nll.masked_fill(padm, 0).sum()
+    loss = 0.9 * nll_s + 0.1 / V * sm.masked_fill(padm, 0).sum()
+    (loss * 0.37).backward()
+    out2, lse = k.ls_ce_fwd(logits, tgt, 0.1, 1)
+    check(out2, torch.stack([loss, nll_s]).detach(), torch.float32, "ls-ce loss")
+    gs = torch.tensor([0.37], device="cuda")
+    d = k.ls_ce_bwd(logits, tgt, lse, gs, 0.1, 1)
+    check(d, lr.grad, dt, "ls-ce dlogits", scale=0.37)
+
+
+def test_adam_and_sumsq(K):
+    k, L = K
+    n = 100003
+    for gdt, pdt in ((torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16)):
+        master = rnd(n, dt=torch.float32, seed=70)
+        m, v = rnd(n, dt=torch.float32, seed=71, scale=0.1), rnd(n, dt=torch.float32, seed=72).abs() * 0.01
+        g = rnd(n, dt=gdt, seed=73)
+        p = torch.empty(n, dtype=pdt, device="cuda")
+        rm, rmm, rv = master.clone(), m.clone(), v.clone()
+        gs = torch.tensor([0.25], device="cuda")
+        k.adam_step(master, m, v, g, p, 1e-3, 0.9, 0.98, 1e-8, 0.01, 3, gs)
+        gg = g.float() * 0.25
+        rmm.mul_(0.9).add_(gg, alpha=0.1)
+        rv.mul_(0.98).addcmul_(gg, gg, value=0.02)
+        step_size = 1e-3 * math.sqrt(1 - 0.98 ** 3) / (1 - 0.9 ** 3)
+        rm.add_(rm, alpha=-0.01 * 1e-3)
+        rm.addcdiv_(rmm, rv.sqrt().add_(1e-8), value=-step_size)
+        check(master, rm, torch.float32, "adam master")
+        check(m, rmm, torch.float32, "adam m")
+        check(v, rv, torch.float32, "adam v")
+        check(p, rm, pdt, "adam model param")
+        out = torch.zeros(1, device="cuda")
+        k.sumsq(g, out)
+        check(out, (g.float() ** 2).sum()[None], torch.float32, "sumsq")
