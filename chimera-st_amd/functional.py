@@ -1,0 +1,345 @@
+"""torch.autograd.Function seam over the C-ABI kernels (the reference's seam on this
+path is nn.Module.forward / autograd.Function calling ATen; here they call libcst_hip.so).
+
+Every function requires CUDA(HIP) tensors; there is no CPU path."""
+import torch
+
+from . import kernels as K
+from . import lib as L
+
+_ACT = {None: L.ACT_NONE, "none": L.ACT_NONE, "relu": L.ACT_RELU, "gelu": L.ACT_GELU}
+
+
+def _flat2d(x):
+    x2 = x.reshape(-1, x.shape[-1])
+    return x2 if x2.is_contiguous() else x2.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# Linear (+bias +activation +residual) — F.linear call sites listed in include/cst.h
+# ------------------------------------------------------------------------------------------------
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, resid, act):
+        x2 = _flat2d(x)
+        M, Kd = x2.shape
+        N = weight.shape[0]
+        w = weight if weight.is_contiguous() else weight.contiguous()
+        y = torch.empty(M, N, dtype=x.dtype, device=x.device)
+        z = torch.empty_like(y) if act != L.ACT_NONE else None
+        r2 = _flat2d(resid) if resid is not None else None
+        K.gemm(x2, w, y, M, N, Kd, a_kmajor=1, b_kmajor=1, lda=Kd, ldb=Kd, ldc=N, bias=bias, act=act, aux_out=z, ld_aux_out=N,
+               resid=r2, ld_resid=N, split_k=1)
+        ctx.save_for_backward(x2, w, z)
+        ctx.act, ctx.has_bias, ctx.has_resid = act, bias is not None, resid is not None
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, z = ctx.saved_tensors
+        M, Kd = x2.shape
+        N = w.shape[0]
+        dy2 = _flat2d(dy)
+        dz = K.act_bwd(dy2, z, ctx.act) if ctx.act != L.ACT_NONE else dy2
+        dx = dw = db = dres = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, Kd, dtype=x2.dtype, device=x2.device)
+            K.gemm(dz, w, dx, M, Kd, N, a_kmajor=1, b_kmajor=0, lda=N, ldb=Kd, ldc=Kd, split_k=1)
+            dx = dx.view(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty(N, Kd, dtype=w.dtype, device=w.device)
+            K.gemm(dz, x2, dw, N, Kd, M, a_kmajor=0, b_kmajor=0, lda=N, ldb=Kd, ldc=Kd, split_k=-1)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = K.colsum(dz).to(w.dtype)
+        if ctx.has_resid and ctx.needs_input_grad[3]:
+            dres = dy
+        return dx, dw, db, dres, None
+
+
+def linear(x, weight, bias=None, act=None, resid=None):
+    """y = act(x W^T + b) (+ resid)."""
+    return _LinearFn.apply(x, weight, bias, resid, _ACT[act])
+
+
+# ------------------------------------------------------------------------------------------------
+# LayerNorm with fused residual add
+# ------------------------------------------------------------------------------------------------
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps):
+        x2 = _flat2d(x)
+        r2 = _flat2d(res) if res is not None else None
+        y, s, mean, rstd = K.layernorm_fwd(x2, r2, gamma, beta, eps, want_sum=True)
+        src = s if res is not None else x2
+        ctx.save_for_backward(src, gamma, mean, rstd)
+        ctx.has_res = res is not None
+        ctx.shape = x.shape
+        if res is not None:
+            return y.view(x.shape), s.view(x.shape)
+        return y.view(x.shape), None
+
+    @staticmethod
+    def backward(ctx, dy, ds):
+        src, gamma, mean, rstd = ctx.saved_tensors
+        dy2 = _flat2d(dy)
+        dres = _flat2d(ds) if ds is not None else None
+        dx, dg, db = K.layernorm_bwd(dy2, src, gamma, mean, rstd, dres)
+        dx = dx.view(ctx.shape)
+        return dx, (dx if ctx.has_res else None), dg.to(gamma.dtype), db.to(gamma.dtype), None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return _LayerNormFn.apply(x, None, gamma, beta, eps)[0]
+
+
+def add_layer_norm(x, res, gamma, beta, eps=1e-5):
+    """s = x + res;  returns (LN(s), s) from one kernel."""
+    return _LayerNormFn.apply(x, res, gamma, beta, eps)
+
+
+# ------------------------------------------------------------------------------------------------
+# fused attention
+# ------------------------------------------------------------------------------------------------
+class _AttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, kpm, H, causal, scale, layout_q, layout_kv):
+        D = q.shape[-1] // H
+        o, lse = K.attn_fwd(q, k, v, H, D, kpm, causal, scale, layout_q, layout_kv)
+        ctx.save_for_backward(q, k, v, o, lse, kpm)
+        ctx.cfg = (H, D, causal, scale, layout_q, layout_kv)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse, kpm = ctx.saved_tensors
+        H, D, causal, scale, lq, lkv = ctx.cfg
+        if do.stride() != o.stride():
+            tmp = torch.empty_like(o)
+            tmp.copy_(do)
+            do = tmp
+        dq, dk, dv = K.attn_bwd(do, q, k, v, o, lse, H, D, kpm, causal, scale, lq, lkv)
+        return dq, dk, dv, None, None, None, None, None, None
+
+
+def attention(q, k, v, num_heads, key_padding_mask=None, causal=False, scale=None, layout_q="bt", layout_kv="bt"):
+    """q [B,Tq,C] / k,v [B,Tk,C] (layout "bt") or time-major ("tb"); channels of head h at [h*D,(h+1)*D).
+    key_padding_mask: bool/uint8 [B,Tk], True = pad."""
+    if scale is None:
+        scale = (q.shape[-1] // num_heads) ** -0.5
+    if key_padding_mask is not None:
+        key_padding_mask = key_padding_mask.to(torch.uint8).contiguous()
+    assert q.stride(-1) == 1 and k.stride(-1) == 1 and v.stride(-1) == 1
+    return _AttnFn.apply(q, k, v, key_padding_mask, num_heads, bool(causal), float(scale), layout_q, layout_kv)
+
+
+# ------------------------------------------------------------------------------------------------
+# wav2vec2 conv layer 0 + GroupNorm + GELU
+# ------------------------------------------------------------------------------------------------
+class _Conv0Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, wav, w, gamma, beta, stride, eps):
+        C, _, k = w.shape
+        w2 = w.reshape(C, k).contiguous()
+        wav = wav.float().contiguous()
+        y, mean, rstd, gram = K.conv0_fwd(wav, w2, gamma, beta, k, stride, eps)
+        ctx.save_for_backward(wav, w2, gamma, beta, mean, rstd, gram)
+        ctx.k, ctx.stride = k, stride
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        wav, w2, gamma, beta, mean, rstd, gram = ctx.saved_tensors
+        dw, dg, db = K.conv0_bwd(dy.contiguous(), wav, w2, gamma, beta, mean, rstd, gram, ctx.k, ctx.stride)
+        return None, dw.view(w2.shape[0], 1, ctx.k).to(w2.dtype), dg.to(gamma.dtype), db.to(gamma.dtype), None, None
+
+
+def conv0_gn_gelu(wav, weight, gn_weight, gn_bias, stride, eps=1e-5):
+    """wav [B,S] -> channels-last [B, L, C] = GELU(GroupNorm_C(conv1d(wav, weight[C,1,k], stride)))."""
+    return _Conv0Fn.apply(wav, weight, gn_weight, gn_bias, stride, eps)
+
+
+# ------------------------------------------------------------------------------------------------
+# channels-last conv1d as implicit GEMM (wav2vec2 conv layers 1.., subsampler)
+# ------------------------------------------------------------------------------------------------
+class _Conv1dCLFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_cl, bias, k, stride, pad, act, prev_z, grad_is_dz):
+        """x [B, Lin, Cin] contiguous; w_cl [Cout, k*Cin]; -> y [B, Lout, Cout] (and saves z if act)."""
+        B, Lin, Cin = x.shape
+        Cout = w_cl.shape[0]
+        if pad:
+            xp = torch.zeros(B, Lin + 2 * pad, Cin, dtype=x.dtype, device=x.device)
+            xp[:, pad:pad + Lin] = x
+        else:
+            xp = x if x.is_contiguous() else x.contiguous()
+        Lp = Lin + 2 * pad
+        Lout = (Lp - k) // stride + 1
+        y = torch.empty(B, Lout, Cout, dtype=x.dtype, device=x.device)
+        z = torch.empty_like(y) if act != L.ACT_NONE else None
+        K.gemm(xp, w_cl, y, Lout, Cout, k * Cin, a_kmajor=1, b_kmajor=1, lda=stride * Cin, ldb=k * Cin, ldc=Cout, bias=bias,
+               act=act, aux_out=z, ld_aux_out=Cout, batch0=B, sa=(Lp * Cin, 0), sc=(Lout * Cout, 0), split_k=1)
+        ctx.save_for_backward(xp, w_cl, z, prev_z)
+        ctx.cfg = (B, Lin, Cin, Cout, k, stride, pad, Lout, act, bias is not None, grad_is_dz)
+        if act != L.ACT_NONE:
+            ctx.mark_non_differentiable(z)
+            return y, z
+        return y, None
+
+    @staticmethod
+    def backward(ctx, dy, _dz_unused):
+        xp, w_cl, z, prev_z = ctx.saved_tensors
+        B, Lin, Cin, Cout, k, stride, pad, Lout, act, has_bias, grad_is_dz = ctx.cfg
+        Lp = Lin + 2 * pad
+        dy = dy.contiguous()
+        dz = K.act_bwd(dy, z, act) if (act != L.ACT_NONE and not grad_is_dz) else dy
+        dz2 = dz.view(B * Lout, Cout)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dcol = torch.empty(B * Lout, k * Cin, dtype=dy.dtype, device=dy.device)
+            K.gemm(dz2, w_cl, dcol, B * Lout, k * Cin, Cout, a_kmajor=1, b_kmajor=0, lda=Cout, ldb=k * Cin, ldc=k * Cin, split_k=1)
+            # prev_z: pre-activation of the producing conv layer -> fold its GELU' into the col2im pass
+            dx = K.col2im1d(dcol, prev_z, B, Lin, Lout, Cin, k, stride, pad, L.ACT_GELU if prev_z is not None else 0)
+        if ctx.needs_input_grad[1]:
+            part = torch.empty(B, Cout, k * Cin, dtype=torch.float32, device=dy.device)
+            K.gemm(dz2, xp, part, Cout, k * Cin, Lout, a_kmajor=0, b_kmajor=0, lda=Cout, ldb=stride * Cin, ldc=k * Cin, batch0=B,
+                   sa=(Lout * Cout, 0), sb=(Lp * Cin, 0), sc=(Cout * k * Cin, 0), split_k=1)
+            dw = part.sum(0).to(w_cl.dtype)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = K.colsum(dz2).to(w_cl.dtype)
+        return dx, dw, db, None, None, None, None, None, None
+
+
+def conv1d_cl(x, weight, bias, stride, pad=0, act=None, prev_z=None, grad_is_dz=False):
+    """Channels-last conv1d.  x [B,Lin,Cin]; weight [Cout,Cin,k] (torch layout).  Returns (y, z) where z is
+    the pre-activation (None without activation).  If `prev_z` (pre-GELU tensor that produced x = GELU(prev_z))
+    is given, the returned input-gradient is already multiplied by GELU'(prev_z), i.e. it is d/d prev_z; the
+    producing layer must then be built with grad_is_dz=True so it does not apply GELU' a second time
+    (see the wav2vec2 feature extractor: one fused col2im+GELU' pass per layer instead of two)."""
+    Cout, Cin, k = weight.shape
+    w_cl = weight.permute(0, 2, 1).reshape(Cout, k * Cin)
+    if not w_cl.is_contiguous():
+        w_cl = w_cl.contiguous()
+    return _Conv1dCLFn.apply(x, w_cl, bias, k, stride, pad, _ACT[act], prev_z, bool(grad_is_dz))
+
+
+# ------------------------------------------------------------------------------------------------
+# grouped positional conv of wav2vec2 (k taps, `groups` groups, pad k//2, SamePad, GELU, + residual)
+# ------------------------------------------------------------------------------------------------
+class _PosConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups):
+        """x [B,T,C]; weight [C, C/g, k] -> x + GELU(conv(x) + bias)   (one fused GEMM launch)."""
+        B, T, C = x.shape
+        k = weight.shape[2]
+        cg = C // groups
+        padl = k // 2
+        # even k: torch pads k//2 both sides and SamePad drops the last output; odd k: symmetric, nothing dropped
+        xp = torch.zeros(B, T + k - 1 + (1 if k % 2 == 0 else 0), C, dtype=x.dtype, device=x.device)
+        xp[:, padl:padl + T] = x
+        Tp = xp.shape[1]
+        wg = weight.view(groups, cg, cg, k).permute(0, 1, 3, 2).contiguous()  # [g][co][j][ci]
+        y = torch.empty(B, T, C, dtype=x.dtype, device=x.device)
+        z = torch.empty_like(y)
+        xc = x if x.is_contiguous() else x.contiguous()
+        K.gemm(xp, wg, y, T, cg, k * cg, a_kmajor=1, b_kmajor=1, lda=C, ldb=k * cg, ldc=C, a_seg=cg, a_seg_stride=C, batch0=B,
+               batch1=groups, sa=(Tp * C, cg), sb=(0, cg * k * cg), sc=(T * C, cg), bias=bias, sbias=(0, cg), act=L.ACT_GELU,
+               aux_out=z, ld_aux_out=C, resid=xc, ld_resid=C, split_k=1)
+        ctx.save_for_backward(xp, weight, z)
+        ctx.cfg = (B, T, C, k, groups, cg, padl, Tp)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, weight, z = ctx.saved_tensors
+        B, T, C, k, groups, cg, padl, Tp = ctx.cfg
+        dy = dy.contiguous()
+        dz = K.act_bwd(dy, z, L.ACT_GELU)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # dx[m] = dy[m] + sum_j dz[m + padl - j] w_j  = dy[m] + sum_j' dzp[m + j'] wflip[j'],  dzp[(k-1-padl) + t] = dz[t]
+            lp = k - 1 - padl
+            dzp = torch.zeros(B, T + k - 1, C, dtype=dy.dtype, device=dy.device)
+            dzp[:, lp:lp + T] = dz
+            wflip = weight.view(groups, cg, cg, k).flip(3).permute(0, 2, 3, 1).contiguous()  # [g][ci][j'][co]
+            dx = torch.empty(B, T, C, dtype=dy.dtype, device=dy.device)
+            K.gemm(dzp, wflip, dx, T, cg, k * cg, a_kmajor=1, b_kmajor=1, lda=C, ldb=k * cg, ldc=C, a_seg=cg, a_seg_stride=C,
+                   batch0=B, batch1=groups, sa=((T + k - 1) * C, cg), sb=(0, cg * k * cg), sc=(T * C, cg), resid=dy, ld_resid=C,
+                   split_k=1)
+        if ctx.needs_input_grad[1]:
+            # dw[g][co][(j,ci)] = sum_t dz[t, g, co] xp[t + j, g, ci]
+            part = torch.empty(B, groups, cg, k * cg, dtype=torch.float32, device=dy.device)
+            K.gemm(dz, xp, part, cg, k * cg, T, a_kmajor=0, b_kmajor=0, lda=C, ldb=C, ldc=k * cg, b_seg=cg, b_seg_stride=C, batch0=B,
+                   batch1=groups, sa=(T * C, cg), sb=(Tp * C, cg), sc=(groups * cg * k * cg, cg * k * cg), split_k=1)
+            dw = part.sum(0).view(groups, cg, k, cg).permute(0, 1, 3, 2).reshape(C, cg, k).to(weight.dtype)
+        if ctx.needs_input_grad[2]:
+            db = K.colsum(dz.view(B * T, C)).to(weight.dtype)
+        return dx, dw, db, None
+
+
+def pos_conv_gelu_residual(x, weight, bias, groups):
+    return _PosConvFn.apply(x, weight, bias, groups)
+
+
+# ------------------------------------------------------------------------------------------------
+class _GluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z):
+        z2 = _flat2d(z)
+        ctx.save_for_backward(z2)
+        ctx.shape = z.shape
+        return K.glu_fwd(z2).view(*z.shape[:-1], z.shape[-1] // 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (z2,) = ctx.saved_tensors
+        return K.glu_bwd(_flat2d(dy), z2).view(ctx.shape)
+
+
+def glu(z):
+    """F.glu over the last (channel) dimension of a channels-last tensor."""
+    return _GluFn.apply(z)
+
+
+class _MaskRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mask):
+        m = mask.reshape(-1).to(torch.uint8).contiguous()
+        ctx.save_for_backward(m)
+        ctx.shape = x.shape
+        return K.mask_rows(_flat2d(x), m).view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (m,) = ctx.saved_tensors
+        return K.mask_rows(_flat2d(dy), m).view(ctx.shape), None
+
+
+def mask_rows(x, mask):
+    """x[mask] = 0 over the leading dims (wav2vec2.py:820-821)."""
+    return _MaskRowsFn.apply(x, mask)
+
+
+class _LsCeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, eps, pad):
+        l2 = _flat2d(logits)
+        t = target.reshape(-1).contiguous()
+        out2, lse = K.ls_ce_fwd(l2, t, eps, pad)
+        ctx.save_for_backward(l2, t, lse)
+        ctx.cfg = (eps, pad, logits.shape)
+        ctx.mark_non_differentiable(out2)
+        return out2[0].clone(), out2
+
+    @staticmethod
+    def backward(ctx, dloss, _):
+        l2, t, lse = ctx.saved_tensors
+        eps, pad, shape = ctx.cfg
+        g = dloss.reshape(1).float().contiguous()
+        return K.ls_ce_bwd(l2, t, lse, g, eps, pad).view(shape), None, None, None
+
+
+def label_smoothed_nll_loss(logits, target, eps, pad):
+    """Returns (loss_sum [differentiable], nll_sum [detached]); fp32 scalars on device."""
+    loss, out2 = _LsCeFn.apply(logits, target, float(eps), int(pad))
+    return loss, out2[1]
