@@ -1,0 +1,152 @@
+"""Mirror of fairseq/criterions/label_smoothed_cross_entropy.py (:33-160) and
+fairseq/criterions/triplet_st_mt_contrastive.py (:18-212).  The log-softmax + NLL + smoothing runs in the fused
+cst_ls_ce kernels (logits read once each way; no fp32 [B*U,V] log-prob tensor)."""
+import math
+from copy import deepcopy
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import functional as CF
+from .registry import register_criterion
+
+
+class FairseqCriterion(nn.Module):
+    def __init__(self, task):
+        super().__init__()
+        self.task = task
+        self.padding_idx = task.target_dictionary.pad() if hasattr(task, "target_dictionary") and task.target_dictionary else -100
+
+    @staticmethod
+    def add_args(parser):
+        pass
+
+    @classmethod
+    def build_criterion(cls, args, task):
+        raise NotImplementedError
+
+    @staticmethod
+    def logging_outputs_can_be_summed() -> bool:
+        return False
+
+
+@register_criterion("label_smoothed_cross_entropy")
+class LabelSmoothedCrossEntropyCriterion(FairseqCriterion):
+    def __init__(self, task, sentence_avg, label_smoothing, ignore_prefix_size=0, report_accuracy=False):
+        super().__init__(task)
+        self.sentence_avg = sentence_avg
+        self.eps = label_smoothing
+        self.ignore_prefix_size = ignore_prefix_size
+        self.report_accuracy = report_accuracy
+        assert ignore_prefix_size == 0
+
+    @staticmethod
+    def add_args(parser):
+        parser.add_argument("--label-smoothing", default=0.0, type=float, metavar="D")
+        parser.add_argument("--report-accuracy", action="store_true")
+        parser.add_argument("--ignore-prefix-size", default=0, type=int)
+
+    @classmethod
+    def build_criterion(cls, args, task):
+        return cls(task, getattr(args, "sentence_avg", False), args.label_smoothing,
+                   getattr(args, "ignore_prefix_size", 0), getattr(args, "report_accuracy", False))
+
+    def forward(self, model, sample, reduce=True):
+        """:56-86.  Note Q6: net_input carries the collater's `mask`; the models here swallow it."""
+        net_output = model(**sample["net_input"])
+        loss, nll_loss = self.compute_loss(model, net_output, sample, reduce=reduce)
+        sample_size = sample["target"].size(0) if self.sentence_avg else sample["ntokens"]
+        logging_output = {"loss": loss.data, "nll_loss": nll_loss.data, "ntokens": sample["ntokens"],
+                          "nsentences": sample["target"].size(0), "sample_size": sample_size}
+        return loss, sample_size, logging_output
+
+    def compute_loss(self, model, net_output, sample, reduce=True):
+        assert reduce, "reduce=False (kd_ratio path) is not on the chimera/scripts path"
+        logits = net_output[0]
+        target = model.get_targets(sample, net_output)
+        return CF.label_smoothed_nll_loss(logits, target, self.eps, self.padding_idx)
+
+    @staticmethod
+    def logging_outputs_can_be_summed() -> bool:
+        return True
+
+
+@register_criterion("triplet_st_mt_contrastive")
+class TripletSTMTContrastiveCriterion(LabelSmoothedCrossEntropyCriterion):
+    def __init__(self, task, sentence_avg, label_smoothing, loss_ratio, contrastive_temp=0.1, ignore_prefix_size=0,
+                 report_accuracy=False, contrastive_increase_until=None, kd_ratio=None):
+        super().__init__(task, sentence_avg, label_smoothing, ignore_prefix_size, report_accuracy)
+        self.loss_ratio = list(loss_ratio)
+        self.contrastive_temp = contrastive_temp
+        self.contrastive_increase_until = contrastive_increase_until
+        self.kd_ratio = kd_ratio if kd_ratio is not None else [None, None]
+        self.num_updates = 0
+        assert list(self.kd_ratio) == [None, None], "kd_ratio is not used by chimera/scripts"
+
+    @staticmethod
+    def add_args(parser):
+        """:47-66."""
+        parser.add_argument("--label-smoothing", default=0.0, type=float, metavar="D")
+        parser.add_argument("--report-accuracy", action="store_true")
+        parser.add_argument("--ignore-prefix-size", default=0, type=int)
+        parser.add_argument("--loss-ratio", default=[1, 1, 1], type=float, nargs=3)
+        parser.add_argument("--contrastive-temp", default=0.1, type=float)
+        parser.add_argument("--contrastive-increase-until", type=int, default=None)
+        parser.add_argument("--kd-ratio", default=[None, None], type=float, nargs=2)
+
+    @classmethod
+    def build_criterion(cls, args, task):
+        return cls(task, getattr(args, "sentence_avg", False), args.label_smoothing, args.loss_ratio,
+                   args.contrastive_temp, getattr(args, "ignore_prefix_size", 0), getattr(args, "report_accuracy", False),
+                   args.contrastive_increase_until, list(args.kd_ratio))
+
+    def set_num_updates(self, n):
+        """The reference reads metrics.get_smoothed_values("train")["num_updates"] (:43-45); the trainer pushes it here."""
+        self.num_updates = n
+
+    def forward(self, model, sample, reduce=True):
+        """:68-146 — audio pass, text pass, contrastive term."""
+        st_net_output, audio_internal = model.forward_with_internal(**sample["net_input"])
+        st_loss, st_nll_loss = self.compute_loss(model, st_net_output, sample, reduce=reduce)
+        if self.loss_ratio[1] != 0:
+            mt_input = {"src_tokens": sample["src_text"], "src_lengths": sample["src_text_lengths"],
+                        "prev_output_tokens": sample["net_input"]["prev_output_tokens"], "mask": sample["net_input"]["mask"]}
+            mt_net_output, text_internal = model.forward_with_internal(**mt_input)
+            mt_loss, mt_nll_loss = self.compute_loss(model, mt_net_output, sample, reduce=reduce)
+        else:
+            mt_loss, mt_nll_loss = 0, 0
+        if self.loss_ratio[2] != 0:
+            contrastive_loss = self.compute_contrastive(audio_internal, text_internal, reduce)
+        else:
+            contrastive_loss = 0
+        loss_ratio = deepcopy(self.loss_ratio)
+        if self.contrastive_increase_until is not None:
+            loss_ratio[2] *= min(1, (self.num_updates or 0) / self.contrastive_increase_until)
+        loss = sum(loss_ratio[i] * l for i, l in enumerate((st_loss, mt_loss, contrastive_loss)))
+        nll_loss = sum(loss_ratio[i] * l for i, l in enumerate((st_nll_loss, mt_nll_loss)))
+        sample_size = sample["target"].size(0) if self.sentence_avg else sample["ntokens"]
+        logging_output = {
+            "loss": loss.data, "nll_loss": nll_loss.data, "st_loss": st_loss.data, "st_nll_loss": st_nll_loss.data,
+            "mt_loss": mt_loss.data if self.loss_ratio[1] != 0 else 0,
+            "mt_nll_loss": mt_nll_loss.data if self.loss_ratio[1] != 0 else 0,
+            "contrastive_loss": contrastive_loss.data if self.loss_ratio[2] != 0 else 0,
+            "ntokens": sample["ntokens"], "nsentences": sample["target"].size(0), "sample_size": sample_size,
+        }
+        return loss, sample_size, logging_output
+
+    def compute_contrastive(self, input1, input2, reduce):
+        """:154-169 — per-utterance M x M cosine-similarity CE (class dim = audio slot).  B*M*M logits (0.13 M values at
+        B=32): left to torch ops this round; cst_contrastive_fwd/bwd is a next-round row."""
+        assert input1.shape == input2.shape
+        input1 = input1.transpose(0, 1)
+        input2 = input2.transpose(0, 1)
+        batch_size, seqlen, _ = input1.shape
+        logits = torch.cosine_similarity(input1.float().unsqueeze(2), input2.float().unsqueeze(1), dim=-1)
+        logits = logits / self.contrastive_temp
+        target = torch.arange(seqlen, device=logits.device)[None].repeat(batch_size, 1)
+        return F.cross_entropy(logits, target, reduction="sum" if reduce else "none")
+
+    @staticmethod
+    def logging_outputs_can_be_summed() -> bool:
+        return True

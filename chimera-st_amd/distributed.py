@@ -1,0 +1,148 @@
+"""Data-parallel seam — replaces LegacyDistributedDataParallel
+(fairseq/legacy_distributed_data_parallel.py:28-178: one flat 2^28 buffer, BLOCKING all-reduce after backward,
+trainer.py:588-589) and its factory DistributedFairseqModel (models/distributed_fairseq_model.py:19-103).
+
+MI355X design: one process per GPU, torch.distributed "nccl" backend = RCCL over xGMI.  Gradients already live in one
+flat buffer (optim.FlatParamBuffers); it is cut into buckets in REVERSE parameter order (decoder -> memory -> encoder
+-> subsampler -> wav2vec2, the order backward produces them) and each bucket's all-reduce is launched from autograd
+post-accumulate hooks as soon as all of its gradients exist, so the wav2vec2 backward (62 % of FLOPs) hides the
+earlier buckets.  Buckets are launched strictly in index order on every rank (deterministic collective order even if
+some parameters receive no gradient: those stay zero, legacy_distributed_data_parallel.py:155-156).  Gradients are
+pre-divided by world size and summed (== mean; :125-126), because the trainer then multiplies by world/sample_size.
+xGMI is point-to-point (7 links/GPU): few large buckets (default 64 MiB) keep RCCL's ring/tree per-link-bound rather
+than latency-bound."""
+import os
+from contextlib import contextmanager
+
+import torch
+import torch.distributed as dist
+
+
+def distributed_init(backend=None):
+    """distributed_utils.distributed_init (:200-233) for a torchrun-style launch (RANK/WORLD_SIZE/LOCAL_RANK/MASTER_*)."""
+    if dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world == 1:
+        return 0, 1
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world
+
+
+class BucketedGradAllReduce:
+    """Overlapped, bucketed mean-all-reduce of a flat gradient buffer."""
+
+    def __init__(self, params, offsets, flat_grad, process_group=None, bucket_cap_mb=64):
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.flat_grad = flat_grad
+        self.params = list(params)
+        cap = max(1, int(bucket_cap_mb * 1024 * 1024 / flat_grad.element_size()))
+        # walk parameters in reverse (gradient-arrival order); a bucket is a contiguous [lo, hi) span of the flat buffer
+        self.buckets, self.param_bucket = [], {}
+        hi = flat_grad.numel()
+        cur_lo, cur_hi, members = hi, hi, []
+        for idx in range(len(self.params) - 1, -1, -1):
+            lo = offsets[idx]
+            if cur_hi - lo > cap and members:
+                self.buckets.append(dict(lo=cur_lo, hi=cur_hi, members=members))
+                cur_hi, members = cur_lo, []
+            cur_lo = lo
+            members.append(idx)
+        if members:
+            self.buckets.append(dict(lo=cur_lo, hi=cur_hi, members=members))
+        for b, bk in enumerate(self.buckets):
+            for idx in bk["members"]:
+                self.param_bucket[idx] = b
+        self.enabled = True
+        self._hooks = []
+        for idx, p in enumerate(self.params):
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(idx)))
+        self.reset()
+
+    def reset(self):
+        self._pending = [len(b["members"]) for b in self.buckets]
+        self._ready = [False] * len(self.buckets)
+        self._next = 0
+        self._works = []
+
+    def _make_hook(self, idx):
+        def hook(param):
+            if not self.enabled or self.world == 1:
+                return
+            b = self.param_bucket[idx]
+            self._pending[b] -= 1
+            if self._pending[b] == 0:
+                self._ready[b] = True
+                self._launch_ready()
+
+        return hook
+
+    def _launch(self, b):
+        bk = self.buckets[b]
+        g = self.flat_grad[bk["lo"]:bk["hi"]]
+        g.div_(self.world)
+        self._works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def _launch_ready(self):
+        while self._next < len(self.buckets) and self._ready[self._next]:
+            self._launch(self._next)
+            self._next += 1
+
+    def finish(self):
+        """Launch whatever has not been reduced yet (parameters without gradient stay zero) and wait for everything."""
+        if self.world > 1 and self.enabled:
+            while self._next < len(self.buckets):
+                self._launch(self._next)
+                self._next += 1
+            for w in self._works:
+                w.wait()
+        self.reset()
+
+
+class DistributedFairseqModel(torch.nn.Module):
+    """models/distributed_fairseq_model.py:19-103 surface: forwards attribute access to the wrapped model
+    (:90-103), provides no_sync() and an explicit all_reduce() (called at trainer.py:588-589)."""
+
+    def __init__(self, args, model, buffers, process_group=None):
+        super().__init__()
+        self.module = model
+        self.reducer = BucketedGradAllReduce(buffers.params, buffers.offsets, buffers.flat_grad, process_group,
+                                             getattr(args, "bucket_cap_mb", 64) if args is not None else 64)
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            return getattr(super().__getattr__("module"), name)
+
+    def forward(self, *a, **kw):
+        return self.module(*a, **kw)
+
+    @contextmanager
+    def no_sync(self):
+        old = self.reducer.enabled
+        self.reducer.enabled = False
+        try:
+            yield
+        finally:
+            self.reducer.enabled = old
+
+    def all_reduce(self):
+        self.reducer.finish()
+
+
+def all_reduce_stats(values, device):
+    """Trainer._fast_stat_sync_sum (trainer.py:1005-1043): one fp64 vector for every summable logging scalar (C3-C5)."""
+    t = torch.tensor(values, dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t)
+    return t.tolist()

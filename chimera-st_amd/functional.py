@@ -18,6 +18,10 @@ def _flat2d(x):
 # ------------------------------------------------------------------------------------------------
 # Linear (+bias +activation +residual) — F.linear call sites listed in include/cst.h
 # ------------------------------------------------------------------------------------------------
+def _vec(dtype):
+    return 8 if dtype == torch.bfloat16 else 4
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, resid, act):
@@ -25,33 +29,52 @@ class _LinearFn(torch.autograd.Function):
         M, Kd = x2.shape
         N = weight.shape[0]
         w = weight if weight.is_contiguous() else weight.contiguous()
-        y = torch.empty(M, N, dtype=x.dtype, device=x.device)
+        # odd output widths (e.g. a 60-symbol test vocabulary in bf16): zero-pad the rows of W up to the 16-byte vector
+        # the dX / dW loaders need; real shapes (512/768/1024/2048/3072/10000) never take this branch.
+        Np = (N + _vec(x.dtype) - 1) // _vec(x.dtype) * _vec(x.dtype)
+        if Np != N:
+            wp = torch.zeros(Np, Kd, dtype=w.dtype, device=w.device)
+            wp[:N] = w
+            w = wp
+            if bias is not None:
+                bp = torch.zeros(Np, dtype=bias.dtype, device=bias.device)
+                bp[:N] = bias
+                bias = bp
+            assert resid is None
+        y = torch.empty(M, Np, dtype=x.dtype, device=x.device)
         z = torch.empty_like(y) if act != L.ACT_NONE else None
         r2 = _flat2d(resid) if resid is not None else None
-        K.gemm(x2, w, y, M, N, Kd, a_kmajor=1, b_kmajor=1, lda=Kd, ldb=Kd, ldc=N, bias=bias, act=act, aux_out=z, ld_aux_out=N,
-               resid=r2, ld_resid=N, split_k=1)
+        K.gemm(x2, w, y, M, Np, Kd, a_kmajor=1, b_kmajor=1, lda=Kd, ldb=Kd, ldc=Np, bias=bias, act=act, aux_out=z, ld_aux_out=Np,
+               resid=r2, ld_resid=Np, split_k=1)
         ctx.save_for_backward(x2, w, z)
         ctx.act, ctx.has_bias, ctx.has_resid = act, bias is not None, resid is not None
-        ctx.xshape = x.shape
+        ctx.xshape, ctx.N = x.shape, N
+        if Np != N:
+            y = y[:, :N].contiguous()
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
         x2, w, z = ctx.saved_tensors
         M, Kd = x2.shape
-        N = w.shape[0]
+        Np, N = w.shape[0], ctx.N
         dy2 = _flat2d(dy)
+        if Np != N:
+            dyp = torch.zeros(M, Np, dtype=dy2.dtype, device=dy2.device)
+            dyp[:, :N] = dy2
+            dy2 = dyp
         dz = K.act_bwd(dy2, z, ctx.act) if ctx.act != L.ACT_NONE else dy2
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, Kd, dtype=x2.dtype, device=x2.device)
-            K.gemm(dz, w, dx, M, Kd, N, a_kmajor=1, b_kmajor=0, lda=N, ldb=Kd, ldc=Kd, split_k=1)
+            K.gemm(dz, w, dx, M, Kd, Np, a_kmajor=1, b_kmajor=0, lda=Np, ldb=Kd, ldc=Kd, split_k=1)
             dx = dx.view(ctx.xshape)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty(N, Kd, dtype=w.dtype, device=w.device)
-            K.gemm(dz, x2, dw, N, Kd, M, a_kmajor=0, b_kmajor=0, lda=N, ldb=Kd, ldc=Kd, split_k=-1)
+            dw = torch.empty(Np, Kd, dtype=w.dtype, device=w.device)
+            K.gemm(dz, x2, dw, Np, Kd, M, a_kmajor=0, b_kmajor=0, lda=Np, ldb=Kd, ldc=Kd, split_k=-1)
+            dw = dw[:N]
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = K.colsum(dz).to(w.dtype)
+            db = K.colsum(dz).to(w.dtype)[:N]
         if ctx.has_resid and ctx.needs_input_grad[3]:
             dres = dy
         return dx, dw, db, dres, None

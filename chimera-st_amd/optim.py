@@ -1,0 +1,119 @@
+"""Optimizer path: the reference chains FP16Optimizer (fp16 model + flat fp32 master,
+optim/fp16_optimizer.py:16-300) -> multiply_grads -> utils.clip_grad_norm_ (utils.py:323-364) -> Adam.step
+(optim/adam.py:146-226) -> copy back, i.e. 5-6 passes over parameter-sized buffers.  Here:
+  * model parameters AND gradients live in two flat buffers (params/grads are views) — the gradient buffer is what
+    the data-parallel wrapper all-reduces bucket by bucket;
+  * one cst_sumsq pass gives the global grad norm on device;
+  * one cst_adam_step pass applies  g * (world/sample_size) * clip_coef,  Adam with fairseq's semantics on the fp32
+    master, and writes the model-dtype parameter.  The combined scale is a DEVICE scalar: no host sync in the step.
+Flags mirror fairseq: --adam-betas --adam-eps --weight-decay --lr --clip-norm --warmup-updates --warmup-init-lr."""
+import math
+
+import torch
+
+from . import kernels as K
+
+ALIGN = 8  # elements: keeps every parameter view 16-byte aligned (bf16) for the GEMM loaders
+
+
+class FlatParamBuffers:
+    """Re-home a model's parameters (and their .grad) as views of two flat tensors."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        assert len(self.params) > 0
+        self.dtype, self.device = self.params[0].dtype, self.params[0].device
+        self.offsets, total = [], 0
+        for p in self.params:
+            assert p.dtype == self.dtype and p.device == self.device, "all trainable parameters must share dtype/device"
+            self.offsets.append(total)
+            total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.total = total
+        self.flat_param = torch.zeros(total, dtype=self.dtype, device=self.device)
+        self.flat_grad = torch.zeros(total, dtype=self.dtype, device=self.device)
+        for p, o in zip(self.params, self.offsets):
+            n = p.numel()
+            self.flat_param[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.flat_param[o:o + n].view(p.shape)
+            p.grad = self.flat_grad[o:o + n].view(p.shape)
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+        for p, o in zip(self.params, self.offsets):  # re-attach if something replaced .grad (e.g. set_to_none)
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + o * self.flat_grad.element_size():
+                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+
+
+def inverse_sqrt_lr(num_updates, lr, warmup_updates, warmup_init_lr):
+    """optim/lr_scheduler/inverse_square_root_schedule.py:52-94."""
+    if warmup_init_lr < 0:
+        warmup_init_lr = 0 if warmup_updates > 0 else lr
+    if warmup_updates > 0 and num_updates < warmup_updates:
+        return warmup_init_lr + num_updates * (lr - warmup_init_lr) / warmup_updates
+    decay_factor = lr * max(warmup_updates, 1) ** 0.5
+    return decay_factor * max(num_updates, 1) ** -0.5 if warmup_updates > 0 else lr
+
+
+class FusedAdam:
+    """FairseqAdam + FP16Optimizer(flat fp32 master) + clip_grad_norm fused over flat buffers."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_norm=0.0,
+                 warmup_updates=0, warmup_init_lr=-1.0, buffers=None):
+        self.buf = buffers if buffers is not None else FlatParamBuffers(params)
+        self.base_lr, self.betas, self.eps, self.weight_decay, self.clip_norm = lr, betas, eps, weight_decay, clip_norm
+        self.warmup_updates, self.warmup_init_lr = warmup_updates, warmup_init_lr
+        n, dev = self.buf.total, self.buf.device
+        self.master = self.buf.flat_param.float().clone()
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.num_updates = 0
+        self.lr = inverse_sqrt_lr(0, lr, warmup_updates, warmup_init_lr)
+        self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._scale = torch.ones(1, dtype=torch.float32, device=dev)
+
+    @classmethod
+    def from_args(cls, args, params, buffers=None):
+        betas = eval(args.adam_betas) if isinstance(args.adam_betas, str) else args.adam_betas
+        return cls(params, lr=args.lr[0], betas=betas, eps=args.adam_eps, weight_decay=args.weight_decay,
+                   clip_norm=getattr(args, "clip_norm", 0.0), warmup_updates=getattr(args, "warmup_updates", 0),
+                   warmup_init_lr=getattr(args, "warmup_init_lr", -1.0), buffers=buffers)
+
+    def zero_grad(self):
+        self.buf.zero_grad()
+
+    def backward(self, loss):
+        loss.backward()
+
+    def get_lr(self):
+        return self.lr
+
+    def grad_norm(self, multiply=1.0):
+        """|| multiply * grad ||_2 as a device tensor (what clip_grad_norm_ returns after multiply_grads)."""
+        self._sumsq.zero_()
+        K.sumsq(self.buf.flat_grad, self._sumsq)
+        return self._sumsq.sqrt() * multiply
+
+    def step(self, multiply=1.0):
+        """One update.  `multiply` = world_size / sample_size (trainer.py:606).  Returns the pre-clip grad norm (device)."""
+        gnorm = self.grad_norm(multiply)  # `multiply` may be a python float or a 1-element device tensor
+        if self.clip_norm > 0:
+            coef = (self.clip_norm / (gnorm + 1e-6)).clamp(max=1.0)
+            self._scale.copy_((coef * multiply).reshape(1))
+        elif torch.is_tensor(multiply):
+            self._scale.copy_(multiply.reshape(1))
+        else:
+            self._scale.fill_(multiply)
+        self.num_updates += 1
+        K.adam_step(self.master, self.exp_avg, self.exp_avg_sq, self.buf.flat_grad, self.buf.flat_param, self.lr,
+                    self.betas[0], self.betas[1], self.eps, self.weight_decay, self.num_updates, self._scale)
+        self.lr = inverse_sqrt_lr(self.num_updates, self.base_lr, self.warmup_updates, self.warmup_init_lr)
+        return gnorm
+
+    def state_dict(self):
+        return {"master": self.master, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
+                "num_updates": self.num_updates, "lr": self.lr}
+
+    def load_state_dict(self, sd):
+        self.master.copy_(sd["master"]); self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.num_updates, self.lr = sd["num_updates"], sd["lr"]
+        self.buf.flat_param.copy_(self.master)

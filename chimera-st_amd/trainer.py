@@ -1,0 +1,86 @@
+"""The trainer seam of the hot path: fairseq/trainer.py train_step (:455-700) — micro-batch loop with no_sync
+(:479-492), task.train_step, summed logging stats (:1005-1043), model.all_reduce() (:588-589), multiply_grads
+(world/sample_size, :601-606), clip (:615), optimizer step (:627), lr schedule — with the MI355X pieces swapped in:
+flat bf16 parameter/gradient buffers, bucketed RCCL all-reduce overlapped with backward, one fused Adam pass."""
+import contextlib
+import random
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .distributed import DistributedFairseqModel, all_reduce_stats
+from .optim import FlatParamBuffers, FusedAdam
+
+
+class Trainer:
+    def __init__(self, args, task, model, criterion, device="cuda"):
+        self.args, self.task, self.criterion = args, task, criterion
+        self.device = torch.device(device)
+        dtype = torch.bfloat16 if getattr(args, "bf16", False) else torch.float32
+        if getattr(args, "fp16", False):
+            raise NotImplementedError("--fp16: this build computes in bf16 (--bf16) or fp32; gfx950 MFMA rates are equal and "
+                                      "bf16 needs no loss scaling (DESIGN.md)")
+        model = model.to(device=self.device, dtype=dtype)  # trainer.py:70-78
+        self.criterion = criterion.to(self.device)
+        self.buffers = FlatParamBuffers(model.parameters())
+        self.optimizer = FusedAdam.from_args(args, None, buffers=self.buffers)
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.model = DistributedFairseqModel(args, model, self.buffers) if self.world > 1 else model
+        self._model = model
+        self.num_updates = 0
+        self.dtype = dtype
+
+    def get_model(self):
+        return self._model
+
+    def _set_seed(self):
+        """trainer.py:934-938 — seed + num_updates so dropout/layerdrop RNG is resumable."""
+        seed = getattr(self.args, "seed", 1) + self.num_updates
+        torch.manual_seed(seed)
+        if self.device.type == "cuda":
+            torch.cuda.manual_seed(seed)
+        np.random.seed(seed)
+        random.seed(seed)
+
+    def _prepare_sample(self, sample):
+        """trainer.py:896-932: H2D; the waveform stays fp32 (conv0 reads it directly), token tensors stay int64."""
+        def mv(x):
+            if torch.is_tensor(x):
+                return x.to(self.device, non_blocking=True)
+            if isinstance(x, dict):
+                return {k: mv(v) for k, v in x.items()}
+            return x
+
+        return mv(sample)
+
+    def train_step(self, samples):
+        """One update over a list of micro-batches.  Returns the summed logging output (loss terms as device tensors
+        converted to floats only here, once per update)."""
+        self._set_seed()
+        self.optimizer.zero_grad()
+        logs, sample_size = [], 0
+        for i, sample in enumerate(samples):
+            sample = self._prepare_sample(sample)
+            last = i == len(samples) - 1
+            ctx = self.model.no_sync() if (self.world > 1 and not last) else contextlib.nullcontext()
+            with ctx:
+                loss, ss, log = self.task.train_step(sample, self.model, self.criterion, self.optimizer, self.num_updates)
+            logs.append(log)
+            sample_size += ss
+        if self.world > 1:
+            self.model.all_reduce()  # waits for the overlapped bucket reductions; launches the stragglers
+        # logging scalars + sample_size: ONE fp64 device vector, one small all-reduce (C3-C5 folded), no host sync
+        # before the optimizer kernels are queued.
+        keys = sorted(k for k in logs[0].keys())
+        vec = torch.stack([sum(torch.as_tensor(l[k], dtype=torch.float64, device=self.device) for l in logs) for k in keys])
+        if self.world > 1:
+            dist.all_reduce(vec)
+        total_ss = vec[keys.index("sample_size")]
+        gnorm = self.optimizer.step(multiply=(self.world / total_ss).float())
+        self.num_updates += 1
+        out = dict(zip(keys, vec.tolist()))  # the step's only host sync
+        out["gnorm"] = float(gnorm)
+        out["lr"] = self.optimizer.get_lr()
+        return out

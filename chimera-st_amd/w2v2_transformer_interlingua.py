@@ -1,0 +1,174 @@
+"""Mirror of fairseq/models/chimera/w2v2_transformer_interlingua.py — the Chimera model:
+S2TTransformerInterlinguaModelW2V2 (:28-152), S2T_W2V2_TransformerInterlinguaEncoder (:155-312) with the M-slot
+shared-semantic-memory module (:264-298), arch s2t_transformer_w2v2_interlingua_base (:315-343).
+
+Memory module on MI355X: the reference runs each memory layer over cat(h_enc, memory) (L+M rows) with a column mask
+that hides the M memory columns and keeps only the last M output rows; rows are independent, so this build runs the
+layer on the M query rows only, with K/V = the layer's self_attn_layer_norm + k/v projections of h_enc — the
+same numbers for the rows that are kept (Q1: padded encoder frames ARE attended; Q2: memory columns are never
+attended), 3.7x fewer FLOPs (credited as such in bench.py, never as the reference-shaped count)."""
+import logging
+
+import torch
+import torch.nn as nn
+
+from .fairseq_model import EncoderOut, lengths_to_padding_mask
+from .modules import Embedding, TransformerEncoderLayer, to_batch_major, to_time_major_view
+from .registry import register_model, register_model_architecture
+from .s2t_transformer import TransformerDecoderScriptable
+from .w2v2_transformer import S2T_W2V2_TransformerEncoder, S2TTransformerModelW2V2, base_architecture
+
+logger = logging.getLogger(__name__)
+
+
+@register_model("s2t_transformer_w2v2_interlingua")
+class S2TTransformerInterlinguaModelW2V2(S2TTransformerModelW2V2):
+    def __init__(self, encoder, decoder, debug_options):
+        super().__init__(encoder, decoder)
+        self.debug_options = debug_options
+
+    @staticmethod
+    def add_args(parser):
+        """w2v2_transformer_interlingua.py:40-76."""
+        S2TTransformerModelW2V2.add_args(parser)
+        parser.add_argument("--interlingua-length", type=int, default=16)
+        parser.add_argument("--interlingua-layers", type=int, default=3)
+        parser.add_argument("--interlingua-debug-options", type=str, nargs="+", default=[], choices=["modal_embedding"])
+        parser.add_argument("--non-shared-encoder-layers", type=int, default=0)
+        for f in ("--fix-wav2vec", "--fix-interlingua", "--fix-decoder", "--fix-decoder-transformers",
+                  "--fix-encoder-transformers", "--reset-encoder", "--no-interlingua"):
+            parser.add_argument(f, action="store_true", default=False)
+
+    @classmethod
+    def build_model(cls, args, task):
+        s2t_transformer_w2v2_interlingua_base(args)
+
+        def build_embedding(dictionary, embed_dim):
+            return Embedding(len(dictionary), embed_dim, dictionary.pad())
+
+        encoder_embed_tokens = (build_embedding(task.source_dictionary, args.encoder_embed_dim)
+                                if task.source_dictionary is not None else None)
+        encoder = cls.build_encoder(args, task.source_dictionary, encoder_embed_tokens)
+        decoder_embed_tokens = build_embedding(task.target_dictionary, args.decoder_embed_dim)
+        decoder = cls.build_decoder(args, task.target_dictionary, decoder_embed_tokens)
+        if args.fix_wav2vec:
+            encoder.wav2vec_model.requires_grad_(False)
+        if args.fix_encoder_transformers:
+            encoder.transformer_layers.requires_grad_(False)
+        if args.fix_decoder_transformers:
+            decoder.layers.requires_grad_(False)
+        if args.fix_decoder:
+            decoder.requires_grad_(False)
+        if args.fix_interlingua:
+            encoder.interlingua_layers.requires_grad_(False)
+            encoder.interlingua_embedding.requires_grad_(False)
+        return cls(encoder, decoder, args.interlingua_debug_options)
+
+    @classmethod
+    def build_encoder(cls, args, src_dict=None, encoder_embed_tokens=None):
+        return S2T_W2V2_TransformerInterlinguaEncoder(args, src_dict, encoder_embed_tokens)
+
+    @classmethod
+    def build_decoder(cls, args, tgt_dict, embed_tokens):
+        return TransformerDecoderScriptable(args, tgt_dict, embed_tokens)
+
+    def forward_with_internal(self, src_tokens, src_lengths, prev_output_tokens, **extra_args):
+        """:137-146 -> ((logits, extra), memory [M,B,C])."""
+        encoder_out = self.encoder(src_tokens=src_tokens, src_lengths=src_lengths)
+        decoder_out = self.decoder(prev_output_tokens=prev_output_tokens, encoder_out=encoder_out)
+        return decoder_out, encoder_out.encoder_out
+
+    def upgrade_state_dict_named(self, state_dict, name):
+        super().upgrade_state_dict_named(state_dict, name)
+        state_dict.pop("encoder.stashed_weights", None)
+        state_dict.pop("decoder.stashed_weights", None)
+        return state_dict
+
+
+class S2T_W2V2_TransformerInterlinguaEncoder(S2T_W2V2_TransformerEncoder):
+    def __init__(self, args, src_tokens, embed_tokens):
+        super().__init__(args)
+        self.max_source_positions = args.max_source_positions
+        self.text_embed_tokens = embed_tokens
+        if embed_tokens is not None:
+            self.encoder_embed_dim = embed_tokens.embedding_dim
+        self.debug_options = args.interlingua_debug_options
+        assert "modal_embedding" not in self.debug_options, "debug-only option, not built"
+        self.non_shared_encoder_layers = args.non_shared_encoder_layers
+        assert self.non_shared_encoder_layers == 0, "non-shared encoder layers are not used by chimera/scripts"
+        self.reset_encoder = args.reset_encoder
+        self.no_interlingua = args.no_interlingua
+        assert args.interlingua_layers >= 1
+        self.interlingua_embedding = Embedding(args.interlingua_length, args.encoder_embed_dim, 0)
+        self.interlingua_layers = nn.ModuleList([TransformerEncoderLayer(args) for _ in range(args.interlingua_layers)])
+        self.modal_embedding = None
+
+    def upgrade_state_dict_named(self, state_dict, name):
+        embed_weight_name = name + ".text_embed_tokens.weight"
+        if self.text_embed_tokens is None:
+            state_dict.pop(embed_weight_name, None)
+        return state_dict
+
+    def max_positions(self):
+        return None
+
+    def forward(self, src_tokens, src_lengths, **extra_args):
+        """:207-312."""
+        is_text = not src_tokens.dtype.is_floating_point
+        if is_text:
+            feature = self.text_embed_tokens(src_tokens)  # B x T x C batch-major
+            input_lengths = src_lengths
+            feature_tm = to_time_major_view(feature)
+        else:
+            w2v_feature, _, input_lengths = self._get_w2v_feature(src_tokens, src_lengths)
+            feature_tm, input_lengths = self.subsample(w2v_feature, input_lengths)
+        xb = self.embed_scale * to_batch_major(feature_tm)
+        encoder_padding_mask = lengths_to_padding_mask(input_lengths, max_len=xb.size(1))
+        if is_text:  # Q3: only text gets sinusoidal positions (:233-236)
+            xb = xb + self.embed_positions(encoder_padding_mask).to(xb.dtype)
+        x = to_time_major_view(self.dropout_module(xb))
+        for layer in self.transformer_layers:
+            x = layer(x, encoder_padding_mask)
+        if self.layer_norm is not None:
+            x = self.layer_norm(x)
+        length_h, batch_size, _ = x.shape
+        if self.no_interlingua:
+            interlingua = x
+            length_i = length_h
+        else:
+            h_enc = x
+            interlingua = self.interlingua_embedding.weight.unsqueeze(0).expand(batch_size, -1, -1)  # B x M x C
+            length_i = interlingua.shape[1]
+            interlingua = to_time_major_view(interlingua.contiguous())
+            for layer in self.interlingua_layers:
+                # == layer(cat(h_enc, mem), no key padding (Q1), column mask hiding the memory columns (Q2))[-M:]
+                interlingua = layer(interlingua, None, kv=h_enc)
+        encoder_padding_mask = torch.zeros(batch_size, length_i, device=x.device, dtype=torch.bool)
+        return EncoderOut(encoder_out=interlingua, encoder_padding_mask=encoder_padding_mask, encoder_embedding=None,
+                          encoder_states=None, src_tokens=None, src_lengths=None)
+
+
+@register_model_architecture("s2t_transformer_w2v2_interlingua", "s2t_transformer_w2v2_interlingua_base")
+def s2t_transformer_w2v2_interlingua_base(args):
+    """:318-343 incl. quirk Q4: base_architecture runs first, so the 256/4-head defaults below never apply, and
+    fix_encoder_transformers reads fix_decoder_transformers."""
+    base_architecture(args)
+    args.use_asr_finetune_w2v = getattr(args, "use_asr_finetune_w2v", False)
+    args.encoder_embed_dim = getattr(args, "encoder_embed_dim", 256)
+    args.encoder_ffn_embed_dim = getattr(args, "encoder_ffn_embed_dim", 256 * 8)
+    args.encoder_attention_heads = getattr(args, "encoder_attention_heads", 4)
+    args.max_source_positions = getattr(args, "max_source_positions", 1000000)
+    args.decoder_attention_heads = getattr(args, "decoder_attention_heads", 4)
+    args.dropout = getattr(args, "dropout", 0.1)
+    args.fix_wav2vec = getattr(args, "fix_wav2vec", False)
+    args.load_pretrained_encoder_from = getattr(args, "load_pretrained_encoder_from", None)
+    args.non_shared_encoder_layers = getattr(args, "non_shared_encoder_layers", 0)
+    args.fix_encoder_transformers = getattr(args, "fix_decoder_transformers", False)
+    args.fix_decoder_transformers = getattr(args, "fix_decoder_transformers", False)
+    args.fix_decoder = getattr(args, "fix_decoder", False)
+    args.fix_interlingua = getattr(args, "fix_interlingua", False)
+    args.no_interlingua = getattr(args, "no_interlingua", False)
+    args.reset_encoder = getattr(args, "reset_encoder", False)
+    args.interlingua_length = getattr(args, "interlingua_length", 16)
+    args.interlingua_layers = getattr(args, "interlingua_layers", 3)
+    args.interlingua_debug_options = getattr(args, "interlingua_debug_options", [])

@@ -1,0 +1,279 @@
+"""wav2vec2 feature path (features_only) — mirror of fairseq/models/wav2vec/wav2vec2.py on the Chimera
+path: ConvFeatureExtractionModel (:685-763), Wav2Vec2Model.forward features_only branch (:527-586) and
+extract_features (:650-652), TransformerEncoder (:766-861), TransformerSentenceEncoderLayer (:864-959).
+
+Pre-training-only parts (quantizer, negatives sampling, masking) are out of scope;
+their parameters that exist in every checkpoint (mask_emb, project_q, final_proj) are kept so
+state dicts round-trip.
+
+MI355X layout: the whole CNN runs channels-last [B, L, C] so every conv after layer 0 is an implicit GEMM on
+MFMA tiles with the GELU in the epilogue, and `features.transpose(1, 2)` (:539) is free."""
+import math
+from argparse import Namespace
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import functional as CF
+from .modules import LayerNorm, Linear, MultiheadAttention, to_batch_major, to_time_major_view
+from .registry import register_model, register_model_architecture
+
+
+class _Slot(nn.Module):
+    """Parameter holder that keeps the reference's nn.Sequential index in state-dict keys (conv_layers.N.0.weight ...)."""
+
+
+class ConvFeatureExtractionModel(nn.Module):
+    """wav2vec2.py:685-763, mode "default": layer 0 = Conv1d(no bias)+GroupNorm(C,C)+GELU, layers 1.. = Conv1d+GELU."""
+
+    def __init__(self, conv_layers, dropout=0.0, mode="default", conv_bias=False):
+        super().__init__()
+        assert mode == "default", "extractor_mode=layer_norm is not on the Chimera path (wav2vec_small uses default)"
+        assert not conv_bias and dropout == 0.0
+        self.conv_spec = [tuple(c) for c in conv_layers]
+        self.conv_layers = nn.ModuleList()
+        in_d = 1
+        for i, (dim, k, stride) in enumerate(self.conv_spec):
+            blk = nn.Module()
+            conv = nn.Module()
+            conv.weight = nn.Parameter(torch.empty(dim, in_d, k))
+            nn.init.kaiming_normal_(conv.weight)
+            blk.add_module("0", conv)
+            if i == 0:
+                gn = nn.Module()
+                gn.weight = nn.Parameter(torch.ones(dim))
+                gn.bias = nn.Parameter(torch.zeros(dim))
+                blk.add_module("2", gn)
+            self.conv_layers.append(blk)
+            in_d = dim
+
+    def forward(self, x):
+        """x [B,S] raw samples -> channels-last features [B, T1, C] (the reference returns [B,C,T1])."""
+        l0 = self.conv_layers[0]
+        dim, k, stride = self.conv_spec[0]
+        y = CF.conv0_gn_gelu(x, getattr(l0, "0").weight, getattr(l0, "2").weight, getattr(l0, "2").bias, stride)
+        z = None
+        n = len(self.conv_spec)
+        for i in range(1, n):
+            dim, k, stride = self.conv_spec[i]
+            w = getattr(self.conv_layers[i], "0").weight
+            # fold GELU' of layer i-1 into layer i's col2im pass; layer i then receives d/dz directly
+            y, z = CF.conv1d_cl(y, w, None, stride, pad=0, act="gelu", prev_z=z, grad_is_dz=(i < n - 1))
+        return y
+
+    def output_length(self, s):
+        for (_, k, st) in self.conv_spec:
+            s = (s - k) // st + 1
+        return s
+
+
+class TransformerSentenceEncoderLayer(nn.Module):
+    """wav2vec2.py:864-959, post-norm branch (layer_norm_first=False)."""
+
+    def __init__(self, embedding_dim=768, ffn_embedding_dim=3072, num_attention_heads=8, dropout=0.1,
+                 attention_dropout=0.1, activation_dropout=0.1, activation_fn="relu", layer_norm_first=False):
+        super().__init__()
+        assert not layer_norm_first, "layer_norm_first=True (wav2vec2 large) is not built yet"
+        self.embedding_dim = embedding_dim
+        self.dropout, self.activation_dropout = dropout, activation_dropout
+        self.activation_fn = activation_fn
+        self.self_attn = MultiheadAttention(embedding_dim, num_attention_heads, dropout=attention_dropout, self_attention=True)
+        self.layer_norm_first = layer_norm_first
+        self.self_attn_layer_norm = LayerNorm(embedding_dim)
+        self.fc1 = Linear(embedding_dim, ffn_embedding_dim)
+        self.fc2 = Linear(ffn_embedding_dim, embedding_dim)
+        self.final_layer_norm = LayerNorm(embedding_dim)
+
+    def forward(self, x, self_attn_mask=None, self_attn_padding_mask=None, need_weights=False, att_args=None):
+        if self.training and (self.dropout > 0 or self.activation_dropout > 0):
+            raise NotImplementedError("wav2vec2 encoder dropout > 0 in training is not built yet (set dropout 0 in the w2v args)")
+        residual = x
+        x, _ = self.self_attn(query=x, key=x, value=x, key_padding_mask=self_attn_padding_mask, need_weights=False,
+                              resid=residual)  # x = residual + attn (out_proj epilogue)
+        x = self.self_attn_layer_norm(x)
+        residual = x
+        h = self.fc1(to_batch_major(x), act=self.activation_fn)
+        x = to_time_major_view(self.fc2(h, resid=to_batch_major(residual)))
+        x = self.final_layer_norm(x)
+        return x, None
+
+
+def init_bert_params(module):
+    """modules/transformer_sentence_encoder.py:22-50 — normal(0, 0.02) for Linear / attention projections."""
+    if isinstance(module, Linear):
+        module.weight.data.normal_(mean=0.0, std=0.02)
+        if module.bias is not None:
+            module.bias.data.zero_()
+    if isinstance(module, MultiheadAttention):
+        for p in (module.q_proj, module.k_proj, module.v_proj):
+            p.weight.data.normal_(mean=0.0, std=0.02)
+
+
+class TransformerEncoder(nn.Module):
+    """wav2vec2.py:766-861: weight-normed grouped pos_conv + SamePad + GELU, LayerNorm, N post-norm layers, layerdrop."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.dropout = args.dropout
+        self.embedding_dim = args.encoder_embed_dim
+        self.conv_pos, self.conv_pos_groups = args.conv_pos, args.conv_pos_groups
+        cg = self.embedding_dim // args.conv_pos_groups
+        std = math.sqrt(4 / (args.conv_pos * self.embedding_dim))
+        pc = nn.Module()  # nn.utils.weight_norm(conv, name="weight", dim=2): weight_g [1,1,k], weight_v [C, C/g, k]
+        v = torch.empty(self.embedding_dim, cg, args.conv_pos).normal_(0, std)
+        pc.bias = nn.Parameter(torch.zeros(self.embedding_dim))
+        pc.weight_g = nn.Parameter(v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt())
+        pc.weight_v = nn.Parameter(v)
+        self.pos_conv = nn.Module()
+        self.pos_conv.add_module("0", pc)
+        self.layers = nn.ModuleList([
+            TransformerSentenceEncoderLayer(
+                embedding_dim=self.embedding_dim, ffn_embedding_dim=args.encoder_ffn_embed_dim,
+                num_attention_heads=args.encoder_attention_heads, dropout=self.dropout,
+                attention_dropout=args.attention_dropout, activation_dropout=args.activation_dropout,
+                activation_fn=args.activation_fn, layer_norm_first=args.layer_norm_first)
+            for _ in range(args.encoder_layers)])
+        self.layer_norm_first = args.layer_norm_first
+        self.layer_norm = LayerNorm(self.embedding_dim)
+        self.layerdrop = args.encoder_layerdrop
+        self.apply(init_bert_params)
+
+    def pos_conv_weight(self):
+        pc = getattr(self.pos_conv, "0")
+        v = pc.weight_v
+        norm = v.float().pow(2).sum(dim=(0, 1), keepdim=True).sqrt()
+        return (v.float() * (pc.weight_g.float() / norm)).to(v.dtype)
+
+    def forward(self, x, padding_mask=None):
+        x, padding_mask = self.extract_features(x, padding_mask)
+        return x, padding_mask
+
+    def extract_features(self, x, padding_mask=None):
+        """x [B,T,C] batch-major."""
+        if padding_mask is not None:
+            x = CF.mask_rows(x, padding_mask)  # x[padding_mask] = 0 (:820-821)
+        pc = getattr(self.pos_conv, "0")
+        x = CF.pos_conv_gelu_residual(x, self.pos_conv_weight(), pc.bias, self.conv_pos_groups)  # x += GELU(SamePad(conv(x)))
+        x = self.layer_norm(x)
+        if self.training and self.dropout > 0:
+            raise NotImplementedError("wav2vec2 encoder dropout > 0 in training is not built yet")
+        x = to_time_major_view(x)
+        for layer in self.layers:
+            dropout_probability = np.random.random()  # same RNG call order as the reference (:836-840)
+            if not self.training or (dropout_probability > self.layerdrop):
+                x, _ = layer(x, self_attn_padding_mask=padding_mask, need_weights=False)
+        return to_batch_major(x), padding_mask
+
+
+@register_model("wav2vec2")
+class Wav2Vec2Model(nn.Module):
+    """wav2vec2.py:33-680, restricted to what extract_features (features_only) touches."""
+
+    @staticmethod
+    def add_args(parser):
+        pass
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        feature_enc_layers = eval(args.conv_feature_layers)
+        self.embed = feature_enc_layers[-1][0]
+        self.feature_extractor = ConvFeatureExtractionModel(conv_layers=feature_enc_layers, dropout=0.0,
+                                                            mode=args.extractor_mode, conv_bias=args.conv_bias)
+        self.post_extract_proj = (Linear(self.embed, args.encoder_embed_dim)
+                                  if self.embed != args.encoder_embed_dim and not args.quantize_input else None)
+        self.feature_grad_mult = args.feature_grad_mult
+        self.dropout_input_p = getattr(args, "dropout_input", 0)
+        final_dim = args.final_dim if args.final_dim > 0 else args.encoder_embed_dim
+        self.mask_emb = nn.Parameter(torch.FloatTensor(args.encoder_embed_dim).uniform_())
+        self.encoder = TransformerEncoder(args)
+        self.layer_norm = LayerNorm(self.embed)
+        # pre-training heads: never on the ST path, kept for checkpoint compatibility
+        self.project_q = Linear(self.embed, final_dim) if not getattr(args, "quantize_targets", False) else None
+        self.final_proj = Linear(args.encoder_embed_dim, final_dim)
+        self._passthrough_state = {}
+
+    @classmethod
+    def build_model(cls, args, task=None):
+        base_architecture(args)
+        return cls(args)
+
+    def forward(self, source, padding_mask=None, mask=True, features_only=False):
+        assert features_only and not mask, "only the features_only / mask=False path is built (SURVEY §2.1 #2)"
+        feats = self.feature_extractor(source)  # [B, T1, C] channels-last
+        if self.feature_grad_mult <= 0:
+            feats = feats.detach()
+        elif self.feature_grad_mult != 1.0:
+            feats = _GradMultiply.apply(feats, self.feature_grad_mult)
+        feats = self.layer_norm(feats)  # transpose(1,2) is free in channels-last (:539-540)
+        if padding_mask is not None:
+            t1 = feats.size(1)
+            extra = padding_mask.size(1) % t1
+            if extra > 0:
+                padding_mask = padding_mask[:, :-extra]
+            padding_mask = padding_mask.view(padding_mask.size(0), t1, -1).all(-1)
+        if self.post_extract_proj is not None:
+            feats = self.post_extract_proj(feats)
+        if self.training and self.dropout_input_p > 0:
+            raise NotImplementedError("dropout_input > 0 is not built yet")
+        x, padding_mask = self.encoder(feats, padding_mask=padding_mask)
+        return {"x": x, "padding_mask": padding_mask}
+
+    def extract_features(self, source, padding_mask, mask=False):
+        res = self.forward(source, padding_mask, mask=mask, features_only=True)
+        return res["x"], res["padding_mask"]
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Accept full pre-training checkpoints: quantizer.* / project_q etc. that this build does not instantiate
+        are parked and re-emitted by state_dict()."""
+        own = set(super().state_dict().keys())
+        extra = {k: v for k, v in state_dict.items() if k not in own}
+        self._passthrough_state = {k: v for k, v in extra.items() if k.split(".")[0] in ("quantizer", "input_quantizer", "project_inp", "target_glu", "project_q")}
+        rest = {k: v for k, v in state_dict.items() if k not in self._passthrough_state}
+        return super().load_state_dict(rest, strict=strict)
+
+
+class _GradMultiply(torch.autograd.Function):
+    """modules/grad_multiply.py."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad * ctx.scale, None
+
+
+@register_model_architecture("wav2vec2", "wav2vec2")
+def base_architecture(args):
+    """wav2vec2.py:962-1029 defaults (only the ones the feature path reads, plus checkpoint-visible ones)."""
+    d = dict(
+        extractor_mode="default", encoder_layers=12, encoder_embed_dim=768, encoder_ffn_embed_dim=3072,
+        encoder_attention_heads=12, activation_fn="gelu", dropout=0.1, attention_dropout=0.1, activation_dropout=0.0,
+        final_dim=0, layer_norm_first=False, encoder_layerdrop=0.0,
+        conv_feature_layers="[(512, 10, 5)] + [(512, 8, 4)] + [(512, 4, 2)] * 3 + [(512, 1, 1)]",
+        logit_temp=0.1, quantize_targets=False, quantize_input=False, same_quantizer=False, feature_grad_mult=1.0,
+        latent_vars=320, latent_groups=2, latent_dim=0, dropout_input=0, dropout_features=0, conv_pos=128,
+        conv_pos_groups=16, conv_bias=False, target_glu=False,
+    )
+    for k, v in d.items():
+        if not hasattr(args, k):
+            setattr(args, k, v)
+
+
+def wav2vec_small_args(**over):
+    """The published wav2vec_small.pt hyper-parameters (SURVEY §8 caveat): 7-layer stride-320 CNN, 12x768 encoder,
+    feature_grad_mult 0.1, layerdrop 0.05."""
+    ns = Namespace(
+        conv_feature_layers="[(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512, 2, 2)] * 2", encoder_layers=12, encoder_embed_dim=768,
+        encoder_ffn_embed_dim=3072, encoder_attention_heads=12, activation_fn="gelu", dropout=0.1, attention_dropout=0.1,
+        activation_dropout=0.0, encoder_layerdrop=0.05, feature_grad_mult=0.1, final_dim=256, quantize_targets=True,
+        conv_pos=128, conv_pos_groups=16, layer_norm_first=False, extractor_mode="default", conv_bias=False,
+        dropout_input=0.1, dropout_features=0.1)
+    for k, v in over.items():
+        setattr(ns, k, v)
+    base_architecture(ns)
+    return ns
