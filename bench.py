@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py — train utterances/sec of the Chimera-ST hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (config.workload): BASELINE configs[1] — `s2t_transformer_w2v2` with the s2t_transformer_m dimensions
+(d 512, ffn 2048, 8 heads, 12 encoder + 6 decoder layers, tied 10 000-way vocabulary) behind the full wav2vec2-small
+front end (7-layer CNN over raw 16 kHz samples + 12 x 768 Transformer), label-smoothed CE, Adam — one full update
+(fwd + bwd + gradient all-reduce + optimizer) per step on a synthetic batch of 32 utterances x <= 30 s per GPU
+(weak scaling), inputs resident in HBM when the clock starts.  Random-init weights, seeded synthetic data.
+Prints ONE JSON line on rank 0."""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+from argparse import Namespace
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK = {"bf16": 2500.0, "f32": 157.3}  # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def build(args, device):
+    importlib.import_module("chimera-st_amd")
+    w2t = importlib.import_module("chimera-st_amd.w2v2_transformer")
+    importlib.import_module("chimera-st_amd.w2v2_transformer_interlingua")
+    importlib.import_module("chimera-st_amd.criterions")
+    tasks = importlib.import_module("chimera-st_amd.tasks")
+    reg = importlib.import_module("chimera-st_amd.registry")
+    w2v = importlib.import_module("chimera-st_amd.wav2vec2")
+    Trainer = importlib.import_module("chimera-st_amd.trainer").Trainer
+    # wav2vec_small hyper-parameters; dropout/layerdrop 0 so every layer runs every step
+    w2t.SYNTHETIC_W2V["wav2vec_small_bench"] = w2v.wav2vec_small_args(dropout=0.0, attention_dropout=0.0, activation_dropout=0.0,
+                                                                     encoder_layerdrop=0.0, dropout_input=0.0, dropout_features=0.0)
+    chimera = args.model == "chimera"
+    ns = Namespace(
+        arch="s2t_transformer_w2v2_interlingua_base" if chimera else "s2t_transformer_w2v2",
+        task="triplet", criterion="triplet_st_mt_contrastive" if chimera else "label_smoothed_cross_entropy",
+        w2v2_model_path="synthetic:wav2vec_small_bench", data=None, synthetic_vocab_size=10000,
+        dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, share_decoder_input_output_embed=True,
+        max_source_positions=2000000, max_target_positions=1024, label_smoothing=0.1,
+        bf16=(args.dtype == "bf16"), lr=[2e-4], adam_betas="(0.9, 0.98)", adam_eps=1e-8, weight_decay=0.0, clip_norm=10.0,
+        warmup_updates=4000, warmup_init_lr=1e-7, seed=1, bucket_cap_mb=64,
+        loss_ratio=[1.0, 1.0, 1.0], contrastive_temp=0.1, contrastive_increase_until=None, kd_ratio=[None, None])
+    if chimera:  # chimera/scripts/train-en2any-ST.sh: 6 shared encoder layers + 3 memory layers, M = 64
+        ns.encoder_layers, ns.interlingua_layers, ns.interlingua_length = 6, 3, 64
+    torch.manual_seed(1)
+    task = reg.setup_task(ns)
+    reg.ARCH_CONFIG_REGISTRY[ns.arch](ns)
+    model = task.build_model(ns)
+    criterion = task.build_criterion(ns)
+    trainer = Trainer(ns, task, model, criterion, device=device)
+    return trainer, task, tasks, ns
+
+
+def make_batch(tasks, task, args, rank, device):
+    g = torch.Generator().manual_seed(1 + rank)
+    smax = int(args.seconds * 16000)
+    if args.lengths == "max":
+        audio = [smax] * args.batch
+    else:  # uniform in [10 s, 30 s], multiples of 320, collater sorts descending
+        lo = min(160000, smax)
+        audio = [int(torch.randint(lo // 320, smax // 320 + 1, (1,), generator=g)) * 320 for _ in range(args.batch)]
+        audio[0] = smax
+    tgt = [int(torch.randint(16, 129, (1,), generator=g)) for _ in range(args.batch)]
+    src = [int(torch.randint(8, 97, (1,), generator=g)) for _ in range(args.batch)]
+    return tasks.synthetic_sample(task.target_dictionary, args.batch, audio, tgt, src, seed=1 + rank, device=device)
+
+
+def cpu_baseline(trainer, task, tasks, ns, args):
+    """The oracle (CPU fp32 restatement pinned to the reference, oracle/chimera_oracle.py) timed on this box's host
+    cores on a bounded sample of the same workload: ONE full update (fwd + bwd + Adam) on one 30 s utterance."""
+    from oracle import chimera_oracle as O
+    wa = importlib.import_module("chimera-st_amd.w2v2_transformer").SYNTHETIC_W2V["wav2vec_small_bench"]
+    cfg = dict(conv_layers=eval(wa.conv_feature_layers), conv_pos=wa.conv_pos, conv_pos_groups=wa.conv_pos_groups,
+               w2v_layers=wa.encoder_layers, w2v_heads=wa.encoder_attention_heads, feature_grad_mult=wa.feature_grad_mult,
+               d=ns.encoder_embed_dim, heads=ns.encoder_attention_heads, dec_heads=ns.decoder_attention_heads,
+               enc_layers=ns.encoder_layers, dec_layers=ns.decoder_layers, mem_layers=getattr(ns, "interlingua_layers", 0))
+    p = {k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point() and "_float_tensor" not in k and k != "decoder.version")
+         for k, v in trainer.get_model().state_dict().items()}
+    p["decoder.output_projection.weight"] = p["decoder.embed_tokens.weight"]
+    cores = torch.get_num_threads()
+    secs = min(args.seconds, args.cpu_seconds)
+    fn = O.triplet_criterion if args.model == "chimera" else O.lsce_criterion
+
+    def one(nsamp, audio_s, u):
+        s = tasks.synthetic_sample(task.target_dictionary, nsamp, [int(audio_s * 16000)] * nsamp, [u] * nsamp, [u] * nsamp, seed=5)
+        t0 = time.time()
+        out = fn(p, s, cfg)
+        out["loss"].backward()
+        leaves = list({id(t): t for t in p.values() if t.requires_grad and t.grad is not None}.values())
+        with torch.no_grad():
+            for t in leaves:
+                O.adam_step(t, t.grad, torch.zeros_like(t), torch.zeros_like(t), 1, 2e-4)
+                t.grad = None
+        return time.time() - t0
+
+    one(1, 1.0, 8)  # warm the thread pool / allocator
+    dt = one(1, secs, 64)
+    return {"value": 1.0 / dt, "unit": "utterances/s", "cores": cores, "kind": "port",
+            "sample": "1 update (fwd+bwd+Adam) of the CPU fp32 oracle on 1 utterance x %.0f s + 64 target tokens, same model dims" % secs}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
+    ap.add_argument("--seconds", type=float, default=30.0, help="max audio length")
+    ap.add_argument("--lengths", default="uniform", choices=["uniform", "max"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--model", default="s2t_w2v2", choices=["s2t_w2v2", "chimera"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=30.0)
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    dist_mod = importlib.import_module("chimera-st_amd.distributed")
+    rank, world = dist_mod.distributed_init()
+    assert world == args.gpus or (world == 1 and args.gpus == 1), "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    lib = importlib.import_module("chimera-st_amd.lib")
+    lib.load()
+
+    trainer, task, tasks, ns = build(args, device)
+    sample = make_batch(tasks, task, args, rank, device)  # resident in HBM before the clock starts
+    import torch.distributed as dist
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.train_step([sample])
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = trainer.train_step([sample])
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t)
+
+    roof = None
+    if not args.no_roofline and rank == 0:
+        lib.prof_enable(True)  # hipEvent pair around every launch of one extra (untimed) update, on the launch stream
+        trainer.train_step([sample])
+        torch.cuda.synchronize()
+        table = lib.prof_query()
+        lib.prof_enable(False)
+        dom = max(table.items(), key=lambda kv: kv[1]["ms"])
+        name, r = dom
+        if r["flops"] > 0:
+            ach = r["flops"] / (r["ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK[args.dtype], "unit": "TFLOP/s",
+                    "frac": ach / PEAK[args.dtype], "traffic": None, "launches": r["launches"],
+                    "avg_launch_ms": r["ms"] / max(r["launches"], 1)}
+        else:
+            ach = r["bytes"] / (r["ms"] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                    "traffic": None, "launches": r["launches"], "avg_launch_ms": r["ms"] / max(r["launches"], 1)}
+        roof["per_class_ms"] = {k: round(v["ms"], 3) for k, v in table.items() if v["launches"]}
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(trainer, task, tasks, ns, args)
+
+    if rank == 0:
+        utt = world * args.batch * args.steps
+        line = {
+            "metric": "train utterances/sec, MuST-C EN-DE s2t_transformer_m, 1/2/4/8 MI355X",
+            "value": utt / dt, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": ("s2t_transformer_w2v2 (s2t_transformer_m dims: d512/ffn2048/8h, 12 enc + 6 dec) + wav2vec2-small "
+                                    "frontend (7-layer CNN on raw 16 kHz + 12x768 encoder), label_smoothed_cross_entropy, Adam"
+                                    if args.model == "s2t_w2v2" else
+                                    "Chimera s2t_transformer_w2v2_interlingua_base (6 enc + 3 memory layers, M=64) + wav2vec2-small, "
+                                    "triplet_st_mt_contrastive, Adam"),
+                       "batch_per_gpu": args.batch, "global_batch": world * args.batch, "max_audio_s": args.seconds,
+                       "audio_lengths": args.lengths, "target_tokens": "16-128", "vocab": 10000, "dropout": 0.0,
+                       "parallelism": "dp%d" % world, "loss": float(out["loss"])},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
