@@ -82,7 +82,10 @@ def parse_args_and_arch(argv, extra_defaults=None):
     known, _ = base.parse_known_args(argv)
     parser = argparse.ArgumentParser(allow_abbrev=False, parents=[base])
     add_common_args(parser)
-    ARCH_MODEL_REGISTRY[known.arch].add_args(parser)
+    # options.py:137-145: model-specific flags live in a group with argument_default=SUPPRESS so that the arch function's
+    # getattr(args, name, default) sees only what the user actually passed
+    model_group = parser.add_argument_group("Model-specific configuration", argument_default=argparse.SUPPRESS)
+    ARCH_MODEL_REGISTRY[known.arch].add_args(model_group)
     TASK_REGISTRY[known.task].add_args(parser)
     CRITERION_REGISTRY[known.criterion].add_args(parser)
     if extra_defaults:
