@@ -1,0 +1,90 @@
+"""GPU tests of the decode path (bit-exact token ids vs the reference's SequenceGenerator fixtures) and of the fused
+optimizer / trainer step (vs two trainer-equivalent reference updates)."""
+from argparse import Namespace
+from importlib import import_module
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_sample, load_golden
+from test_model_gpu import assert_close, build_from_golden, to_cuda
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("beam", [1, 5])
+def test_decode_matches_reference_generator(beam):
+    g = load_golden("decode_tiny.npz")
+    model, task, args = build_from_golden(g, "chimera", torch.float32)
+    SG = import_module("chimera-st_amd.sequence_generator").SequenceGenerator
+    gen = SG([model], task.target_dictionary, beam_size=beam, max_len_a=0, max_len_b=12, min_len=1)
+    sample = to_cuda(golden_sample(g))
+    hyps = gen.generate([model], sample)
+    for b in range(len(hyps)):
+        for r in range(min(beam, 3)):
+            key = "gen/beam%d/b%d/r%d/" % (beam, b, r)
+            assert hyps[b][r]["tokens"].tolist() == g[key + "tokens"].tolist(), key  # bit-exact token ids
+            assert abs(float(hyps[b][r]["score"]) - float(g[key + "score"])) < 1e-3
+            assert_close(hyps[b][r]["positional_scores"], g[key + "pos_scores"], 1e-3, key + "pos_scores")
+
+
+def test_decode_text_input_and_incremental_equals_full():
+    g = load_golden("decode_tiny.npz")
+    model, task, args = build_from_golden(g, "chimera", torch.float32)
+    SG = import_module("chimera-st_amd.sequence_generator").SequenceGenerator
+    gen = SG([model], task.target_dictionary, beam_size=1, max_len_a=0, max_len_b=12)
+    s = to_cuda(golden_sample(g))
+    txt = {"net_input": {"src_tokens": s["src_text"], "src_lengths": s["src_text_lengths"]}}
+    hyps = gen.generate([model], txt)
+    for b in range(len(hyps)):
+        assert hyps[b][0]["tokens"].tolist() == g["gen/text_beam1/b%d/r0/tokens" % b].tolist()
+    # incremental-state decoder == full decoder on the same prefix (1e-6 in the reference)
+    model.eval()
+    with torch.no_grad():
+        enc = model.encoder(s["net_input"]["src_tokens"], s["net_input"]["src_lengths"])
+        prev = s["net_input"]["prev_output_tokens"]
+        full, _ = model.decoder(prev, encoder_out=enc)
+        inc = {}
+        outs = []
+        for t in range(prev.size(1)):
+            o, _ = model.decoder(prev[:, :t + 1], encoder_out=enc, incremental_state=inc)
+            outs.append(o[:, -1])
+        inc_logits = torch.stack(outs, 1)
+    # rows after a pad token differ by construction (the full pass masks pad keys); compare non-pad prefixes
+    m = prev.ne(1)
+    assert float((full - inc_logits)[m].abs().max()) < 1e-4
+
+
+def test_two_updates_match_reference_optimizer():
+    """multiply_grads(1/sample_size) -> clip 0.05 -> Adam(wd 0.01) -> inverse_sqrt(warmup 4), twice (optim_tiny.npz)."""
+    g0 = load_golden("chimera_tiny.npz")
+    g = load_golden("optim_tiny.npz")
+    model, task, args = build_from_golden(g0, "chimera", torch.float32)
+    crit = import_module("chimera-st_amd.criterions").TripletSTMTContrastiveCriterion(task, False, 0.1, [1.0, 1.0, 1.0], 0.1)
+    Trainer = import_module("chimera-st_amd.trainer").Trainer
+    targs = Namespace(bf16=False, lr=[1e-3], adam_betas="(0.9, 0.98)", adam_eps=1e-8, weight_decay=0.01, clip_norm=0.05,
+                      warmup_updates=4, warmup_init_lr=1e-7, seed=1)
+    tr = Trainer(targs, task, model, crit, device="cuda")
+    assert tr.optimizer.get_lr() == pytest.approx(float(g["lr/0"]), rel=1e-9)
+    sample = golden_sample(g0)
+    for step in range(2):
+        out = tr.train_step([sample])
+        assert out["loss"] == pytest.approx(float(g["loss/%d" % step]), rel=1e-4)
+        assert out["gnorm"] == pytest.approx(float(g["gnorm/%d" % step]), rel=1e-3)
+        assert out["lr"] == pytest.approx(float(g["lr/%d" % (step + 1)]), rel=1e-9)
+    for name, p in tr.get_model().named_parameters():
+        assert_close(p, g["param_after/" + name], 1e-4, "param " + name)
+
+
+def test_bf16_trainer_runs_and_decreases_loss():
+    g0 = load_golden("chimera_tiny.npz")
+    model, task, args = build_from_golden(g0, "chimera", torch.float32)
+    crit = import_module("chimera-st_amd.criterions").TripletSTMTContrastiveCriterion(task, False, 0.1, [1.0, 1.0, 1.0], 0.1)
+    Trainer = import_module("chimera-st_amd.trainer").Trainer
+    targs = Namespace(bf16=True, lr=[2e-3], adam_betas="(0.9, 0.98)", adam_eps=1e-8, weight_decay=0.0, clip_norm=1.0,
+                      warmup_updates=1, warmup_init_lr=2e-3, seed=1)
+    tr = Trainer(targs, task, model, crit, device="cuda")
+    sample = golden_sample(g0)
+    losses = [tr.train_step([sample])["loss"] for _ in range(12)]
+    assert all(np.isfinite(losses)) and losses[-1] < 0.8 * losses[0]
