@@ -67,22 +67,31 @@ __global__ void act_fwd_kernel(const T* x, T* y, int64_t n8, int act) {
   }
 }
 
-// thread = one 8-column vector, rows chunked over blockIdx.y; fp32 atomics of the chunk partials
+// block = 256 threads = 4 row-lanes x 64 column vectors (8 columns each): rows chunked over blockIdx.y, the 4 row-lanes
+// interleave rows so each wave reads a full 1-KiB row segment; LDS combine, then one fp32 atomic per column per block.
 template <typename T>
-__global__ void colsum_kernel(const T* x, int64_t ldx, float* out, int64_t rows, int64_t cols, int64_t rows_per) {
-  const int64_t cv = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (cv * 8 >= cols) return;
+__global__ __launch_bounds__(256) void colsum_kernel(const T* x, int64_t ldx, float* out, int64_t rows, int64_t cols, int64_t rows_per) {
+  __shared__ float red[4][64 * 8];
+  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t cv = (int64_t)blockIdx.x * 64 + cl;
+  const bool ok = cv * 8 < cols;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per;
   const int64_t r1 = r0 + rows_per < rows ? r0 + rows_per : rows;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int64_t r = r0; r < r1; ++r) {
-    float v[8];
-    load8(x + r * ldx + cv * 8, v);
+  if (ok)
+    for (int64_t r = r0 + g; r < r1; r += 4) {
+      float v[8];
+      load8(x + r * ldx + cv * 8, v);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] += v[e];
+      for (int e = 0; e < 8; ++e) acc[e] += v[e];
+    }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[g][cl * 8 + e] = acc[e];
+  __syncthreads();
+  if (g == 0 && ok) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(out + cv * 8 + e, red[0][cl * 8 + e] + red[1][cl * 8 + e] + red[2][cl * 8 + e] + red[3][cl * 8 + e]);
   }
-#pragma unroll
-  for (int e = 0; e < 8; ++e) atomicAdd(out + cv * 8 + e, acc[e]);
 }
 
 template <typename T>
@@ -181,12 +190,14 @@ extern "C" int cst_colsum(const void* x, int64_t ldx, float* out, int64_t rows, 
   hipStream_t s = (hipStream_t)stream;
   CstProfScope prof(CST_K_ELEMENTWISE, s, 0.0, (double)rows * cols * cst_dtype_size(dtype));
   if (hipMemsetAsync(out, 0, sizeof(float) * cols, s) != hipSuccess) { cst_set_error("cst_colsum: memset failed"); return CST_ERR_LAUNCH; }
-  int64_t chunks = cst_ceil_div(rows, 128);
-  if (chunks > 1024) chunks = 1024;
+  const int64_t cblocks = cst_ceil_div(cols / 8, 64);
+  int64_t chunks = cst_ceil_div(2048, cblocks);  // ~2048 workgroups in total
+  if (chunks > cst_ceil_div(rows, 32)) chunks = cst_ceil_div(rows, 32);
+  if (chunks < 1) chunks = 1;
   const int64_t rows_per = cst_ceil_div(rows, chunks);
-  dim3 grid((unsigned)cst_ceil_div(cols / 8, 64), (unsigned)cst_ceil_div(rows, rows_per));
-  if (dtype == CST_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(64), 0, s, (const bf16_t*)x, ldx, out, rows, cols, rows_per);
-  else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(64), 0, s, (const float*)x, ldx, out, rows, cols, rows_per);
+  dim3 grid((unsigned)cblocks, (unsigned)cst_ceil_div(rows, rows_per));
+  if (dtype == CST_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ldx, out, rows, cols, rows_per);
+  else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ldx, out, rows, cols, rows_per);
   return cst_check_launch("cst_colsum");
 }
 

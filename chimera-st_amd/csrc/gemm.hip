@@ -15,6 +15,7 @@
 // Workgroup -> tile map is XCD-aware (bijective remap so each XCD's L2 sees a contiguous
 // band of tiles sharing A rows).
 #include "cst_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -37,6 +38,7 @@ struct GemmParams {
   int splits;
   float* ws;  // split-K partials [batch][split][M][N]
   int c_f32;
+  int vec_epi;  // all epilogue operands 16-byte aligned -> staged, vectorised epilogue
   int tiles_m, tiles_n;
 };
 
@@ -57,7 +59,46 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int64_t cofs
   else DT<T>::st((T*)p.C + cofs + row * p.ldc + col, v);
 }
 
-template <typename T, bool A_KMAJOR, bool B_KMAJOR>
+// 8 consecutive columns of one row: the same epilogue as epilogue_store, with 16-byte global accesses.
+template <typename T>
+__device__ __forceinline__ void epilogue_store8(const GemmParams& p, int64_t cofs, int64_t bofs, int64_t row, int64_t col, float (&v)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+  if (p.bias_mode == CST_BIAS_COL) {
+    float b[8];
+    load8((const T*)p.bias + bofs + col, b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += b[e];
+  } else if (p.bias_mode == CST_BIAS_ROW) {
+    const float b = DT<T>::ld((const T*)p.bias + bofs + row);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += b;
+  }
+  if (p.aux_out) store8((T*)p.aux_out + cofs + row * p.ld_aux_out + col, v);
+  if (p.act == CST_ACT_RELU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
+  } else if (p.act == CST_ACT_GELU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+  }
+  if (p.dact) {
+    float z[8];
+    load8((const T*)p.aux_in + cofs + row * p.ld_aux_in + col, z);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= dact_f(z[e], p.dact);
+  }
+  if (p.resid) {
+    float r[8];
+    load8((const T*)p.resid + cofs + row * p.ld_resid + col, r);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += r[e];
+  }
+  if (p.c_f32) store8((float*)p.C + cofs + row * p.ldc + col, v);
+  else store8((T*)p.C + cofs + row * p.ldc + col, v);
+}
+
+template <typename T, bool A_KMAJOR, bool B_KMAJOR, bool SEG>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
   constexpr int VEC = DT<T>::VEC;
   constexpr int BK = 8 * VEC;
@@ -93,74 +134,84 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
   const int64_t cofs = b0 * p.sc0 + b1 * p.sc1;
   const int64_t bofs = b0 * p.sbias0 + b1 * p.sbias1;
 
-  const int64_t ktiles = (p.K + BK - 1) / BK;
-  const int64_t per = (ktiles + p.splits - 1) / p.splits;
-  const int64_t kt0 = split * per;
-  const int64_t kt1 = (kt0 + per < ktiles) ? kt0 + per : ktiles;
+  const int ktiles = (int)((p.K + BK - 1) / BK);
+  const int kfull = (int)(p.K / BK);  // tiles [0, kfull) need no K bound check
+  const int per = (ktiles + p.splits - 1) / p.splits;
+  const int kt0 = split * per;
+  const int kt1 = (kt0 + per < ktiles) ? kt0 + per : ktiles;
 
-  // ---- per-thread staging descriptors: 4 vectors of A and 4 of B per K tile ----
+  // ---- per-thread staging state: 4 x 16-byte vectors of A and of B per K tile.  Rows / mn positions beyond the
+  //      matrix are CLAMPED to a valid address (their products only reach accumulator rows/cols that are never stored),
+  //      so the steady-state loop is branch-free pointer bumps; only the K tail tile is predicated. ----
   u32x4 ra[4], rb[4];
-  // k-major: v = tid + 256 i -> row = v>>3, kvec = v&7; mn-major: krow = v / MVECS, mvec = v % MVECS
-  int64_t a_rowoff[4], b_rowoff[4];  // fixed part of the global offset
-  bool a_ok[4], b_ok[4];             // fixed validity (row / mn bound)
-  int a_q[4], a_r[4], b_q[4], b_r[4];  // running segmented-k state (k-major only)
+  const T* pa[4];
+  const T* pb[4];
+  int ka[4], kb[4];          // k index this vector covers in tile kt0 (k-major: of its first element; mn-major: its k row)
+  int aq[4], ar[4], bq[4], br[4];  // SEG only: running (segment, offset) of the k index
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int v = tid + NTHREADS * i;
     if (A_KMAJOR) {
-      const int64_t row = m0 + (v >> 3);
-      a_ok[i] = row < p.M;
-      a_rowoff[i] = row * p.lda;
-      const int64_t c = kt0 * BK + (v & 7) * VEC;
-      a_q[i] = p.a_seg ? (int)(c / p.a_seg) : 0;
-      a_r[i] = p.a_seg ? (int)(c % p.a_seg) : (int)c;
+      int64_t row = m0 + (v >> 3);
+      row = row < p.M ? row : p.M - 1;
+      ka[i] = kt0 * BK + (v & 7) * VEC;
+      if (SEG && p.a_seg) { aq[i] = ka[i] / (int)p.a_seg; ar[i] = ka[i] % (int)p.a_seg; pa[i] = A + row * p.lda; }
+      else { aq[i] = 0; ar[i] = 0; pa[i] = A + row * p.lda + ka[i]; }
     } else {
-      const int64_t m = m0 + (int64_t)(v % MVECS) * VEC;
-      a_ok[i] = m < p.M;  // M % VEC == 0 is required for mn-major operands
-      a_rowoff[i] = segaddr(m, p.a_seg, p.a_seg_stride);
-      a_q[i] = v / MVECS; a_r[i] = 0;
+      int64_t m = m0 + (int64_t)(v % MVECS) * VEC;
+      m = m < p.M ? m : p.M - VEC;
+      ka[i] = kt0 * BK + v / MVECS;
+      aq[i] = 0; ar[i] = 0;
+      pa[i] = A + (int64_t)ka[i] * p.lda + segaddr(m, p.a_seg, p.a_seg_stride);
     }
     if (B_KMAJOR) {
-      const int64_t row = n0 + (v >> 3);
-      b_ok[i] = row < p.N;
-      b_rowoff[i] = row * p.ldb;
-      const int64_t c = kt0 * BK + (v & 7) * VEC;
-      b_q[i] = p.b_seg ? (int)(c / p.b_seg) : 0;
-      b_r[i] = p.b_seg ? (int)(c % p.b_seg) : (int)c;
+      int64_t row = n0 + (v >> 3);
+      row = row < p.N ? row : p.N - 1;
+      kb[i] = kt0 * BK + (v & 7) * VEC;
+      if (SEG && p.b_seg) { bq[i] = kb[i] / (int)p.b_seg; br[i] = kb[i] % (int)p.b_seg; pb[i] = B + row * p.ldb; }
+      else { bq[i] = 0; br[i] = 0; pb[i] = B + row * p.ldb + kb[i]; }
     } else {
-      const int64_t n = n0 + (int64_t)(v % MVECS) * VEC;
-      b_ok[i] = n < p.N;
-      b_rowoff[i] = segaddr(n, p.b_seg, p.b_seg_stride);
-      b_q[i] = v / MVECS; b_r[i] = 0;
+      int64_t n = n0 + (int64_t)(v % MVECS) * VEC;
+      n = n < p.N ? n : p.N - VEC;
+      kb[i] = kt0 * BK + v / MVECS;
+      bq[i] = 0; br[i] = 0;
+      pb[i] = B + (int64_t)kb[i] * p.ldb + segaddr(n, p.b_seg, p.b_seg_stride);
     }
   }
+  const int64_t step_a = A_KMAJOR ? (int64_t)BK : (int64_t)BK * p.lda;
+  const int64_t step_b = B_KMAJOR ? (int64_t)BK : (int64_t)BK * p.ldb;
 
-  auto load_tile = [&](int64_t kt) {
+  // TAIL = true: the tile may cross K -> vectors at k >= K are replaced by zeros (K % VEC == 0 for k-major operands)
+  auto load_tile = [&](auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      u32x4 va = {0, 0, 0, 0}, vb = {0, 0, 0, 0};
-      if (A_KMAJOR) {
-        const int64_t k = (p.a_seg ? (int64_t)a_q[i] * p.a_seg + a_r[i] : (int64_t)a_r[i]);
-        if (a_ok[i] && k < p.K)
-          va = *reinterpret_cast<const u32x4*>(A + a_rowoff[i] + (p.a_seg ? (int64_t)a_q[i] * p.a_seg_stride + a_r[i] : k));
-        a_r[i] += BK;
-        if (p.a_seg) while (a_r[i] >= p.a_seg) { a_r[i] -= (int)p.a_seg; ++a_q[i]; }
+      const T* qa = pa[i];
+      const T* qb = pb[i];
+      if (SEG && A_KMAJOR && p.a_seg) qa = pa[i] + (int64_t)aq[i] * p.a_seg_stride + ar[i];
+      if (SEG && B_KMAJOR && p.b_seg) qb = pb[i] + (int64_t)bq[i] * p.b_seg_stride + br[i];
+      if (TAIL) {
+        const bool oka = ka[i] < p.K, okb = kb[i] < p.K;
+        u32x4 va = *reinterpret_cast<const u32x4*>(oka ? qa : A);
+        u32x4 vb = *reinterpret_cast<const u32x4*>(okb ? qb : B);
+        const u32x4 zero = {0, 0, 0, 0};
+        ra[i] = oka ? va : zero;
+        rb[i] = okb ? vb : zero;
       } else {
-        const int64_t k = kt * BK + a_q[i];
-        if (a_ok[i] && k < p.K) va = *reinterpret_cast<const u32x4*>(A + k * p.lda + a_rowoff[i]);
+        ra[i] = *reinterpret_cast<const u32x4*>(qa);
+        rb[i] = *reinterpret_cast<const u32x4*>(qb);
       }
-      if (B_KMAJOR) {
-        const int64_t k = (p.b_seg ? (int64_t)b_q[i] * p.b_seg + b_r[i] : (int64_t)b_r[i]);
-        if (b_ok[i] && k < p.K)
-          vb = *reinterpret_cast<const u32x4*>(B + b_rowoff[i] + (p.b_seg ? (int64_t)b_q[i] * p.b_seg_stride + b_r[i] : k));
-        b_r[i] += BK;
-        if (p.b_seg) while (b_r[i] >= p.b_seg) { b_r[i] -= (int)p.b_seg; ++b_q[i]; }
-      } else {
-        const int64_t k = kt * BK + b_q[i];
-        if (b_ok[i] && k < p.K) vb = *reinterpret_cast<const u32x4*>(B + k * p.ldb + b_rowoff[i]);
-      }
-      ra[i] = va; rb[i] = vb;
+      ka[i] += BK;
+      kb[i] += BK;
+      if (SEG && A_KMAJOR && p.a_seg) { ar[i] += BK; while (ar[i] >= (int)p.a_seg) { ar[i] -= (int)p.a_seg; ++aq[i]; } }
+      else pa[i] += step_a;
+      if (SEG && B_KMAJOR && p.b_seg) { br[i] += BK; while (br[i] >= (int)p.b_seg) { br[i] -= (int)p.b_seg; ++bq[i]; } }
+      else pb[i] += step_b;
     }
+  };
+  auto load_any = [&](int kt) {
+    if (kt < kfull) load_tile(std::false_type{});
+    else load_tile(std::true_type{});
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
@@ -182,15 +233,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   if (kt0 < kt1) {
-    load_tile(kt0);
+    load_any(kt0);
     store_tile(0);
   }
   __syncthreads();
   int cur = 0;
   const int lrow = lane & 31, lk = 8 * (lane >> 5);
-  for (int64_t kt = kt0; kt < kt1; ++kt) {
+  for (int kt = kt0; kt < kt1; ++kt) {
     const bool more = kt + 1 < kt1;
-    if (more) load_tile(kt + 1);
+    if (more) load_any(kt + 1);
     const T* sa = lds_a[cur];
     const T* sb = lds_b[cur];
 #pragma unroll
@@ -213,33 +264,43 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
     cur ^= 1;
   }
 
-  // ---- epilogue ----
-  if (p.splits > 1) {
-    float* ws = p.ws + ((int64_t)z) * p.M * p.N;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int64_t col = n0 + wn * 64 + j * 32 + lrow;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t row = m0 + wm * 64 + i * 32 + acc_row(r, lane);
-          if (row < p.M && col < p.N) ws[row * p.N + col] = acc[i][j][r];
-        }
-      }
-    return;
-  }
+  // ---- epilogue: accumulators -> LDS (fp32, [128][132]) -> row-contiguous 8-column vectors -> 16-byte global stores ----
+  constexpr int LDC = BN + 4;
+  float* stage = reinterpret_cast<float*>(smem_raw);
+  __syncthreads();  // every wave is done reading the operand tiles
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int64_t col = n0 + wn * 64 + j * 32 + lrow;
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + wm * 64 + i * 32 + acc_row(r, lane);
-        if (row < p.M && col < p.N) epilogue_store<T>(p, cofs, bofs, row, col, acc[i][j][r]);
-      }
+      for (int r = 0; r < 16; ++r)
+        stage[(wm * 64 + i * 32 + acc_row(r, lane)) * LDC + wn * 64 + j * 32 + lrow] = acc[i][j][r];
+  __syncthreads();
+  float* wsp = p.splits > 1 ? p.ws + ((int64_t)z) * p.M * p.N : nullptr;
+  const bool ws_vec = (p.N % 4) == 0;
+#pragma unroll 2
+  for (int it = 0; it < 8; ++it) {
+    const int v = tid + NTHREADS * it;
+    const int rl = v >> 4, cl = (v & 15) * 8;
+    const int64_t row = m0 + rl, col = n0 + cl;
+    if (row >= p.M || col >= p.N) continue;
+    float x[8];
+    {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(stage + rl * LDC + cl);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(stage + rl * LDC + cl + 4);
+      x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
     }
+    const bool full = col + 8 <= p.N;
+    if (wsp) {  // split-K partial slab (raw fp32 sums; epilogue applied by the reduce kernel)
+      if (full && ws_vec) store8(wsp + row * p.N + col, x);
+      else
+        for (int e = 0; e < 8 && col + e < p.N; ++e) wsp[row * p.N + col + e] = x[e];
+    } else if (full && p.vec_epi) {
+      epilogue_store8<T>(p, cofs, bofs, row, col, x);
+    } else {
+      for (int e = 0; e < 8 && col + e < p.N; ++e) epilogue_store<T>(p, cofs, bofs, row, col + e, x[e]);
+    }
+  }
 }
 
 template <typename T>
@@ -257,20 +318,22 @@ __global__ void splitk_reduce_kernel(GemmParams p) {
   }
 }
 
-template <typename T, bool AK, bool BK_>
+template <typename T, bool AK, bool BK_, bool SEG>
 int launch(const GemmParams& p, int64_t nbatch, hipStream_t s) {
   constexpr int VEC = DT<T>::VEC;
   constexpr int BKc = 8 * VEC, LDK = BKc + VEC, LDM = 128 + VEC;
   constexpr int A_ELEMS = AK ? BM * LDK : BKc * LDM;
   constexpr int B_ELEMS = BK_ ? BN * LDK : BKc * LDM;
-  const size_t lds = 2 * (size_t)(A_ELEMS + B_ELEMS) * sizeof(T);
+  size_t lds = 2 * (size_t)(A_ELEMS + B_ELEMS) * sizeof(T);
+  const size_t stage_bytes = (size_t)BM * (BN + 4) * sizeof(float);
+  if (lds < stage_bytes) lds = stage_bytes;
   static bool attr_set = false;  // LDS > 64 KiB needs the opt-in attribute (160 KiB/CU on gfx950)
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, AK, BK_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, AK, BK_, SEG>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     attr_set = true;
   }
   dim3 grid(p.tiles_m * p.tiles_n, 1, (unsigned)(nbatch * p.splits));
-  hipLaunchKernelGGL((gemm_kernel<T, AK, BK_>), grid, dim3(NTHREADS), lds, s, p);
+  hipLaunchKernelGGL((gemm_kernel<T, AK, BK_, SEG>), grid, dim3(NTHREADS), lds, s, p);
   return cst_check_launch("cst_gemm");
 }
 
@@ -328,6 +391,15 @@ extern "C" int cst_gemm(const cst_gemm_desc* d, cst_stream stream) {
   p.sa0 = d->sa0; p.sa1 = d->sa1; p.sb0 = d->sb0; p.sb1 = d->sb1; p.sc0 = d->sc0; p.sc1 = d->sc1;
   p.c_f32 = (d->c_dtype == CST_F32 && d->dtype != CST_F32) ? 1 : 0;
   if (d->dtype == CST_F32) p.c_f32 = 0;  // T == float already stores fp32
+  {
+    auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q % 16) == 0; };
+    bool ok = d->ldc % 8 == 0 && d->sc0 % 8 == 0 && d->sc1 % 8 == 0 && al16(d->C) && al16(d->bias) && al16(d->aux_out) && al16(d->aux_in) && al16(d->resid);
+    if (d->bias && d->bias_mode == CST_BIAS_COL) ok = ok && d->sbias0 % 8 == 0 && d->sbias1 % 8 == 0;
+    if (d->aux_out) ok = ok && d->ld_aux_out % 8 == 0;
+    if (d->aux_in) ok = ok && d->ld_aux_in % 8 == 0;
+    if (d->resid) ok = ok && d->ld_resid % 8 == 0;
+    p.vec_epi = ok ? 1 : 0;
+  }
   p.tiles_m = (int)cst_ceil_div(d->M, BM);
   p.tiles_n = (int)cst_ceil_div(d->N, BN);
   p.splits = choose_splits(d);
@@ -350,9 +422,14 @@ extern "C" int cst_gemm(const cst_gemm_desc* d, cst_stream stream) {
   CstProfScope prof(CST_K_GEMM, s, flops, bytes);
   int rc;
   const bool ak = d->a_kmajor != 0, bk = d->b_kmajor != 0;
-#define CST_GEMM_DISPATCH(T)                                         \
-  (ak ? (bk ? launch<T, true, true>(p, nbatch, s) : launch<T, true, false>(p, nbatch, s)) \
-      : (bk ? launch<T, false, true>(p, nbatch, s) : launch<T, false, false>(p, nbatch, s)))
+  // SEG instantiation only where a k-major operand is segmented (the grouped pos-conv); mn-major segments are folded
+  // into the per-thread base pointer and cost nothing per tile.
+  const bool seg = (ak && d->a_seg) || (bk && d->b_seg);
+#define CST_GEMM_DISPATCH(T)                                                                                   \
+  (seg ? (ak ? (bk ? launch<T, true, true, true>(p, nbatch, s) : launch<T, true, false, true>(p, nbatch, s))   \
+             : launch<T, false, true, true>(p, nbatch, s))                                                     \
+       : (ak ? (bk ? launch<T, true, true, false>(p, nbatch, s) : launch<T, true, false, false>(p, nbatch, s)) \
+             : (bk ? launch<T, false, true, false>(p, nbatch, s) : launch<T, false, false, false>(p, nbatch, s))))
   if (d->dtype == CST_BF16) rc = CST_GEMM_DISPATCH(bf16_t);
   else rc = CST_GEMM_DISPATCH(float);
 #undef CST_GEMM_DISPATCH

@@ -140,16 +140,26 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(const T* dy, cons
   }
 }
 
-__global__ void ln_bwd_reduce_kernel(const float* part, float* dgamma, float* dbeta, int nblocks, int cols) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+// partial [nblocks][2][cols] -> dgamma/dbeta: block = 64 columns x 16 row-groups, coalesced 256-B row reads
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* part, float* dgamma, float* dbeta, int nblocks, int cols) {
+  __shared__ float ra[16][64], rb[16][64];
+  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float a = 0.0f, b = 0.0f;
-  for (int i = 0; i < nblocks; ++i) {
-    a += part[(int64_t)i * 2 * cols + c];
-    b += part[(int64_t)i * 2 * cols + cols + c];
+  if (c < cols)
+    for (int i = g; i < nblocks; i += 16) {
+      a += part[(int64_t)i * 2 * cols + c];
+      b += part[(int64_t)i * 2 * cols + cols + c];
+    }
+  ra[g][cl] = a;
+  rb[g][cl] = b;
+  __syncthreads();
+  if (g == 0 && c < cols) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { a += ra[k][cl]; b += rb[k][cl]; }
+    dgamma[c] = a;
+    dbeta[c] = b;
   }
-  dgamma[c] = a;
-  dbeta[c] = b;
 }
 
 int ln_blocks(int64_t rows) {
@@ -196,6 +206,6 @@ extern "C" int cst_layernorm_bwd(const void* dy, const void* sx, const void* gam
   else CST_REQUIRE(false, "cst_layernorm_bwd: bad dtype %d", dtype);
   int rc = cst_check_launch("cst_layernorm_bwd");
   if (rc != CST_OK) return rc;
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)cst_ceil_div(cols, 256)), dim3(256), 0, s, (const float*)workspace, dgamma, dbeta, nb, (int)cols);
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)cst_ceil_div(cols, 64)), dim3(1024), 0, s, (const float*)workspace, dgamma, dbeta, nb, (int)cols);
   return cst_check_launch("cst_layernorm_bwd reduce");
 }
