@@ -109,8 +109,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
   constexpr int MVECS = 128 / VEC;  // vectors per mn-major row
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
-  T* lds_a[2] = {smem, smem + A_ELEMS + B_ELEMS};
-  T* lds_b[2] = {smem + A_ELEMS, smem + 2 * A_ELEMS + B_ELEMS};
+  // NOTE: stage addresses are formed as smem + cur * STAGE (never by selecting between two pointers): a pointer select
+  // loses the LDS address space and hipcc then emits flat_load/flat_store, whose vmcnt waits also drain the global prefetch.
+  constexpr int STAGE = A_ELEMS + B_ELEMS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -122,7 +123,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
     const int q = ntiles / 8, r = ntiles % 8, xcd = id % 8, loc = id / 8;
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
-  const int tm = id / p.tiles_n, tn = id % p.tiles_n;
+  // grouped order inside each XCD's contiguous id range: GROUP_M row-tiles x all column-tiles, walked column-major, so the
+  // ~64 tiles an XCD runs concurrently form a compact 8 x 8 patch (8 A panels + 8 B panels ~ 3 MB at K=768: fits the 4 MB L2)
+  constexpr int GROUP_M = 8;
+  int tm, tn;
+  {
+    const int per_group = GROUP_M * p.tiles_n;
+    const int grp = id / per_group, rem = id % per_group;
+    const int gm0 = grp * GROUP_M;
+    const int gsz = (p.tiles_m - gm0 < GROUP_M) ? (p.tiles_m - gm0) : GROUP_M;
+    tm = gm0 + rem % gsz;
+    tn = rem / gsz;
+  }
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
 
   const int z = blockIdx.z;
@@ -217,8 +229,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int v = tid + NTHREADS * i;
-      T* da = A_KMAJOR ? lds_a[buf] + (v >> 3) * LDK + (v & 7) * VEC : lds_a[buf] + (v / MVECS) * LDM + (v % MVECS) * VEC;
-      T* db = B_KMAJOR ? lds_b[buf] + (v >> 3) * LDK + (v & 7) * VEC : lds_b[buf] + (v / MVECS) * LDM + (v % MVECS) * VEC;
+      T* da = smem + buf * STAGE + (A_KMAJOR ? (v >> 3) * LDK + (v & 7) * VEC : (v / MVECS) * LDM + (v % MVECS) * VEC);
+      T* db = smem + buf * STAGE + A_ELEMS + (B_KMAJOR ? (v >> 3) * LDK + (v & 7) * VEC : (v / MVECS) * LDM + (v % MVECS) * VEC);
       *reinterpret_cast<u32x4*>(da) = ra[i];
       *reinterpret_cast<u32x4*>(db) = rb[i];
     }
@@ -242,8 +254,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
   for (int kt = kt0; kt < kt1; ++kt) {
     const bool more = kt + 1 < kt1;
     if (more) load_any(kt + 1);
-    const T* sa = lds_a[cur];
-    const T* sb = lds_b[cur];
+    const T* sa = smem + cur * STAGE;
+    const T* sb = sa + A_ELEMS;
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 16) {
       Frag<T> fa[2], fb[2];
