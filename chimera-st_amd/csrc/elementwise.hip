@@ -67,30 +67,46 @@ __global__ void act_fwd_kernel(const T* x, T* y, int64_t n8, int act) {
   }
 }
 
-// block = 256 threads = 4 row-lanes x 64 column vectors (8 columns each): rows chunked over blockIdx.y, the 4 row-lanes
-// interleave rows so each wave reads a full 1-KiB row segment; LDS combine, then one fp32 atomic per column per block.
+// block = 256 threads = 16 row-lanes x 16 column vectors (128 columns): each half-wave reads a 256-B row segment, 4 row
+// loads in flight per thread; LDS combine over the 16 row-lanes; one fp32 atomic per column per block (<= ~200 blocks per
+// column, so the atomics are not the bottleneck).
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* x, int64_t ldx, float* out, int64_t rows, int64_t cols, int64_t rows_per) {
-  __shared__ float red[4][64 * 8];
-  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int64_t cv = (int64_t)blockIdx.x * 64 + cl;
+  __shared__ float red[16][16 * 8 + 1];
+  const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int64_t cv = (int64_t)blockIdx.x * 16 + cl;
   const bool ok = cv * 8 < cols;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per;
   const int64_t r1 = r0 + rows_per < rows ? r0 + rows_per : rows;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (ok)
-    for (int64_t r = r0 + g; r < r1; r += 4) {
+  if (ok) {
+    int64_t r = r0 + g;
+    for (; r + 48 < r1; r += 64) {
+      float v0[8], v1[8], v2[8], v3[8];
+      load8(x + r * ldx + cv * 8, v0);
+      load8(x + (r + 16) * ldx + cv * 8, v1);
+      load8(x + (r + 32) * ldx + cv * 8, v2);
+      load8(x + (r + 48) * ldx + cv * 8, v3);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += (v0[e] + v1[e]) + (v2[e] + v3[e]);
+    }
+    for (; r < r1; r += 16) {
       float v[8];
       load8(x + r * ldx + cv * 8, v);
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] += v[e];
     }
+  }
 #pragma unroll
   for (int e = 0; e < 8; ++e) red[g][cl * 8 + e] = acc[e];
   __syncthreads();
-  if (g == 0 && ok) {
+  if (threadIdx.x < 128) {
+    const int c = threadIdx.x;
+    float a = 0.0f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(out + cv * 8 + e, red[0][cl * 8 + e] + red[1][cl * 8 + e] + red[2][cl * 8 + e] + red[3][cl * 8 + e]);
+    for (int k = 0; k < 16; ++k) a += red[k][c];
+    const int64_t col = (int64_t)blockIdx.x * 128 + c;
+    if (col < cols) atomicAdd(out + col, a);
   }
 }
 
@@ -190,9 +206,9 @@ extern "C" int cst_colsum(const void* x, int64_t ldx, float* out, int64_t rows, 
   hipStream_t s = (hipStream_t)stream;
   CstProfScope prof(CST_K_ELEMENTWISE, s, 0.0, (double)rows * cols * cst_dtype_size(dtype));
   if (hipMemsetAsync(out, 0, sizeof(float) * cols, s) != hipSuccess) { cst_set_error("cst_colsum: memset failed"); return CST_ERR_LAUNCH; }
-  const int64_t cblocks = cst_ceil_div(cols / 8, 64);
-  int64_t chunks = cst_ceil_div(2048, cblocks);  // ~2048 workgroups in total
-  if (chunks > cst_ceil_div(rows, 32)) chunks = cst_ceil_div(rows, 32);
+  const int64_t cblocks = cst_ceil_div(cols / 8, 16);
+  int64_t chunks = cst_ceil_div(1536, cblocks);  // ~1536 workgroups in total
+  if (chunks > cst_ceil_div(rows, 64)) chunks = cst_ceil_div(rows, 64);
   if (chunks < 1) chunks = 1;
   const int64_t rows_per = cst_ceil_div(rows, chunks);
   dim3 grid((unsigned)cblocks, (unsigned)cst_ceil_div(rows, rows_per));

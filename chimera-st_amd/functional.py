@@ -250,6 +250,10 @@ def conv1d_cl(x, weight, bias, stride, pad=0, act=None, prev_z=None, grad_is_dz=
 # grouped positional conv of wav2vec2 (k taps, `groups` groups, pad k//2, SamePad, GELU, + residual)
 # ------------------------------------------------------------------------------------------------
 class _PosConvFn(torch.autograd.Function):
+    """Grouped conv as a batched implicit GEMM.  The input is re-staged GROUP-MAJOR ([B, G, T+k, C/G], one 74 MB copy at
+    B=32) so that for one (utterance, group) the im2col row of frame t is the contiguous window starting at frame t:
+    a plain k-major operand with lda = C/G < K (overlapping rows) — no segmented addressing in the inner loop."""
+
     @staticmethod
     def forward(ctx, x, weight, bias, groups):
         """x [B,T,C]; weight [C, C/g, k] -> x + GELU(conv(x) + bias)   (one fused GEMM launch)."""
@@ -257,24 +261,23 @@ class _PosConvFn(torch.autograd.Function):
         k = weight.shape[2]
         cg = C // groups
         padl = k // 2
-        # even k: torch pads k//2 both sides and SamePad drops the last output; odd k: symmetric, nothing dropped
-        xp = torch.zeros(B, T + k - 1 + (1 if k % 2 == 0 else 0), C, dtype=x.dtype, device=x.device)
-        xp[:, padl:padl + T] = x
-        Tp = xp.shape[1]
+        Tp = T + k - 1 + (1 if k % 2 == 0 else 0)  # even k: torch pads k//2 both sides, SamePad drops the last output
+        xg = torch.zeros(B, groups, Tp, cg, dtype=x.dtype, device=x.device)
+        xg[:, :, padl:padl + T] = x.view(B, T, groups, cg).permute(0, 2, 1, 3)
         wg = weight.view(groups, cg, cg, k).permute(0, 1, 3, 2).contiguous()  # [g][co][j][ci]
         y = torch.empty(B, T, C, dtype=x.dtype, device=x.device)
         z = torch.empty_like(y)
         xc = x if x.is_contiguous() else x.contiguous()
-        K.gemm(xp, wg, y, T, cg, k * cg, a_kmajor=1, b_kmajor=1, lda=C, ldb=k * cg, ldc=C, a_seg=cg, a_seg_stride=C, batch0=B,
-               batch1=groups, sa=(Tp * C, cg), sb=(0, cg * k * cg), sc=(T * C, cg), bias=bias, sbias=(0, cg), act=L.ACT_GELU,
+        K.gemm(xg, wg, y, T, cg, k * cg, a_kmajor=1, b_kmajor=1, lda=cg, ldb=k * cg, ldc=C, batch0=B, batch1=groups,
+               sa=(groups * Tp * cg, Tp * cg), sb=(0, cg * k * cg), sc=(T * C, cg), bias=bias, sbias=(0, cg), act=L.ACT_GELU,
                aux_out=z, ld_aux_out=C, resid=xc, ld_resid=C, split_k=1)
-        ctx.save_for_backward(xp, weight, z)
+        ctx.save_for_backward(xg, weight, z)
         ctx.cfg = (B, T, C, k, groups, cg, padl, Tp)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        xp, weight, z = ctx.saved_tensors
+        xg, weight, z = ctx.saved_tensors
         B, T, C, k, groups, cg, padl, Tp = ctx.cfg
         dy = dy.contiguous()
         dz = K.act_bwd(dy, z, L.ACT_GELU)
@@ -282,18 +285,18 @@ class _PosConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # dx[m] = dy[m] + sum_j dz[m + padl - j] w_j  = dy[m] + sum_j' dzp[m + j'] wflip[j'],  dzp[(k-1-padl) + t] = dz[t]
             lp = k - 1 - padl
-            dzp = torch.zeros(B, T + k - 1, C, dtype=dy.dtype, device=dy.device)
-            dzp[:, lp:lp + T] = dz
+            Tz = T + k - 1
+            dzg = torch.zeros(B, groups, Tz, cg, dtype=dy.dtype, device=dy.device)
+            dzg[:, :, lp:lp + T] = dz.view(B, T, groups, cg).permute(0, 2, 1, 3)
             wflip = weight.view(groups, cg, cg, k).flip(3).permute(0, 2, 3, 1).contiguous()  # [g][ci][j'][co]
             dx = torch.empty(B, T, C, dtype=dy.dtype, device=dy.device)
-            K.gemm(dzp, wflip, dx, T, cg, k * cg, a_kmajor=1, b_kmajor=1, lda=C, ldb=k * cg, ldc=C, a_seg=cg, a_seg_stride=C,
-                   batch0=B, batch1=groups, sa=((T + k - 1) * C, cg), sb=(0, cg * k * cg), sc=(T * C, cg), resid=dy, ld_resid=C,
-                   split_k=1)
+            K.gemm(dzg, wflip, dx, T, cg, k * cg, a_kmajor=1, b_kmajor=1, lda=cg, ldb=k * cg, ldc=C, batch0=B, batch1=groups,
+                   sa=(groups * Tz * cg, Tz * cg), sb=(0, cg * k * cg), sc=(T * C, cg), resid=dy, ld_resid=C, split_k=1)
         if ctx.needs_input_grad[1]:
-            # dw[g][co][(j,ci)] = sum_t dz[t, g, co] xp[t + j, g, ci]
+            # dw[g][co][(j,ci)] = sum_t dz[t, g, co] xg[g, t + j, ci]   (B operand: overlapping mn-major rows, ldb = cg)
             part = torch.empty(B, groups, cg, k * cg, dtype=torch.float32, device=dy.device)
-            K.gemm(dz, xp, part, cg, k * cg, T, a_kmajor=0, b_kmajor=0, lda=C, ldb=C, ldc=k * cg, b_seg=cg, b_seg_stride=C, batch0=B,
-                   batch1=groups, sa=(T * C, cg), sb=(Tp * C, cg), sc=(groups * cg * k * cg, cg * k * cg), split_k=1)
+            K.gemm(dz, xg, part, cg, k * cg, T, a_kmajor=0, b_kmajor=0, lda=C, ldb=cg, ldc=k * cg, batch0=B, batch1=groups,
+                   sa=(T * C, cg), sb=(groups * Tp * cg, Tp * cg), sc=(groups * cg * k * cg, cg * k * cg), split_k=1)
             dw = part.sum(0).view(groups, cg, k, cg).permute(0, 1, 3, 2).reshape(C, cg, k).to(weight.dtype)
         if ctx.needs_input_grad[2]:
             db = K.colsum(dz.view(B * T, C)).to(weight.dtype)
