@@ -41,17 +41,32 @@ struct AttnParams {
 // the row (within a 32-row MFMA tile) that k-slot j of half-wave `hi` holds for the 16-row step t
 __device__ __forceinline__ int slot_row(int t, int j, int hi) { return 16 * t + (j & 3) + 8 * (j >> 2) + 4 * hi; }
 
-// cooperative copy of a [rows<=KT][D] tile (row stride `st` in global) into LDS [KT][D+VEC]; rows >= nrows zero-filled
+// Register-staged tile prefetch: a [KT][D] tile (row stride `st` in global) is fetched into NV 16-byte vectors per thread
+// (issued BEFORE the MFMA work of the current tile, T14 in the CDNA guide) and written to an LDS stage afterwards.
+// Rows beyond `nrows` are clamped to the last valid row: they only ever meet probabilities / gradients that are exactly
+// zero (masked), so no zero-fill pass is needed, but they must be finite.
 template <typename T, int D>
-__device__ __forceinline__ void load_tile(T* lds, const T* g, int64_t st, int nrows, int tid) {
-  constexpr int VEC = DT<T>::VEC, LD = D + VEC, VPR = D / VEC;
-  for (int v = tid; v < KT * VPR; v += NW * 64) {
-    const int r = v / VPR, c = (v % VPR) * VEC;
-    u32x4 x = {0, 0, 0, 0};
-    if (r < nrows) x = *reinterpret_cast<const u32x4*>(g + (int64_t)r * st + c);
-    *reinterpret_cast<u32x4*>(lds + r * LD + c) = x;
+struct TileRegs {
+  static constexpr int VEC = DT<T>::VEC, VPR = D / VEC, NV = (KT * VPR + NW * 64 - 1) / (NW * 64);
+  u32x4 r[NV];
+  __device__ __forceinline__ void fetch(const T* g, int64_t st, int nrows, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = tid + NW * 64 * i;
+      int row = v / VPR;
+      row = row < nrows ? row : nrows - 1;
+      if (v < KT * VPR) r[i] = *reinterpret_cast<const u32x4*>(g + (int64_t)row * st + (v % VPR) * VEC);
+    }
   }
-}
+  __device__ __forceinline__ void stage(T* lds, int tid) const {
+    constexpr int LD = D + VEC;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = tid + NW * 64 * i;
+      if (v < KT * VPR) *reinterpret_cast<u32x4*>(lds + (v / VPR) * LD + (v % VPR) * VEC) = r[i];
+    }
+  }
+};
 
 // registers: D/16 fragments of one row (row = lane&31) of a [T][D] matrix in global memory
 template <typename T, int D>
@@ -65,20 +80,6 @@ __device__ __forceinline__ void load_row_frags(Frag<T> (&f)[D / 16], const T* g,
       frag_from_f32(f[kk], z);
     }
   }
-}
-
-// A fragment "transposed": row = d (lane&31 + d0), the 8 k-slots are tile rows slot_row(t, j, hi)
-template <typename T, int LD>
-__device__ __forceinline__ void frag_gather_rows(Frag<float>& f, const float* lds, int d, int t, int hi, int rbase) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) f.v[j] = lds[(rbase + slot_row(t, j, hi)) * LD + d];
-}
-template <typename T, int LD>
-__device__ __forceinline__ void frag_gather_rows(Frag<bf16_t>& f, const bf16_t* lds, int d, int t, int hi, int rbase) {
-  u16x8 x;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const unsigned short*>(lds + (rbase + slot_row(t, j, hi)) * LD + d);
-  f.v = __builtin_bit_cast(bf16x8, x);
 }
 
 // store acc (rows = d = d0 + acc_row(r), col = this lane's token) as 4-element runs along d
@@ -96,10 +97,11 @@ __device__ __forceinline__ void store_dcol(T* g, const f32x16& acc, int d0, int 
 // ---------------------------------------------------------------------------------------------
 template <typename T, int D>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
-  constexpr int VEC = DT<T>::VEC, LD = D + VEC;
-  __shared__ __attribute__((aligned(16))) T sK[KT * LD];
-  __shared__ __attribute__((aligned(16))) T sV[KT * LD];
-  __shared__ uint8_t sM[KT];
+  constexpr int VEC = DT<T>::VEC, LD = D + VEC, TILE = KT * LD;
+  // dynamic LDS: 2 stages x {K tile, V tile} + 2 x KT mask bytes; stage addresses are always smem + stage * 2*TILE
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  unsigned long long* sMask = reinterpret_cast<unsigned long long*>(smem + 4 * TILE);  // per stage: bit k = key k masked
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
   const int64_t b = blockIdx.z, h = blockIdx.y;
   const int q_blk0 = blockIdx.x * (NW * QB);
@@ -107,7 +109,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
   const T* Qg = (const T*)p.Q + b * p.q_sb + h * p.q_sh;
   const T* Kg = (const T*)p.K + b * p.k_sb + h * p.k_sh;
   const T* Vg = (const T*)p.V + b * p.v_sb + h * p.v_sh;
-  const int64_t cshift = p.Tk - p.Tq;  // causal: key j visible to query i iff j <= i + cshift
+  const int cshift = (int)(p.Tk - p.Tq);  // causal: key j visible to query i iff j <= i + cshift
+  const float c2 = p.scale * 1.4426950408889634f;  // softmax in the exp2 domain: p = 2^(s*c2 - m)
 
   Frag<T> fq[D / 16];
   load_row_frags<T, D>(fq, Qg, p.q_st, q, (int)p.Tq, lane);
@@ -124,13 +127,32 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
     const int64_t last = (int64_t)q_blk0 + NW * QB - 1 + cshift + 1;
     if (last < kend) kend = last;
   }
-  for (int64_t j0 = 0; j0 < kend; j0 += KT) {
+  TileRegs<T, D> rk, rv;
+  uint8_t rmask = 0;
+  auto prefetch = [&](int64_t j0) {
     const int nk = (int)((p.Tk - j0 < KT) ? (p.Tk - j0) : KT);
-    __syncthreads();
-    load_tile<T, D>(sK, Kg + j0 * p.k_st, p.k_st, nk, tid);
-    load_tile<T, D>(sV, Vg + j0 * p.v_st, p.v_st, nk, tid);
-    if (tid < KT) sM[tid] = (tid >= nk) ? 1 : (p.kpm ? p.kpm[b * p.kpm_stride + j0 + tid] : 0);
-    __syncthreads();
+    rk.fetch(Kg + j0 * p.k_st, p.k_st, nk, tid);
+    rv.fetch(Vg + j0 * p.v_st, p.v_st, nk, tid);
+    if (tid < KT) rmask = (tid >= nk) ? 1 : (p.kpm ? p.kpm[b * p.kpm_stride + j0 + tid] : 0);
+  };
+  auto stage = [&](int st) {
+    rk.stage(smem + st * 2 * TILE, tid);
+    rv.stage(smem + st * 2 * TILE + TILE, tid);
+    if (wave == 0) {  // KT == 64: wave 0 holds one mask byte per key
+      const unsigned long long bits = __ballot(rmask != 0);
+      if (lane == 0) sMask[st] = bits;
+    }
+  };
+  if (kend > 0) { prefetch(0); stage(0); }
+  __syncthreads();
+  int cur = 0;
+  const int qlo = q_blk0 + wave * QB;
+  for (int64_t j0 = 0; j0 < kend; j0 += KT) {
+    const bool more = j0 + KT < kend;
+    if (more) prefetch(j0 + KT);  // global loads in flight under this tile's MFMAs
+    const T* sK = smem + cur * 2 * TILE;
+    const T* sV = sK + TILE;
+    const unsigned long long mb = sMask[cur];
 
     f32x16 s[2];
 #pragma unroll
@@ -144,29 +166,35 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
         mma16(s[ks], fk, fq[kk]);
       }
     }
+    // masking only on tiles that contain a padded key or cross the causal diagonal (wave-uniform test)
+    if (mb != 0ull || (p.causal && ((int)j0 + KT - 1 > qlo + cshift))) {
+      const unsigned long long mbl = mb >> (4 * hi);
+      const int lim = p.causal ? q + cshift - (int)j0 : 0x7fffffff;  // keys with tile index > lim are in the future
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kb = ks * 32 + (r & 3) + 8 * (r >> 2);  // + 4*hi = key index inside the tile
+          const bool masked = ((mbl >> kb) & 1ull) || (kb + 4 * hi > lim);
+          s[ks][r] = masked ? -INFINITY : s[ks][r];
+        }
+    }
     float mt = -INFINITY;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kr = ks * 32 + acc_row(r, lane);
-        float v = s[ks][r] * p.scale;
-        const bool masked = sM[kr] || (p.causal && (j0 + kr > (int64_t)q + cshift));
-        v = masked ? -INFINITY : v;
-        s[ks][r] = v;
-        mt = fmaxf(mt, v);
-      }
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[ks][r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * c2;  // c2 > 0: max commutes with the scale; -inf stays -inf
     const float m_new = fmaxf(m_run, mt);
     float alpha = 1.0f;
     if (m_new != -INFINITY) {
-      alpha = __expf(m_run - m_new);  // m_run = -inf -> 0
+      alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // m_run = -inf -> 0
       float ls = 0.0f;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float e = __expf(s[ks][r] - m_new);
+          const float e = __builtin_amdgcn_exp2f(fmaf(s[ks][r], c2, -m_new));
           s[ks][r] = e;
           ls += e;
         }
@@ -195,10 +223,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
         for (int dt = 0; dt < D / 32; ++dt) {
           Frag<T> fv;
-          frag_gather_rows<T, LD>(fv, sV, dt * 32 + (lane & 31), t, hi, ks * 32);
+          frag_load_tr(fv, sV, LD, dt * 32, ks * 32 + 16 * t + 4 * hi, ks * 32 + 16 * t + 4 * hi + 8, lane);
           mma16(o[dt], fv, fp);
         }
       }
+    if (more) stage(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   if (q < p.Tq) {
@@ -206,7 +237,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
     T* Og = (T*)p.O + b * p.o_sb + h * p.o_sh + (int64_t)q * p.o_st;
 #pragma unroll
     for (int dt = 0; dt < D / 32; ++dt) store_dcol<T>(Og, o[dt], dt * 32, lane, inv);
-    if (hi == 0) p.lse[(b * p.H + h) * p.Tq + q] = l_tot > 0.0f ? m_run + __logf(l_tot) : -INFINITY;
+    if (hi == 0) p.lse[(b * p.H + h) * p.Tq + q] = l_tot > 0.0f ? m_run * 0.6931471805599453f + __logf(l_tot) : -INFINITY;
   }
 }
 
@@ -235,10 +266,10 @@ __global__ void attn_delta_kernel(AttnParams p) {
 // dQ: per wave 32 queries (lane-local query column), loop over KV tiles.
 template <typename T, int D>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnParams p) {
-  constexpr int VEC = DT<T>::VEC, LD = D + VEC;
-  __shared__ __attribute__((aligned(16))) T sK[KT * LD];
-  __shared__ __attribute__((aligned(16))) T sV[KT * LD];
-  __shared__ uint8_t sM[KT];
+  constexpr int VEC = DT<T>::VEC, LD = D + VEC, TILE = KT * LD;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  unsigned long long* sMask = reinterpret_cast<unsigned long long*>(smem + 4 * TILE);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
   const int64_t b = blockIdx.z, h = blockIdx.y;
   const int q_blk0 = blockIdx.x * (NW * QB);
@@ -247,16 +278,18 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnParams p) {
   const T* Kg = (const T*)p.K + b * p.k_sb + h * p.k_sh;
   const T* Vg = (const T*)p.V + b * p.v_sb + h * p.v_sh;
   const T* dOg = (const T*)p.dO + b * p.do_sb + h * p.do_sh;
-  const int64_t cshift = p.Tk - p.Tq;
+  const int cshift = (int)(p.Tk - p.Tq);
+  const float c2 = p.scale * 1.4426950408889634f;
 
   Frag<T> fq[D / 16], fdo[D / 16];
   load_row_frags<T, D>(fq, Qg, p.q_st, q, (int)p.Tq, lane);
   load_row_frags<T, D>(fdo, dOg, p.do_st, q, (int)p.Tq, lane);
   float lse = -INFINITY, dlt = 0.0f;
   if (q < p.Tq) {
-    lse = p.lse[(b * p.H + h) * p.Tq + q];
+    lse = p.lse[(b * p.H + h) * p.Tq + q] * 1.4426950408889634f;  // log2 domain; -inf (fully masked row) stays -inf
     dlt = p.delta[(b * p.H + h) * p.Tq + q];
   }
+  const bool row_dead = lse == -INFINITY;
   f32x16 dq[D / 32];
 #pragma unroll
   for (int dt = 0; dt < D / 32; ++dt)
@@ -268,13 +301,34 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnParams p) {
     const int64_t last = (int64_t)q_blk0 + NW * QB + cshift;
     if (last < kend) kend = last;
   }
-  for (int64_t j0 = 0; j0 < kend; j0 += KT) {
+  TileRegs<T, D> rk, rv;
+  uint8_t rmask = 0;
+  auto prefetch = [&](int64_t j0) {
     const int nk = (int)((p.Tk - j0 < KT) ? (p.Tk - j0) : KT);
-    __syncthreads();
-    load_tile<T, D>(sK, Kg + j0 * p.k_st, p.k_st, nk, tid);
-    load_tile<T, D>(sV, Vg + j0 * p.v_st, p.v_st, nk, tid);
-    if (tid < KT) sM[tid] = (tid >= nk) ? 1 : (p.kpm ? p.kpm[b * p.kpm_stride + j0 + tid] : 0);
-    __syncthreads();
+    rk.fetch(Kg + j0 * p.k_st, p.k_st, nk, tid);
+    rv.fetch(Vg + j0 * p.v_st, p.v_st, nk, tid);
+    if (tid < KT) rmask = (tid >= nk) ? 1 : (p.kpm ? p.kpm[b * p.kpm_stride + j0 + tid] : 0);
+  };
+  auto stage = [&](int st) {
+    rk.stage(smem + st * 2 * TILE, tid);
+    rv.stage(smem + st * 2 * TILE + TILE, tid);
+    if (wave == 0) {
+      const unsigned long long bits = __ballot(rmask != 0);
+      if (lane == 0) sMask[st] = bits;
+    }
+  };
+  if (kend > 0) { prefetch(0); stage(0); }
+  __syncthreads();
+  int cur = 0;
+  for (int64_t j0 = 0; j0 < kend; j0 += KT) {
+    const bool more = j0 + KT < kend;
+    if (more) prefetch(j0 + KT);
+    const T* sK = smem + cur * 2 * TILE;
+    const T* sV = sK + TILE;
+    const unsigned long long mb = sMask[cur];
+    const bool need_mask = mb != 0ull || (p.causal && ((int)j0 + KT - 1 > q_blk0 + wave * QB + cshift));
+    const unsigned long long mbl = mb >> (4 * hi);
+    const int lim = p.causal ? q + cshift - (int)j0 : 0x7fffffff;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       f32x16 s, dp;
@@ -290,9 +344,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnParams p) {
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int kr = ks * 32 + acc_row(r, lane);
-        const bool masked = sM[kr] || (p.causal && (j0 + kr > (int64_t)q + cshift)) || lse == -INFINITY;
-        const float pr = masked ? 0.0f : __expf(s[r] * p.scale - lse);
+        float pr = row_dead ? 0.0f : __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse));
+        if (need_mask) {
+          const int kb = ks * 32 + (r & 3) + 8 * (r >> 2);
+          pr = (((mbl >> kb) & 1ull) || (kb + 4 * hi > lim)) ? 0.0f : pr;
+        }
         s[r] = pr * (dp[r] - dlt);  // dS^T (scale folded in at the end)
       }
 #pragma unroll
@@ -305,11 +361,14 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
         for (int dt = 0; dt < D / 32; ++dt) {
           Frag<T> fkt;
-          frag_gather_rows<T, LD>(fkt, sK, dt * 32 + (lane & 31), t, hi, ks * 32);
+          frag_load_tr(fkt, sK, LD, dt * 32, ks * 32 + 16 * t + 4 * hi, ks * 32 + 16 * t + 4 * hi + 8, lane);
           mma16(dq[dt], fkt, fds);  // dQ^T[d][q] += K^T dS^T
         }
       }
     }
+    if (more) stage(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
   }
   if (q < p.Tq) {
     T* g = (T*)p.dQ + b * p.dq_sb + h * p.dq_sh + (int64_t)q * p.dq_st;
@@ -321,10 +380,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnParams p) {
 // dK,dV: per wave 32 keys (lane-local key column), loop over Q tiles of 64 queries.
 template <typename T, int D>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
-  constexpr int VEC = DT<T>::VEC, LD = D + VEC;
-  __shared__ __attribute__((aligned(16))) T sQ[KT * LD];
-  __shared__ __attribute__((aligned(16))) T sdO[KT * LD];
-  __shared__ float sL[KT], sD[KT];
+  constexpr int VEC = DT<T>::VEC, LD = D + VEC, TILE = KT * LD;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  float* sStat = reinterpret_cast<float*>(smem + 4 * TILE);  // [2 stages][lse KT | delta KT]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
   const int64_t b = blockIdx.z, h = blockIdx.y;
   const int k_blk0 = blockIdx.x * (NW * QB);
@@ -333,7 +392,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
   const T* Kg = (const T*)p.K + b * p.k_sb + h * p.k_sh;
   const T* Vg = (const T*)p.V + b * p.v_sb + h * p.v_sh;
   const T* dOg = (const T*)p.dO + b * p.do_sb + h * p.do_sh;
-  const int64_t cshift = p.Tk - p.Tq;
+  const int cshift = (int)(p.Tk - p.Tq);
+  const float c2 = p.scale * 1.4426950408889634f;
 
   Frag<T> fk[D / 16], fv[D / 16];
   load_row_frags<T, D>(fk, Kg, p.k_st, key, (int)p.Tk, lane);
@@ -352,16 +412,32 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
     if (qstart < 0) qstart = 0;
     qstart = (qstart / KT) * KT;
   }
-  for (int64_t i0 = qstart; i0 < p.Tq; i0 += KT) {
+  TileRegs<T, D> rq, rdo;
+  float rl = -INFINITY, rd = 0.0f;
+  auto prefetch = [&](int64_t i0) {
     const int nq = (int)((p.Tq - i0 < KT) ? (p.Tq - i0) : KT);
-    __syncthreads();
-    load_tile<T, D>(sQ, Qg + i0 * p.q_st, p.q_st, nq, tid);
-    load_tile<T, D>(sdO, dOg + i0 * p.do_st, p.do_st, nq, tid);
+    rq.fetch(Qg + i0 * p.q_st, p.q_st, nq, tid);
+    rdo.fetch(dOg + i0 * p.do_st, p.do_st, nq, tid);
     if (tid < KT) {
-      sL[tid] = tid < nq ? p.lse[(b * p.H + h) * p.Tq + i0 + tid] : -INFINITY;
-      sD[tid] = tid < nq ? p.delta[(b * p.H + h) * p.Tq + i0 + tid] : 0.0f;
+      rl = tid < nq ? p.lse[(b * p.H + h) * p.Tq + i0 + tid] * 1.4426950408889634f : -INFINITY;  // log2 domain; -inf -> P = 0
+      rd = tid < nq ? p.delta[(b * p.H + h) * p.Tq + i0 + tid] : 0.0f;
     }
-    __syncthreads();
+  };
+  auto stage = [&](int st) {
+    rq.stage(smem + st * 2 * TILE, tid);
+    rdo.stage(smem + st * 2 * TILE + TILE, tid);
+    if (tid < KT) { sStat[st * 2 * KT + tid] = rl; sStat[st * 2 * KT + KT + tid] = rd; }
+  };
+  if (qstart < p.Tq) { prefetch(qstart); stage(0); }
+  __syncthreads();
+  int cur = 0;
+  for (int64_t i0 = qstart; i0 < p.Tq; i0 += KT) {
+    const bool more = i0 + KT < p.Tq;
+    if (more) prefetch(i0 + KT);
+    const T* sQ = smem + cur * 2 * TILE;
+    const T* sdO = sQ + TILE;
+    const float* sL = sStat + cur * 2 * KT;
+    const float* sD = sL + KT;
 #pragma unroll
     for (int qs = 0; qs < 2; ++qs) {
       f32x16 s, dp;
@@ -376,12 +452,14 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
         mma16(dp, fdor, fv[kk]);   // dP[q][key] = dO V^T
       }
       f32x16 pr;
+      const bool diag = p.causal && (k_blk0 + wave * QB + QB - 1 > (int)i0 + qs * 32 + cshift);  // wave-uniform: tile touches the future
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int qr = qs * 32 + acc_row(r, lane);
         const float l = sL[qr];
-        const bool masked = key_masked || l == -INFINITY || (p.causal && ((int64_t)key > i0 + qr + cshift));
-        const float e = masked ? 0.0f : __expf(s[r] * p.scale - l);
+        float e = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -l));  // l = -inf (dead / out-of-range row): handled below
+        e = (key_masked || l == -INFINITY) ? 0.0f : e;
+        if (diag) e = (key > (int)i0 + qr + cshift) ? 0.0f : e;
         pr[r] = e;
         s[r] = e * (dp[r] - sD[qr]);  // dS[q][key]
       }
@@ -396,13 +474,16 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
         for (int dt = 0; dt < D / 32; ++dt) {
           Frag<T> fdot, fqt;
-          frag_gather_rows<T, LD>(fdot, sdO, dt * 32 + (lane & 31), t, hi, qs * 32);
-          frag_gather_rows<T, LD>(fqt, sQ, dt * 32 + (lane & 31), t, hi, qs * 32);
+          frag_load_tr(fdot, sdO, LD, dt * 32, qs * 32 + 16 * t + 4 * hi, qs * 32 + 16 * t + 4 * hi + 8, lane);
+          frag_load_tr(fqt, sQ, LD, dt * 32, qs * 32 + 16 * t + 4 * hi, qs * 32 + 16 * t + 4 * hi + 8, lane);
           mma16(dv[dt], fdot, fp);   // dV^T[d][key] += dO^T P
           mma16(dk[dt], fqt, fds);   // dK^T[d][key] += Q^T dS
         }
       }
     }
+    if (more) stage(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
   }
   if (key < p.Tk) {
     T* gk = (T*)p.dK + b * p.dk_sb + h * p.dk_sh + (int64_t)key * p.dk_st;
@@ -449,6 +530,14 @@ int fill_params(const cst_attn_desc* d, AttnParams& p, bool bwd) {
   return CST_OK;
 }
 
+template <typename T, int D>
+constexpr size_t attn_lds_bytes() {
+  return 4 * (size_t)KT * (D + DT<T>::VEC) * sizeof(T) + 4 * KT * sizeof(float);  // 2 stages x 2 tiles + masks / (lse, delta)
+}
+void attn_set_lds(const void* fn) {  // tiles of the f32 / D=64 variants exceed the 64 KiB default (gfx950: 160 KiB per CU)
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+}
+
 double attn_flops(const cst_attn_desc* d, double gemms) {
   double pairs = (double)d->Tq * (double)d->Tk;
   if (d->causal) pairs *= 0.5;
@@ -464,7 +553,8 @@ extern "C" int cst_attn_fwd(const cst_attn_desc* d, cst_stream stream) {
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)cst_ceil_div(d->Tq, NW * QB), (unsigned)d->H, (unsigned)d->B);
   CstProfScope prof(CST_K_ATTN_FWD, s, attn_flops(d, 2.0), 0.0);
-#define CST_FWD(T, DD) hipLaunchKernelGGL((attn_fwd_kernel<T, DD>), grid, dim3(NW * 64), 0, s, p)
+#define CST_FWD(T, DD) do { const size_t lds = attn_lds_bytes<T, DD>(); attn_set_lds(reinterpret_cast<const void*>(&attn_fwd_kernel<T, DD>)); \
+    hipLaunchKernelGGL((attn_fwd_kernel<T, DD>), grid, dim3(NW * 64), lds, s, p); } while (0)
   if (d->dtype == CST_BF16) { if (d->D == 64) CST_FWD(bf16_t, 64); else CST_FWD(bf16_t, 32); }
   else { if (d->D == 64) CST_FWD(float, 64); else CST_FWD(float, 32); }
 #undef CST_FWD
@@ -483,8 +573,11 @@ extern "C" int cst_attn_bwd(const cst_attn_desc* d, cst_stream stream) {
 #define CST_BWD(T, DD)                                                                                     \
   do {                                                                                                     \
     hipLaunchKernelGGL((attn_delta_kernel<T, DD>), dim3((unsigned)cst_ceil_div(rows, 256)), dim3(256), 0, s, p); \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DD>), gq, dim3(NW * 64), 0, s, p);                            \
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DD>), gk, dim3(NW * 64), 0, s, p);                           \
+    const size_t lds = attn_lds_bytes<T, DD>();                                                              \
+    attn_set_lds(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<T, DD>));                                 \
+    attn_set_lds(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<T, DD>));                                \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DD>), gq, dim3(NW * 64), lds, s, p);                          \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DD>), gk, dim3(NW * 64), lds, s, p);                         \
   } while (0)
   if (d->dtype == CST_BF16) { if (d->D == 64) CST_BWD(bf16_t, 64); else CST_BWD(bf16_t, 32); }
   else { if (d->D == 64) CST_BWD(float, 64); else CST_BWD(float, 32); }

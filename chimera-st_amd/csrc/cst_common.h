@@ -44,12 +44,11 @@ using u16x8 = __attribute__((ext_vector_type(8))) unsigned short;
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
   return __uint_as_float(((unsigned int)b) << 16);
 }
-// round-to-nearest-even, NaN preserved (matches torch's float -> bfloat16)
+// float -> bf16, round-to-nearest-even.  A plain cast: hipcc lowers it to the gfx950 hardware converter
+// (v_cvt_pk_bf16_f32), branch-free — a hand-written bit-twiddling version with a NaN branch cost ~8 VALU + an exec-mask
+// branch per element and dominated the attention inner loop.
 __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
-  unsigned int u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
+  return __builtin_bit_cast(unsigned short, static_cast<__bf16>(f));
 }
 
 template <typename T> struct DT;
@@ -89,11 +88,10 @@ __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
   *reinterpret_cast<f32x4*>(p + 4) = b;
 }
 __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
-  u32x4 r;
+  bf16x8 r;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-    r[i] = (unsigned int)f32_to_bf16_bits(v[2 * i]) | ((unsigned int)f32_to_bf16_bits(v[2 * i + 1]) << 16);
-  *reinterpret_cast<u32x4*>(p) = r;
+  for (int i = 0; i < 8; ++i) r[i] = static_cast<__bf16>(v[i]);
+  *reinterpret_cast<bf16x8*>(p) = r;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -163,12 +161,36 @@ __device__ __forceinline__ void frag_load_strided(Frag<float>& f, const float* p
 #pragma unroll
   for (int j = 0; j < 8; ++j) f.v[j] = p[j * stride];
 }
+// Fragment whose reduction index is the SLOW index of an LDS tile laid out [k][mn] (mn contiguous, row stride `ld`):
+// lane l receives tile[k][mn0 + (l&31)] for the 8 k values {ka..ka+3, kb..kb+3} (ka/kb already include this half-wave's
+// offset).  bf16: two ds_read_b64_tr_b16 (gfx950 LDS transpose read; measured semantics, tools/probes/trprobe.hip:
+// within a 16-lane group source lane s supplies the 8-byte chunk (row s>>2, chunk s&3) of a 4 x 16 block and lane i
+// receives column i of that block, 4 consecutive rows).  f32: eight ds_read_b32 (half-wave = 32 consecutive addresses).
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void frag_load_tr(Frag<bf16_t>& f, const bf16_t* tile, int ld, int mn0, int ka, int kb, int lane) {
+  const int s = lane & 15;
+  const int col = mn0 + 16 * ((lane >> 4) & 1) + 4 * (s & 3);
+  const bf16_t* pa = tile + (ka + (s >> 2)) * ld + col;
+  const bf16_t* pb = tile + (kb + (s >> 2)) * ld + col;
+  const v4s_t x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_t __attribute__((address_space(3)))*)pa);
+  const v4s_t y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_t __attribute__((address_space(3)))*)pb);
+  u16x8 t;
+  t[0] = (unsigned short)x[0]; t[1] = (unsigned short)x[1]; t[2] = (unsigned short)x[2]; t[3] = (unsigned short)x[3];
+  t[4] = (unsigned short)y[0]; t[5] = (unsigned short)y[1]; t[6] = (unsigned short)y[2]; t[7] = (unsigned short)y[3];
+  f.v = __builtin_bit_cast(bf16x8, t);
+}
+__device__ __forceinline__ void frag_load_tr(Frag<float>& f, const float* tile, int ld, int mn0, int ka, int kb, int lane) {
+  const float* p = tile + mn0 + (lane & 31);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f.v[j] = p[(ka + j) * ld];
+    f.v[4 + j] = p[(kb + j) * ld];
+  }
+}
 // fragment from 8 fp32 register values (e.g. softmax probabilities)
 __device__ __forceinline__ void frag_from_f32(Frag<bf16_t>& f, const float (&x)[8]) {
-  u16x8 t;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) t[j] = f32_to_bf16_bits(x[j]);
-  f.v = __builtin_bit_cast(bf16x8, t);
+  for (int j = 0; j < 8; ++j) f.v[j] = static_cast<__bf16>(x[j]);
 }
 __device__ __forceinline__ void frag_from_f32(Frag<float>& f, const float (&x)[8]) {
 #pragma unroll

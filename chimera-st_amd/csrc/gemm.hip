@@ -103,7 +103,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
   constexpr int VEC = DT<T>::VEC;
   constexpr int BK = 8 * VEC;
   constexpr int LDK = BK + VEC;    // k-major LDS row stride (elements)
-  constexpr int LDM = 128 + VEC;   // mn-major LDS row stride
+  constexpr int LDM = sizeof(T) == 2 ? 160 : 128 + VEC;  // mn-major LDS row stride (bf16: 80 dwords = 16 mod 64 -> conflict-free tr reads)
   constexpr int A_ELEMS = A_KMAJOR ? BM * LDK : BK * LDM;
   constexpr int B_ELEMS = B_KMAJOR ? BN * LDK : BK * LDM;
   constexpr int MVECS = 128 / VEC;  // vectors per mn-major row
@@ -262,9 +262,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         if (A_KMAJOR) frag_load_contig(fa[i], sa + (wm * 64 + i * 32 + lrow) * LDK + kk + lk);
-        else frag_load_strided(fa[i], sa + (kk + lk) * LDM + wm * 64 + i * 32 + lrow, LDM);
+        else frag_load_tr(fa[i], sa, LDM, wm * 64 + i * 32, kk + lk, kk + lk + 4, lane);
         if (B_KMAJOR) frag_load_contig(fb[i], sb + (wn * 64 + i * 32 + lrow) * LDK + kk + lk);
-        else frag_load_strided(fb[i], sb + (kk + lk) * LDM + wn * 64 + i * 32 + lrow, LDM);
+        else frag_load_tr(fb[i], sb, LDM, wn * 64 + i * 32, kk + lk, kk + lk + 4, lane);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -333,7 +333,7 @@ __global__ void splitk_reduce_kernel(GemmParams p) {
 template <typename T, bool AK, bool BK_, bool SEG>
 int launch(const GemmParams& p, int64_t nbatch, hipStream_t s) {
   constexpr int VEC = DT<T>::VEC;
-  constexpr int BKc = 8 * VEC, LDK = BKc + VEC, LDM = 128 + VEC;
+  constexpr int BKc = 8 * VEC, LDK = BKc + VEC, LDM = sizeof(T) == 2 ? 160 : 128 + VEC;
   constexpr int A_ELEMS = AK ? BM * LDK : BKc * LDM;
   constexpr int B_ELEMS = BK_ ? BN * LDK : BKc * LDM;
   size_t lds = 2 * (size_t)(A_ELEMS + B_ELEMS) * sizeof(T);
