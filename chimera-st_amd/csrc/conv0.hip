@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* wav, const 
 
 // ---- backward pass over dy: per (b,c) accumulate s1, s2, r[0..k) --------------------------------
 // acc layout in ws: [B][k+2][C]  (row 0 = s1, row 1 = s2, rows 2.. = r[j])
-constexpr int C0_BWD_TB = 256;  // frames per block
+constexpr int C0_BWD_TB = 1024;  // frames per block (fewer, larger blocks: the per-block result goes out as fp32 atomics)
 
 template <typename T>
 __global__ __launch_bounds__(256) void conv0_bwd_kernel(const T* dy, const float* wav, const T* w, const T* gamma,
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(const T* dy, const float
   // thread -> fixed channel vector, strided over frames so partial sums stay in registers
   const int tpc = blockDim.x / cvecs > 0 ? blockDim.x / cvecs : 1;  // threads per channel vector
   const int cv = threadIdx.x % cvecs, tsl = threadIdx.x / cvecs;
-  if (tsl >= tpc) return;
+  const bool active = tsl < tpc;
   float s1[8], s2[8], r[KMAX][8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s1[e] = 0.0f; s2[e] = 0.0f; }
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(const T* dy, const float
 #pragma unroll
     for (int e = 0; e < 8; ++e) r[j][e] = 0.0f;
   for (int ccv = cv; ccv < cvecs; ccv += blockDim.x) {  // (runs once: cvecs <= blockDim.x)
-    for (int tl = tsl; tl < nt; tl += tpc) {
+    for (int tl = tsl; active && tl < nt; tl += tpc) {
       float d[8], u[8];
       load8(dy + (b * L + t0 + tl) * C + ccv * 8, d);
 #pragma unroll
@@ -191,18 +191,27 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(const T* dy, const float
         for (int j = 0; j < KMAX; ++j) r[j][e] += dz * xv[j];
       }
     }
+    // combine the frame-lanes that share this channel vector through LDS (one 8-float row of the accumulator set at a
+    // time, so the staging area is 8 KiB), then ONE atomic per value per block instead of one per thread.
     float* o = ws + b * (k + 2) * (int64_t)C + ccv * 8;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      atomicAdd(o + e, s1[e]);
-      atomicAdd(o + C + e, s2[e]);
-    }
+    for (int row = 0; row < KMAX + 2; ++row) {
+      if (row < k + 2) {  // wave-uniform
+        __syncthreads();
+        float* mine = sm + (size_t)threadIdx.x * 8;
 #pragma unroll
-    for (int j = 0; j < KMAX; ++j)
-      if (j < k) {
+        for (int e = 0; e < 8; ++e) mine[e] = row == 0 ? s1[e] : (row == 1 ? s2[e] : r[row >= 2 ? row - 2 : 0][e]);
+        __syncthreads();
+        if (tsl == 0) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) atomicAdd(o + (int64_t)(2 + j) * C + e, r[j][e]);
+          for (int e = 0; e < 8; ++e) {
+            float v = 0.0f;
+            for (int t2 = 0; t2 < tpc; ++t2) v += sm[(size_t)(t2 * cvecs + ccv) * 8 + e];
+            atomicAdd(o + (int64_t)row * C + e, v);
+          }
+        }
       }
+    }
   }
 }
 
@@ -279,7 +288,7 @@ extern "C" int cst_conv0_gn_gelu_bwd(const void* dy, const float* wav, const voi
   const double bytes = (double)B * S * 4.0 + (double)B * L * C * cst_dtype_size(dtype);
   CstProfScope prof(CST_K_CONV0, s, 4.0 * (double)B * L * C * k, bytes);
   if (hipMemsetAsync(workspace, 0, (size_t)cst_conv0_bwd_workspace(B, C, k), s) != hipSuccess) { cst_set_error("conv0 bwd: memset failed"); return CST_ERR_LAUNCH; }
-  const size_t lds = sizeof(float) * ((size_t)k * C + 4 * C + (size_t)C0_BWD_TB * stride + k);
+  size_t lds = sizeof(float) * ((size_t)k * C + 4 * C + (size_t)C0_BWD_TB * stride + k);
   dim3 grid((unsigned)cst_ceil_div(L, C0_BWD_TB), (unsigned)B), fg((unsigned)cst_ceil_div(C, 128));
   if (dtype == CST_BF16) {
     hipLaunchKernelGGL(conv0_bwd_kernel<bf16_t>, grid, dim3(256), lds, s, (const bf16_t*)dy, wav, (const bf16_t*)w, (const bf16_t*)gamma, (const bf16_t*)beta, mean, rstd, workspace, S, L, (int)C, k, stride);
