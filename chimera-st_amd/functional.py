@@ -121,6 +121,34 @@ def add_layer_norm(x, res, gamma, beta, eps=1e-5):
     return _LayerNormFn.apply(x, res, gamma, beta, eps)
 
 
+class _LayerNormPassFn(torch.autograd.Function):
+    """y = LN(x) and x handed back as a second output: a pre-norm block uses the pass-through as its residual, so the
+    residual-branch gradient and the LN gradient arrive in ONE backward call and are summed inside cst_layernorm_bwd
+    (no separate autograd accumulation kernel per block)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x2 = _flat2d(x)
+        y, _, mean, rstd = K.layernorm_fwd(x2, None, gamma, beta, eps)
+        ctx.save_for_backward(x2, gamma, mean, rstd)
+        ctx.shape = x.shape
+        return y.view(x.shape), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dxp):
+        x2, gamma, mean, rstd = ctx.saved_tensors
+        dres = _flat2d(dxp) if dxp is not None else None
+        if dy is None:
+            return (dxp, None, None, None)
+        dx, dg, db = K.layernorm_bwd(_flat2d(dy), x2, gamma, mean, rstd, dres)
+        return dx.view(ctx.shape), dg.to(gamma.dtype), db.to(gamma.dtype), None
+
+
+def layer_norm_residual(x, gamma, beta, eps=1e-5):
+    """Returns (LN(x), x') where x' aliases x and must be used for the block's residual connection."""
+    return _LayerNormPassFn.apply(x, gamma, beta, eps)
+
+
 # ------------------------------------------------------------------------------------------------
 # fused attention
 # ------------------------------------------------------------------------------------------------
@@ -154,6 +182,51 @@ def attention(q, k, v, num_heads, key_padding_mask=None, causal=False, scale=Non
         key_padding_mask = key_padding_mask.to(torch.uint8).contiguous()
     assert q.stride(-1) == 1 and k.stride(-1) == 1 and v.stride(-1) == 1
     return _AttnFn.apply(q, k, v, key_padding_mask, num_heads, bool(causal), float(scale), layout_q, layout_kv)
+
+
+class _AttnPackedFn(torch.autograd.Function):
+    """Self-attention on a packed projection qkv [B, T, 3C] (q | k | v along channels).  The backward writes dq/dk/dv
+    into ONE [B, T, 3C] buffer, so the projection's dX / dW are single GEMMs and x receives a single gradient."""
+
+    @staticmethod
+    def forward(ctx, qkv, kpm, H, causal, scale):
+        C = qkv.shape[-1] // 3
+        D = C // H
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        B, T = qkv.shape[0], qkv.shape[1]
+        o = torch.empty(B, T, C, dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
+        d = K.attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, "bt", "bt")
+        K.attn_fwd_desc(d)
+        ctx.save_for_backward(qkv, o, lse, kpm)
+        ctx.cfg = (H, D, C, causal, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, o, lse, kpm = ctx.saved_tensors
+        H, D, C, causal, scale = ctx.cfg
+        if not do.is_contiguous():
+            do = do.contiguous()
+        dqkv = torch.empty_like(qkv)
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        dq, dk, dv = dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:]
+        delta = torch.empty_like(lse)
+        d = K.attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, "bt", "bt")
+        K.attn_bwd_fill(d, do, dq, dk, dv, delta, D, "bt", "bt")
+        K.attn_bwd_desc(d)
+        return dqkv, None, None, None, None
+
+
+def attention_packed(qkv, num_heads, key_padding_mask=None, causal=False, scale=None):
+    """qkv [B, T, 3C] contiguous -> [B, T, C]."""
+    C = qkv.shape[-1] // 3
+    if scale is None:
+        scale = (C // num_heads) ** -0.5
+    if key_padding_mask is not None:
+        key_padding_mask = key_padding_mask.to(torch.uint8).contiguous()
+    assert qkv.is_contiguous()
+    return _AttnPackedFn.apply(qkv, key_padding_mask, num_heads, bool(causal), float(scale))
 
 
 # ------------------------------------------------------------------------------------------------

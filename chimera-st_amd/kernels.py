@@ -148,11 +148,16 @@ def attn_fwd(q, k, v, H, D, kpm, causal, scale, layout_q="bt", layout_kv="bt"):
     return o, lse
 
 
-def attn_bwd(do, q, k, v, o, lse, H, D, kpm, causal, scale, layout_q="bt", layout_kv="bt"):
-    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-    delta = torch.empty_like(lse)
-    d = attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, layout_q, layout_kv)
+def attn_fwd_desc(d):
+    L.check(L.load().cst_attn_fwd(ctypes.byref(d), L.stream_ptr()), "cst_attn_fwd")
 
+
+def attn_bwd_desc(d):
+    L.check(L.load().cst_attn_bwd(ctypes.byref(d), L.stream_ptr()), "cst_attn_bwd")
+
+
+def attn_bwd_fill(d, do, dq, dk, dv, delta, D, layout_q="bt", layout_kv="bt"):
+    """Fill the backward half of an attention descriptor (gradient tensors may be strided views, d contiguous)."""
     def st(t, lay):
         sb, _, stt = _bhtd_strides(t, lay)
         return sb, D, stt
@@ -162,6 +167,13 @@ def attn_bwd(do, q, k, v, o, lse, H, D, kpm, causal, scale, layout_q="bt", layou
     d.dK = dk.data_ptr(); d.dk_sb, d.dk_sh, d.dk_st = st(dk, layout_kv)
     d.dV = dv.data_ptr(); d.dv_sb, d.dv_sh, d.dv_st = st(dv, layout_kv)
     d.delta = delta.data_ptr()
+
+
+def attn_bwd(do, q, k, v, o, lse, H, D, kpm, causal, scale, layout_q="bt", layout_kv="bt"):
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    delta = torch.empty_like(lse)
+    d = attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, layout_q, layout_kv)
+    attn_bwd_fill(d, do, dq, dk, dv, delta, D, layout_q, layout_kv)
     L.check(L.load().cst_attn_bwd(ctypes.byref(d), L.stream_ptr()), "cst_attn_bwd")
     return dq, dk, dv
 

@@ -56,6 +56,14 @@ class LayerNorm(nn.Module):
             return CF.layer_norm(x.transpose(0, 1), self.weight, self.bias, self.eps).transpose(0, 1)
         return CF.layer_norm(x, self.weight, self.bias, self.eps)
 
+    def forward_residual(self, x):
+        """(LN(x), x') — x' aliases x and is what the caller must feed its residual connection, so that the LN gradient
+        and the residual gradient are summed inside the LN backward kernel (functional._LayerNormPassFn)."""
+        if x.dim() == 3 and not x.is_contiguous() and x.transpose(0, 1).is_contiguous():
+            y, xp = CF.layer_norm_residual(x.transpose(0, 1), self.weight, self.bias, self.eps)
+            return y.transpose(0, 1), xp.transpose(0, 1)
+        return CF.layer_norm_residual(x, self.weight, self.bias, self.eps)
+
 
 def Embedding(num_embeddings, embedding_dim, padding_idx):
     """models/transformer.py:906-911."""
@@ -261,6 +269,18 @@ class MultiheadAttention(FairseqIncrementalState, nn.Module):
                 assert self.encoder_decoder_attention and not self.self_attention
                 key = value = None
 
+        if self.self_attention and saved_state is None:
+            # packed projection: one [3C, C] GEMM (and one dX / dW GEMM in backward) instead of three; the fused attention
+            # kernel reads q | k | v as channel slices of the [B, T, 3C] result and writes dq | dk | dv the same way.
+            w = torch.cat((self.q_proj.weight, self.k_proj.weight, self.v_proj.weight), 0)
+            bqkv = (torch.cat((self.q_proj.bias, self.k_proj.bias, self.v_proj.bias), 0)
+                    if self.q_proj.bias is not None else None)
+            qkv = CF.linear(qb, w, bqkv)
+            if key_padding_mask is not None and key_padding_mask.dim() == 0:
+                key_padding_mask = None
+            attn = CF.attention_packed(qkv, self.num_heads, key_padding_mask, causal, self.scaling)
+            out = self.out_proj(attn, resid=to_batch_major(resid) if resid is not None else None)
+            return to_time_major_view(out), None
         q = self.q_proj(qb)
         k = v = None
         if self.self_attention:
@@ -390,7 +410,7 @@ class TransformerEncoderLayer(nn.Module):
         the same self_attn_layer_norm, i.e. exactly the rows of cat(h_enc, memory) the masked reference attends to."""
         residual = x
         if self.normalize_before:
-            h = self.self_attn_layer_norm(x)
+            h, residual = self.self_attn_layer_norm.forward_residual(x)
             hk = self.self_attn_layer_norm(kv) if kv is not None else h
         else:
             h, hk = x, (kv if kv is not None else x)
@@ -404,7 +424,10 @@ class TransformerEncoderLayer(nn.Module):
         if not self.normalize_before:
             x = self.self_attn_layer_norm(x)
         residual = x
-        h = self.final_layer_norm(x) if self.normalize_before else x
+        if self.normalize_before:
+            h, residual = self.final_layer_norm.forward_residual(x)
+        else:
+            h = x
         h = self.fc1(to_batch_major(h), act=self.activation_fn)
         if fused:
             x = to_time_major_view(self.fc2(h, resid=to_batch_major(residual)))
@@ -473,7 +496,10 @@ class TransformerDecoderLayer(nn.Module):
                 need_head_weights=False):
         fused = self._fused()
         residual = x
-        h = self.self_attn_layer_norm(x) if self.normalize_before else x
+        if self.normalize_before:
+            h, residual = self.self_attn_layer_norm.forward_residual(x)
+        else:
+            h = x
         a, _ = self.self_attn(query=h, key=h, value=h, key_padding_mask=self_attn_padding_mask,
                               incremental_state=incremental_state, need_weights=False, attn_mask=self_attn_mask,
                               resid=residual if fused else None)
@@ -482,7 +508,10 @@ class TransformerDecoderLayer(nn.Module):
             x = self.self_attn_layer_norm(x)
         if self.encoder_attn is not None and encoder_out is not None:
             residual = x
-            h = self.encoder_attn_layer_norm(x) if self.normalize_before else x
+            if self.normalize_before:
+                h, residual = self.encoder_attn_layer_norm.forward_residual(x)
+            else:
+                h = x
             a, _ = self.encoder_attn(query=h, key=encoder_out, value=encoder_out, key_padding_mask=encoder_padding_mask,
                                      incremental_state=incremental_state, static_kv=True, need_weights=False,
                                      resid=residual if fused else None)
@@ -490,7 +519,10 @@ class TransformerDecoderLayer(nn.Module):
             if not self.normalize_before:
                 x = self.encoder_attn_layer_norm(x)
         residual = x
-        h = self.final_layer_norm(x) if self.normalize_before else x
+        if self.normalize_before:
+            h, residual = self.final_layer_norm.forward_residual(x)
+        else:
+            h = x
         h = self.fc1(to_batch_major(h), act=self.activation_fn)
         if fused:
             x = to_time_major_view(self.fc2(h, resid=to_batch_major(residual)))

@@ -30,6 +30,8 @@ def gemm_key(A, B, C, M, N, Kd, **k):
     return "M=%d N=%d K=%d %s%s b=%dx%d act=%s sk=%s" % (M, N, Kd, "k" if k["a_kmajor"] else "m", "k" if k["b_kmajor"] else "m",
                                                        k.get("batch0", 1), k.get("batch1", 1), k.get("act", 0), k.get("split_k", -1))
 K.gemm = wrap("gemm", K.gemm, gemm_key)
+K.attn_fwd_desc = wrap("attn_fwd", K.attn_fwd_desc, lambda d: "B%d H%d Tq%d Tk%d" % (d.B, d.H, d.Tq, d.Tk))
+K.attn_bwd_desc = wrap("attn_bwd", K.attn_bwd_desc, lambda d: "B%d H%d Tq%d Tk%d" % (d.B, d.H, d.Tq, d.Tk))
 for n in ("layernorm_fwd", "layernorm_bwd", "attn_fwd", "attn_bwd", "conv0_fwd", "conv0_bwd", "glu_fwd", "glu_bwd", "act_bwd", "colsum",
           "col2im1d", "mask_rows", "ls_ce_fwd", "ls_ce_bwd", "adam_step", "sumsq"):
     setattr(K, n, wrap(n, getattr(K, n), lambda *a, **k: "x".join(str(tuple(t.shape)) for t in a[:1] if torch.is_tensor(t))))
