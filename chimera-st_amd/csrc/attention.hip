@@ -96,7 +96,7 @@ __device__ __forceinline__ void store_dcol(T* g, const f32x16& acc, int d0, int 
 
 // ---------------------------------------------------------------------------------------------
 template <typename T, int D>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_fwd_kernel(AttnParams p) {
   constexpr int VEC = DT<T>::VEC, LD = D + VEC, TILE = KT * LD;
   // dynamic LDS: 2 stages x {K tile, V tile} + 2 x KT mask bytes; stage addresses are always smem + stage * 2*TILE
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -265,7 +265,7 @@ __global__ void attn_delta_kernel(AttnParams p) {
 // ---------------------------------------------------------------------------------------------
 // dQ: per wave 32 queries (lane-local query column), loop over KV tiles.
 template <typename T, int D>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnParams p) {
+__global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_bwd_dq_kernel(AttnParams p) {
   constexpr int VEC = DT<T>::VEC, LD = D + VEC, TILE = KT * LD;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnParams p) {
 
 // dK,dV: per wave 32 keys (lane-local key column), loop over Q tiles of 64 queries.
 template <typename T, int D>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnParams p) {
   constexpr int VEC = DT<T>::VEC, LD = D + VEC, TILE = KT * LD;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
