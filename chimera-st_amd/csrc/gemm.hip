@@ -19,7 +19,13 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, NTHREADS = 256;
+// tile configurations: Cfg<BM, BN, WM, WN>: WM x WN waves, each (BM/WM) x (BN/WN) = (TM*32) x (TN*32)
+template <int BM_, int BN_, int WM_, int WN_>
+struct Cfg {
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NT = 64 * WM_ * WN_, TM = BM_ / WM_ / 32, TN = BN_ / WN_ / 32;
+};
+using CfgSmall = Cfg<128, 128, 2, 2>;   // 4 waves, 2 blocks/CU: small / skinny problems, grouped conv
+using CfgLarge = Cfg<256, 256, 2, 4>;   // 8 waves (wave tile 128 x 64), 1 block/CU: half the L2->LDS bytes per FLOP
 
 struct GemmParams {
   int64_t M, N, K;
@@ -98,15 +104,19 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int64_t cof
   else store8((T*)p.C + cofs + row * p.ldc + col, v);
 }
 
-template <typename T, bool A_KMAJOR, bool B_KMAJOR, bool SEG>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
+template <typename T, bool A_KMAJOR, bool B_KMAJOR, bool SEG, typename C>
+__global__ __launch_bounds__(C::NT) void gemm_kernel(GemmParams p) {
+  constexpr int BM = C::BM, BN = C::BN, NTHREADS = C::NT, TM = C::TM, TN = C::TN;
   constexpr int VEC = DT<T>::VEC;
   constexpr int BK = 8 * VEC;
   constexpr int LDK = BK + VEC;    // k-major LDS row stride (elements)
-  constexpr int LDM = sizeof(T) == 2 ? 160 : 128 + VEC;  // mn-major LDS row stride (bf16: 80 dwords = 16 mod 64 -> conflict-free tr reads)
-  constexpr int A_ELEMS = A_KMAJOR ? BM * LDK : BK * LDM;
-  constexpr int B_ELEMS = B_KMAJOR ? BN * LDK : BK * LDM;
-  constexpr int MVECS = 128 / VEC;  // vectors per mn-major row
+  // mn-major LDS row stride: bf16 rows are padded to (16 mod 64) dwords -> conflict-free ds_read_b64_tr_b16
+  constexpr int LDMA = sizeof(T) == 2 ? BM + 32 : BM + VEC;
+  constexpr int LDMB = sizeof(T) == 2 ? BN + 32 : BN + VEC;
+  constexpr int A_ELEMS = A_KMAJOR ? BM * LDK : BK * LDMA;
+  constexpr int B_ELEMS = B_KMAJOR ? BN * LDK : BK * LDMB;
+  constexpr int MVA = BM / VEC, MVB = BN / VEC;          // vectors per mn-major row
+  constexpr int NVA = BM * 8 / NTHREADS, NVB = BN * 8 / NTHREADS;  // 16-byte vectors per thread per K tile
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
   // NOTE: stage addresses are formed as smem + cur * STAGE (never by selecting between two pointers): a pointer select
@@ -114,7 +124,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
   constexpr int STAGE = A_ELEMS + B_ELEMS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / C::WN, wn = wave % C::WN;
 
   // ---- XCD-aware tile id (bijective) ----
   const int ntiles = p.tiles_m * p.tiles_n;
@@ -155,13 +165,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
   // ---- per-thread staging state: 4 x 16-byte vectors of A and of B per K tile.  Rows / mn positions beyond the
   //      matrix are CLAMPED to a valid address (their products only reach accumulator rows/cols that are never stored),
   //      so the steady-state loop is branch-free pointer bumps; only the K tail tile is predicated. ----
-  u32x4 ra[4], rb[4];
-  const T* pa[4];
-  const T* pb[4];
-  int ka[4], kb[4];          // k index this vector covers in tile kt0 (k-major: of its first element; mn-major: its k row)
-  int aq[4], ar[4], bq[4], br[4];  // SEG only: running (segment, offset) of the k index
+  u32x4 ra[NVA], rb[NVB];
+  const T* pa[NVA];
+  const T* pb[NVB];
+  int ka[NVA], kb[NVB];          // k index this vector covers in tile kt0 (k-major: of its first element; mn-major: its k row)
+  int aq[NVA], ar[NVA], bq[NVB], br[NVB];  // SEG only: running (segment, offset) of the k index
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NVA; ++i) {
     const int v = tid + NTHREADS * i;
     if (A_KMAJOR) {
       int64_t row = m0 + (v >> 3);
@@ -170,12 +180,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
       if (SEG && p.a_seg) { aq[i] = ka[i] / (int)p.a_seg; ar[i] = ka[i] % (int)p.a_seg; pa[i] = A + row * p.lda; }
       else { aq[i] = 0; ar[i] = 0; pa[i] = A + row * p.lda + ka[i]; }
     } else {
-      int64_t m = m0 + (int64_t)(v % MVECS) * VEC;
+      int64_t m = m0 + (int64_t)(v % MVA) * VEC;
       m = m < p.M ? m : p.M - VEC;
-      ka[i] = kt0 * BK + v / MVECS;
+      ka[i] = kt0 * BK + v / MVA;
       aq[i] = 0; ar[i] = 0;
       pa[i] = A + (int64_t)ka[i] * p.lda + segaddr(m, p.a_seg, p.a_seg_stride);
     }
+  }
+#pragma unroll
+  for (int i = 0; i < NVB; ++i) {
+    const int v = tid + NTHREADS * i;
     if (B_KMAJOR) {
       int64_t row = n0 + (v >> 3);
       row = row < p.N ? row : p.N - 1;
@@ -183,9 +197,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
       if (SEG && p.b_seg) { bq[i] = kb[i] / (int)p.b_seg; br[i] = kb[i] % (int)p.b_seg; pb[i] = B + row * p.ldb; }
       else { bq[i] = 0; br[i] = 0; pb[i] = B + row * p.ldb + kb[i]; }
     } else {
-      int64_t n = n0 + (int64_t)(v % MVECS) * VEC;
+      int64_t n = n0 + (int64_t)(v % MVB) * VEC;
       n = n < p.N ? n : p.N - VEC;
-      kb[i] = kt0 * BK + v / MVECS;
+      kb[i] = kt0 * BK + v / MVB;
       bq[i] = 0; br[i] = 0;
       pb[i] = B + (int64_t)kb[i] * p.ldb + segaddr(n, p.b_seg, p.b_seg_stride);
     }
@@ -196,27 +210,34 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
   // TAIL = true: the tile may cross K -> vectors at k >= K are replaced by zeros (K % VEC == 0 for k-major operands)
   auto load_tile = [&](auto tail_tag) {
     constexpr bool TAIL = decltype(tail_tag)::value;
+    const u32x4 zero = {0, 0, 0, 0};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NVA; ++i) {
       const T* qa = pa[i];
-      const T* qb = pb[i];
       if (SEG && A_KMAJOR && p.a_seg) qa = pa[i] + (int64_t)aq[i] * p.a_seg_stride + ar[i];
-      if (SEG && B_KMAJOR && p.b_seg) qb = pb[i] + (int64_t)bq[i] * p.b_seg_stride + br[i];
       if (TAIL) {
-        const bool oka = ka[i] < p.K, okb = kb[i] < p.K;
-        u32x4 va = *reinterpret_cast<const u32x4*>(oka ? qa : A);
-        u32x4 vb = *reinterpret_cast<const u32x4*>(okb ? qb : B);
-        const u32x4 zero = {0, 0, 0, 0};
+        const bool oka = ka[i] < p.K;
+        const u32x4 va = *reinterpret_cast<const u32x4*>(oka ? qa : A);
         ra[i] = oka ? va : zero;
-        rb[i] = okb ? vb : zero;
       } else {
         ra[i] = *reinterpret_cast<const u32x4*>(qa);
-        rb[i] = *reinterpret_cast<const u32x4*>(qb);
       }
       ka[i] += BK;
-      kb[i] += BK;
       if (SEG && A_KMAJOR && p.a_seg) { ar[i] += BK; while (ar[i] >= (int)p.a_seg) { ar[i] -= (int)p.a_seg; ++aq[i]; } }
       else pa[i] += step_a;
+    }
+#pragma unroll
+    for (int i = 0; i < NVB; ++i) {
+      const T* qb = pb[i];
+      if (SEG && B_KMAJOR && p.b_seg) qb = pb[i] + (int64_t)bq[i] * p.b_seg_stride + br[i];
+      if (TAIL) {
+        const bool okb = kb[i] < p.K;
+        const u32x4 vb = *reinterpret_cast<const u32x4*>(okb ? qb : B);
+        rb[i] = okb ? vb : zero;
+      } else {
+        rb[i] = *reinterpret_cast<const u32x4*>(qb);
+      }
+      kb[i] += BK;
       if (SEG && B_KMAJOR && p.b_seg) { br[i] += BK; while (br[i] >= (int)p.b_seg) { br[i] -= (int)p.b_seg; ++bq[i]; } }
       else pb[i] += step_b;
     }
@@ -227,20 +248,24 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NVA; ++i) {
       const int v = tid + NTHREADS * i;
-      T* da = smem + buf * STAGE + (A_KMAJOR ? (v >> 3) * LDK + (v & 7) * VEC : (v / MVECS) * LDM + (v % MVECS) * VEC);
-      T* db = smem + buf * STAGE + A_ELEMS + (B_KMAJOR ? (v >> 3) * LDK + (v & 7) * VEC : (v / MVECS) * LDM + (v % MVECS) * VEC);
+      T* da = smem + buf * STAGE + (A_KMAJOR ? (v >> 3) * LDK + (v & 7) * VEC : (v / MVA) * LDMA + (v % MVA) * VEC);
       *reinterpret_cast<u32x4*>(da) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NVB; ++i) {
+      const int v = tid + NTHREADS * i;
+      T* db = smem + buf * STAGE + A_ELEMS + (B_KMAJOR ? (v >> 3) * LDK + (v & 7) * VEC : (v / MVB) * LDMB + (v % MVB) * VEC);
       *reinterpret_cast<u32x4*>(db) = rb[i];
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
@@ -251,6 +276,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
   __syncthreads();
   int cur = 0;
   const int lrow = lane & 31, lk = 8 * (lane >> 5);
+  constexpr int WROWS = TM * 32, WCOLS = TN * 32;
   for (int kt = kt0; kt < kt1; ++kt) {
     const bool more = kt + 1 < kt1;
     if (more) load_any(kt + 1);
@@ -258,59 +284,73 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
     const T* sb = sa + A_ELEMS;
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 16) {
-      Frag<T> fa[2], fb[2];
+      Frag<T> fa[TM], fb[TN];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        if (A_KMAJOR) frag_load_contig(fa[i], sa + (wm * 64 + i * 32 + lrow) * LDK + kk + lk);
-        else frag_load_tr(fa[i], sa, LDM, wm * 64 + i * 32, kk + lk, kk + lk + 4, lane);
-        if (B_KMAJOR) frag_load_contig(fb[i], sb + (wn * 64 + i * 32 + lrow) * LDK + kk + lk);
-        else frag_load_tr(fb[i], sb, LDM, wn * 64 + i * 32, kk + lk, kk + lk + 4, lane);
+      for (int i = 0; i < TM; ++i) {
+        if (A_KMAJOR) frag_load_contig(fa[i], sa + (wm * WROWS + i * 32 + lrow) * LDK + kk + lk);
+        else frag_load_tr(fa[i], sa, LDMA, wm * WROWS + i * 32, kk + lk, kk + lk + 4, lane);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < TN; ++j) {
+        if (B_KMAJOR) frag_load_contig(fb[j], sb + (wn * WCOLS + j * 32 + lrow) * LDK + kk + lk);
+        else frag_load_tr(fb[j], sb, LDMB, wn * WCOLS + j * 32, kk + lk, kk + lk + 4, lane);
+      }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) mma16(acc[i][j], fa[i], fb[j]);
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mma16(acc[i][j], fa[i], fb[j]);
     }
     if (more) store_tile(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }
 
-  // ---- epilogue: accumulators -> LDS (fp32, [128][132]) -> row-contiguous 8-column vectors -> 16-byte global stores ----
+  // ---- epilogue: accumulators -> LDS (fp32, 64 rows x (BN+4) per pass) -> row-contiguous 8-column vectors -> 16-byte
+  //      global stores.  Each pass covers tile rows [64 p, 64 p + 64); a wave contributes the 32-row MFMA tiles inside it.
   constexpr int LDC = BN + 4;
+  constexpr int VPR = BN / 8;                       // 8-column vectors per tile row
+  constexpr int NPASS = BM / 64;
+  constexpr int ITERS = 64 * VPR / NTHREADS;        // vectors per thread per pass
   float* stage = reinterpret_cast<float*>(smem_raw);
-  __syncthreads();  // every wave is done reading the operand tiles
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        stage[(wm * 64 + i * 32 + acc_row(r, lane)) * LDC + wn * 64 + j * 32 + lrow] = acc[i][j][r];
-  __syncthreads();
   float* wsp = p.splits > 1 ? p.ws + ((int64_t)z) * p.M * p.N : nullptr;
   const bool ws_vec = (p.N % 4) == 0;
-#pragma unroll 2
-  for (int it = 0; it < 8; ++it) {
-    const int v = tid + NTHREADS * it;
-    const int rl = v >> 4, cl = (v & 15) * 8;
-    const int64_t row = m0 + rl, col = n0 + cl;
-    if (row >= p.M || col >= p.N) continue;
-    float x[8];
-    {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(stage + rl * LDC + cl);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(stage + rl * LDC + cl + 4);
-      x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    __syncthreads();  // operand tiles (pass 0) / previous pass's staging fully consumed
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int trow = wm * WROWS + i * 32;  // tile-relative first row of this MFMA tile
+      if (trow / 64 == ps) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            stage[(trow - 64 * ps + acc_row(r, lane)) * LDC + wn * WCOLS + j * 32 + lrow] = acc[i][j][r];
+      }
     }
-    const bool full = col + 8 <= p.N;
-    if (wsp) {  // split-K partial slab (raw fp32 sums; epilogue applied by the reduce kernel)
-      if (full && ws_vec) store8(wsp + row * p.N + col, x);
-      else
-        for (int e = 0; e < 8 && col + e < p.N; ++e) wsp[row * p.N + col + e] = x[e];
-    } else if (full && p.vec_epi) {
-      epilogue_store8<T>(p, cofs, bofs, row, col, x);
-    } else {
-      for (int e = 0; e < 8 && col + e < p.N; ++e) epilogue_store<T>(p, cofs, bofs, row, col + e, x[e]);
+    __syncthreads();
+#pragma unroll 2
+    for (int it = 0; it < ITERS; ++it) {
+      const int v = tid + NTHREADS * it;
+      const int rl = v / VPR, cl = (v % VPR) * 8;
+      const int64_t row = m0 + 64 * ps + rl, col = n0 + cl;
+      if (row >= p.M || col >= p.N) continue;
+      float x[8];
+      {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(stage + rl * LDC + cl);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(stage + rl * LDC + cl + 4);
+        x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
+      }
+      const bool full = col + 8 <= p.N;
+      if (wsp) {  // split-K partial slab (raw fp32 sums; epilogue applied by the reduce kernel)
+        if (full && ws_vec) store8(wsp + row * p.N + col, x);
+        else
+          for (int e = 0; e < 8 && col + e < p.N; ++e) wsp[row * p.N + col + e] = x[e];
+      } else if (full && p.vec_epi) {
+        epilogue_store8<T>(p, cofs, bofs, row, col, x);
+      } else {
+        for (int e = 0; e < 8 && col + e < p.N; ++e) epilogue_store<T>(p, cofs, bofs, row, col + e, x[e]);
+      }
     }
   }
 }
@@ -330,31 +370,51 @@ __global__ void splitk_reduce_kernel(GemmParams p) {
   }
 }
 
-template <typename T, bool AK, bool BK_, bool SEG>
-int launch(const GemmParams& p, int64_t nbatch, hipStream_t s) {
+template <typename T, bool AK, bool BK_, bool SEG, typename C>
+int launch(GemmParams p, int64_t M, int64_t N, int64_t nbatch, hipStream_t s) {
   constexpr int VEC = DT<T>::VEC;
-  constexpr int BKc = 8 * VEC, LDK = BKc + VEC, LDM = sizeof(T) == 2 ? 160 : 128 + VEC;
-  constexpr int A_ELEMS = AK ? BM * LDK : BKc * LDM;
-  constexpr int B_ELEMS = BK_ ? BN * LDK : BKc * LDM;
+  constexpr int BKc = 8 * VEC, LDK = BKc + VEC;
+  constexpr int LDMA = sizeof(T) == 2 ? C::BM + 32 : C::BM + VEC, LDMB = sizeof(T) == 2 ? C::BN + 32 : C::BN + VEC;
+  constexpr int A_ELEMS = AK ? C::BM * LDK : BKc * LDMA;
+  constexpr int B_ELEMS = BK_ ? C::BN * LDK : BKc * LDMB;
   size_t lds = 2 * (size_t)(A_ELEMS + B_ELEMS) * sizeof(T);
-  const size_t stage_bytes = (size_t)BM * (BN + 4) * sizeof(float);
+  const size_t stage_bytes = (size_t)64 * (C::BN + 4) * sizeof(float);
   if (lds < stage_bytes) lds = stage_bytes;
   static bool attr_set = false;  // LDS > 64 KiB needs the opt-in attribute (160 KiB/CU on gfx950)
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, AK, BK_, SEG>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, AK, BK_, SEG, C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
+  p.tiles_m = (int)cst_ceil_div(M, C::BM);
+  p.tiles_n = (int)cst_ceil_div(N, C::BN);
   dim3 grid(p.tiles_m * p.tiles_n, 1, (unsigned)(nbatch * p.splits));
-  hipLaunchKernelGGL((gemm_kernel<T, AK, BK_, SEG>), grid, dim3(NTHREADS), lds, s, p);
+  hipLaunchKernelGGL((gemm_kernel<T, AK, BK_, SEG, C>), grid, dim3(C::NT), lds, s, p);
   return cst_check_launch("cst_gemm");
+}
+
+// Large tiles when they still give every CU a workgroup (256 CUs, 1 large block each); else the small configuration.
+bool use_large(const cst_gemm_desc* d, int splits) {
+  if ((d->a_kmajor && d->a_seg) || (d->b_kmajor && d->b_seg)) return false;
+  const int64_t tiles = cst_ceil_div(d->M, 256) * cst_ceil_div(d->N, 256) * d->batch0 * d->batch1 * splits;
+  return d->M >= 256 && d->N >= 256 && tiles >= 200;
 }
 
 int choose_splits(const cst_gemm_desc* d) {
   if (d->split_k > 1) return d->split_k;
   if (d->split_k == 0 || d->split_k == 1) return 1;
-  const int64_t tiles = cst_ceil_div(d->M, BM) * cst_ceil_div(d->N, BN) * d->batch0 * d->batch1;
   const int bk = d->dtype == CST_BF16 ? 64 : 32;
   const int64_t ktiles = cst_ceil_div(d->K, bk);
+  const int64_t nb = d->batch0 * d->batch1;
+  // prefer the large configuration: splits so that ~256-512 large workgroups exist
+  if (d->M >= 256 && d->N >= 256) {
+    const int64_t tl = cst_ceil_div(d->M, 256) * cst_ceil_div(d->N, 256) * nb;
+    if (tl >= 200) return 1;
+    int64_t s = cst_ceil_div(256, tl);
+    if (s > ktiles / 8) s = ktiles / 8;
+    if (s > 32) s = 32;
+    if (s >= 1 && tl * s >= 200) return (int)s;
+  }
+  const int64_t tiles = cst_ceil_div(d->M, 128) * cst_ceil_div(d->N, 128) * nb;
   if (tiles >= 256 || ktiles < 16) return 1;
   int64_t s = cst_ceil_div(512, tiles);
   if (s > ktiles / 8) s = ktiles / 8;
@@ -412,12 +472,11 @@ extern "C" int cst_gemm(const cst_gemm_desc* d, cst_stream stream) {
     if (d->resid) ok = ok && d->ld_resid % 8 == 0;
     p.vec_epi = ok ? 1 : 0;
   }
-  p.tiles_m = (int)cst_ceil_div(d->M, BM);
-  p.tiles_n = (int)cst_ceil_div(d->N, BN);
+  p.tiles_m = p.tiles_n = 0;  // set per configuration in launch()
   p.splits = choose_splits(d);
   p.ws = nullptr;
   const int64_t nbatch = d->batch0 * d->batch1;
-  CST_REQUIRE((int64_t)p.tiles_m * p.tiles_n < (1ll << 31) && nbatch * p.splits < 65536, "cst_gemm: grid too large");
+  CST_REQUIRE(cst_ceil_div(d->M, 128) * cst_ceil_div(d->N, 128) < (1ll << 31) && nbatch * p.splits < 65536, "cst_gemm: grid too large");
   if (p.splits > 1) {
     const int64_t need = (int64_t)p.splits * d->M * d->N * nbatch * (int64_t)sizeof(float);
     if (!d->workspace || d->workspace_bytes < need) {
@@ -434,17 +493,18 @@ extern "C" int cst_gemm(const cst_gemm_desc* d, cst_stream stream) {
   CstProfScope prof(CST_K_GEMM, s, flops, bytes);
   int rc;
   const bool ak = d->a_kmajor != 0, bk = d->b_kmajor != 0;
-  // SEG instantiation only where a k-major operand is segmented (the grouped pos-conv); mn-major segments are folded
-  // into the per-thread base pointer and cost nothing per tile.
+  // SEG instantiation only where a k-major operand is segmented (grouped conv with channel-major input); mn-major
+  // segments are folded into the per-thread base pointer and cost nothing per tile.
   const bool seg = (ak && d->a_seg) || (bk && d->b_seg);
-#define CST_GEMM_DISPATCH(T)                                                                                   \
-  (seg ? (ak ? (bk ? launch<T, true, true, true>(p, nbatch, s) : launch<T, true, false, true>(p, nbatch, s))   \
-             : launch<T, false, true, true>(p, nbatch, s))                                                     \
-       : (ak ? (bk ? launch<T, true, true, false>(p, nbatch, s) : launch<T, true, false, false>(p, nbatch, s)) \
-             : (bk ? launch<T, false, true, false>(p, nbatch, s) : launch<T, false, false, false>(p, nbatch, s))))
+  const bool large = use_large(d, p.splits);
+#define CST_GEMM_LAYOUT(T, SEGV, CFG)                                                                                   \
+  (ak ? (bk ? launch<T, true, true, SEGV, CFG>(p, d->M, d->N, nbatch, s) : launch<T, true, false, SEGV, CFG>(p, d->M, d->N, nbatch, s)) \
+      : (bk ? launch<T, false, true, SEGV, CFG>(p, d->M, d->N, nbatch, s) : launch<T, false, false, SEGV, CFG>(p, d->M, d->N, nbatch, s)))
+#define CST_GEMM_DISPATCH(T) (seg ? CST_GEMM_LAYOUT(T, true, CfgSmall) : (large ? CST_GEMM_LAYOUT(T, false, CfgLarge) : CST_GEMM_LAYOUT(T, false, CfgSmall)))
   if (d->dtype == CST_BF16) rc = CST_GEMM_DISPATCH(bf16_t);
   else rc = CST_GEMM_DISPATCH(float);
 #undef CST_GEMM_DISPATCH
+#undef CST_GEMM_LAYOUT
   if (rc != CST_OK) return rc;
   if (p.splits > 1) {
     const int64_t total = d->M * d->N;
