@@ -125,7 +125,7 @@ def main():
     dist_mod = importlib.import_module("chimera-st_amd.distributed")
     rank, world = dist_mod.distributed_init()
     assert world == args.gpus or (world == 1 and args.gpus == 1), "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     lib = importlib.import_module("chimera-st_amd.lib")

@@ -79,8 +79,11 @@ __global__ __launch_bounds__(256) void ls_ce_bwd_kernel(const T* logits, const i
   }
 }
 
+// deterministic two-stage sum of squares: per-block partials in a fixed layout, then ONE block adds them in a fixed order
+// (replicas of a data-parallel job must compute bit-identical gradient norms, or their clip coefficients — and then their
+// parameters — drift apart by ulps every step).
 template <typename T>
-__global__ void sumsq_kernel(const T* x, int64_t n, float* out) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const T* x, int64_t n, float* part) {
   __shared__ float red[4];
   float acc = 0.0f;
   const int64_t n8 = n / 8;
@@ -93,7 +96,14 @@ __global__ void sumsq_kernel(const T* x, int64_t n, float* out) {
   if (blockIdx.x == 0)
     for (int64_t i = n8 * 8 + threadIdx.x; i < n; i += blockDim.x) { const float f = DT<T>::ld(x + i); acc += f * f; }
   acc = block_sum(acc, red);
-  if (threadIdx.x == 0) atomicAdd(out, acc);
+  if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* part, int nparts, float* out) {
+  __shared__ float red[4];
+  float acc = 0.0f;
+  for (int i = threadIdx.x; i < nparts; i += 256) acc += part[i];
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) out[0] += acc;
 }
 
 template <typename TG, typename TP>
@@ -138,15 +148,18 @@ extern "C" int cst_ls_ce_bwd(const void* logits, const int64_t* target, const fl
   return cst_check_launch("cst_ls_ce_bwd");
 }
 
-extern "C" int cst_sumsq(const void* x, int64_t n, float* out, int dtype, cst_stream stream) {
-  CST_REQUIRE(x && out && n > 0, "cst_sumsq: bad args");
+extern "C" int64_t cst_sumsq_workspace(void) { return 2048 * (int64_t)sizeof(float); }
+
+extern "C" int cst_sumsq(const void* x, int64_t n, float* out, float* workspace, int dtype, cst_stream stream) {
+  CST_REQUIRE(x && out && workspace && n > 0, "cst_sumsq: bad args");
   CST_REQUIRE(dtype == CST_F32 || dtype == CST_BF16, "cst_sumsq: bad dtype");
   CST_REQUIRE((uintptr_t)x % 16 == 0, "cst_sumsq: x must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   CstProfScope prof(CST_K_OPTIM, s, 0.0, (double)n * cst_dtype_size(dtype));
   int blocks = (int)(cst_ceil_div(n, 256 * 8) < 2048 ? cst_ceil_div(n, 256 * 8) : 2048);
-  if (dtype == CST_BF16) hipLaunchKernelGGL(sumsq_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, n, out);
-  else hipLaunchKernelGGL(sumsq_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, n, out);
+  if (dtype == CST_BF16) hipLaunchKernelGGL(sumsq_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, n, workspace);
+  else hipLaunchKernelGGL(sumsq_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, n, workspace);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, (const float*)workspace, blocks, out);
   return cst_check_launch("cst_sumsq");
 }
 

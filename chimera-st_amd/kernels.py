@@ -281,7 +281,9 @@ def ls_ce_bwd(logits, target, lse, gscale, eps, pad):
 
 
 def sumsq(x, out):
-    L.check(L.load().cst_sumsq(L.ptr(x), x.numel(), L.ptr(out), L.dtype_code(x.dtype), L.stream_ptr()), "cst_sumsq")
+    lib = L.load()
+    ws = workspace(lib.cst_sumsq_workspace(), x.device)
+    L.check(lib.cst_sumsq(L.ptr(x), x.numel(), L.ptr(out), L.ptr(ws), L.dtype_code(x.dtype), L.stream_ptr()), "cst_sumsq")
 
 
 def adam_step(master, m, v, grad, param, lr, beta1, beta2, eps, wd, step, grad_scale):

@@ -216,8 +216,10 @@ int cst_ls_ce_bwd(const void* logits, const int64_t* target, const float* lse, c
  * Optimizer path — replaces FP16Optimizer's flat-copy / unscale / clip / Adam / copy-back chain
  * (optim/fp16_optimizer.py:16-300; utils.py:323-364; optim/adam.py:146-226).
  * ------------------------------------------------------------------------------------------ */
-/* out[0] += sum(x^2) (fp32 atomics; caller zeroes) */
-int cst_sumsq(const void* x, int64_t n, float* out, int dtype, cst_stream stream);
+/* out[0] += sum(x^2).  Deterministic (fixed-order two-stage reduction, no atomics): data-parallel replicas must get
+ * bit-identical gradient norms.  workspace: cst_sumsq_workspace() bytes. */
+int64_t cst_sumsq_workspace(void);
+int cst_sumsq(const void* x, int64_t n, float* out, float* workspace, int dtype, cst_stream stream);
 /* One fused pass over flat buffers: g = grad * (*grad_scale); Adam (fairseq semantics: bias
  * correction folded into the step size, decoupled weight decay); master fp32 -> model dtype.
  * grad_scale is a DEVICE fp32 scalar (e.g. clip coefficient / sample_size) so no host sync. */
