@@ -187,6 +187,39 @@ __device__ __forceinline__ void frag_load_tr(Frag<float>& f, const float* tile, 
     f.v[4 + j] = p[(kb + j) * ld];
   }
 }
+// ---- fragment loads from the UNPADDED, swizzled LDS images that global_load_lds produces (gemm_glds_kernel) ----
+// k-major image: rows of 128 bytes, 16-byte chunk c of row r stored at chunk c ^ ((r >> 1) & 7); k = element index in the row
+__device__ __forceinline__ void frag_load_kswz(Frag<bf16_t>& f, const bf16_t* tile, int r, int k) {
+  const int c = (k >> 3) ^ ((r >> 1) & 7);
+  f.v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(tile) + r * 128 + c * 16);
+}
+__device__ __forceinline__ void frag_load_kswz(Frag<float>& f, const float* tile, int r, int k) {
+  const int sw = (r >> 1) & 7, c0 = (k >> 2) ^ sw, c1 = ((k >> 2) + 1) ^ sw;
+  const char* row = reinterpret_cast<const char*>(tile) + r * 128;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(row + c0 * 16);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(row + c1 * 16);
+  f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+  f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+}
+// mn-major image [k][W]: bf16 rows swizzled chunk ^= 4*(k&3) (pairs of 16-B chunks stay adjacent for the transpose read);
+// lane l receives image[k0 + {0..3, 4..7}][mn0 + (l&31)], k0 already includes the half-wave offset.
+__device__ __forceinline__ void frag_load_tr_swz(Frag<bf16_t>& f, const bf16_t* tile, int W, int mn0, int k0, int lane) {
+  const int s = lane & 15;
+  const int col = mn0 + 16 * ((lane >> 4) & 1) + 4 * (s & 3);  // element column this lane's 8-byte source chunk starts at
+  const int ka = k0 + (s >> 2), kb = ka + 4;
+  const int ca = ((col >> 3) ^ (4 * (ka & 3))) * 8 + (col & 7), cb = ((col >> 3) ^ (4 * (kb & 3))) * 8 + (col & 7);
+  const v4s_t x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_t __attribute__((address_space(3)))*)(tile + ka * W + ca));
+  const v4s_t y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_t __attribute__((address_space(3)))*)(tile + kb * W + cb));
+  u16x8 t;
+  t[0] = (unsigned short)x[0]; t[1] = (unsigned short)x[1]; t[2] = (unsigned short)x[2]; t[3] = (unsigned short)x[3];
+  t[4] = (unsigned short)y[0]; t[5] = (unsigned short)y[1]; t[6] = (unsigned short)y[2]; t[7] = (unsigned short)y[3];
+  f.v = __builtin_bit_cast(bf16x8, t);
+}
+__device__ __forceinline__ void frag_load_tr_swz(Frag<float>& f, const float* tile, int W, int mn0, int k0, int lane) {
+  const float* p = tile + mn0 + (lane & 31);  // f32 rows are not swizzled: 32 consecutive lanes -> 32 consecutive banks
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = p[(k0 + j) * W];
+}
 // fragment from 8 fp32 register values (e.g. softmax probabilities)
 __device__ __forceinline__ void frag_from_f32(Frag<bf16_t>& f, const float (&x)[8]) {
 #pragma unroll

@@ -15,6 +15,7 @@
 // Workgroup -> tile map is XCD-aware (bijective remap so each XCD's L2 sees a contiguous
 // band of tiles sharing A rows).
 #include "cst_common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -25,6 +26,7 @@ struct Cfg {
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NT = 64 * WM_ * WN_, TM = BM_ / WM_ / 32, TN = BN_ / WN_ / 32;
 };
 using CfgSmall = Cfg<128, 128, 2, 2>;   // 4 waves, 2 blocks/CU: small / skinny problems, grouped conv
+using CfgMid = Cfg<256, 128, 4, 2>;     // 8 waves (wave tile 64 x 64): 48 KiB per stage -> 3-deep global_load_lds ring
 using CfgLarge = Cfg<256, 256, 2, 4>;   // 8 waves (wave tile 128 x 64), 1 block/CU: half the L2->LDS bytes per FLOP
 
 struct GemmParams {
@@ -355,6 +357,252 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmParams p) {
   }
 }
 
+// =====================================================================================================================
+// gemm_glds_kernel — same contract as gemm_kernel, operand tiles fetched with global_load_lds (16 B per lane straight into
+// LDS: no staging VGPRs, no ds_write pass), NS-stage ring with counted vmcnt, one raw s_barrier per K tile.
+// LDS images are UNPADDED (the DMA writes wave-uniform-base + lane*16) and XOR-swizzled through the per-lane SOURCE
+// address; fragment reads apply the same permutation (cdna guide rule 21):
+//   k-major tile  [rows][128 B]:  16-B chunk c of row r lives at chunk  c ^ ((r >> 1) & 7)   -> ds_read_b128 conflict-free
+//   mn-major tile [BK][W elems] (bf16): chunk c of k-row k lives at     c ^ (4 * (k & 3))     -> ds_read_b64_tr_b16 conflict-free
+// Used for every non-segmented problem; the K tail tile (K % BK != 0) is staged synchronously with zero fill.
+// =====================================================================================================================
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, bool A_KMAJOR, bool B_KMAJOR, typename C, int NS>
+__global__ __launch_bounds__(C::NT) void gemm_glds_kernel(GemmParams p) {
+  constexpr int BM = C::BM, BN = C::BN, NTHREADS = C::NT, TM = C::TM, TN = C::TN, NWAVES = C::NT / 64;
+  constexpr int ES = sizeof(T), VEC = DT<T>::VEC, BK = 128 / ES;
+  constexpr int A_BYTES = A_KMAJOR ? BM * 128 : BK * BM * ES;
+  constexpr int B_BYTES = B_KMAJOR ? BN * 128 : BK * BN * ES;
+  constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int GA = A_BYTES / 1024 / NWAVES, GB = B_BYTES / 1024 / NWAVES;  // 1-KiB DMA groups per wave per tile
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / C::WN, wn = wave % C::WN;
+  const int ntiles = p.tiles_m * p.tiles_n;
+  int id = blockIdx.x;
+  {
+    const int q = ntiles / 8, r = ntiles % 8, xcd = id % 8, loc = id / 8;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  constexpr int GROUP_M = 8;
+  int tm, tn;
+  {
+    const int per_group = GROUP_M * p.tiles_n;
+    const int grp = id / per_group, rem = id % per_group;
+    const int gm0 = grp * GROUP_M;
+    const int gsz = (p.tiles_m - gm0 < GROUP_M) ? (p.tiles_m - gm0) : GROUP_M;
+    tm = gm0 + rem % gsz;
+    tn = rem / gsz;
+  }
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const int z = blockIdx.z;
+  const int split = z % p.splits;
+  const int64_t bidx = z / p.splits;
+  const int64_t b0 = bidx / p.batch1, b1 = bidx % p.batch1;
+  const T* A = (const T*)p.A + b0 * p.sa0 + b1 * p.sa1;
+  const T* B = (const T*)p.B + b0 * p.sb0 + b1 * p.sb1;
+  const int64_t cofs = b0 * p.sc0 + b1 * p.sc1;
+  const int64_t bofs = b0 * p.sbias0 + b1 * p.sbias1;
+  const int ktiles = (int)((p.K + BK - 1) / BK);
+  const int kfull = (int)(p.K / BK);
+  const int per = (ktiles + p.splits - 1) / p.splits;
+  const int kt0 = split * per;
+  const int kt1 = (kt0 + per < ktiles) ? kt0 + per : ktiles;
+  const int nt = kt1 - kt0;
+
+  // ---- per-lane DMA sources.  Group g of an operand tile = LDS bytes [g*1024, g*1024 + 1024); this wave owns groups
+  //      wave + NWAVES*i.  Lane l fills bytes [l*16, l*16+16) of the group: which (row, chunk) that is, and therefore which
+  //      global address feeds it, follows from the swizzle. ----
+  const T* pa[GA];
+  const T* pb[GB];
+  int ka[GA], kb[GB];  // k index covered (k-major: first element of the chunk; mn-major: the k row), for the tail predicate
+#pragma unroll
+  for (int i = 0; i < GA; ++i) {
+    const int g = wave + NWAVES * i;
+    if (A_KMAJOR) {
+      const int r = 8 * g + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+      int64_t row = m0 + r;
+      row = row < p.M ? row : p.M - 1;
+      ka[i] = kt0 * BK + c * VEC;
+      pa[i] = A + row * p.lda + ka[i];
+    } else {
+      constexpr int RB = BM * ES, RPG = 1024 / RB > 0 ? 1024 / RB : 1, CPR = RB / 16;
+      const int kl = g * RPG + (lane * 16) / RB, pc = ((lane * 16) % RB) / 16;
+      const int c = ES == 2 ? (pc ^ (4 * (kl & 3))) : pc;
+      int64_t m = m0 + (int64_t)c * VEC;
+      m = m < p.M ? m : p.M - VEC;
+      ka[i] = kt0 * BK + kl;
+      pa[i] = A + (int64_t)ka[i] * p.lda + segaddr(m, p.a_seg, p.a_seg_stride);
+      (void)CPR;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < GB; ++i) {
+    const int g = wave + NWAVES * i;
+    if (B_KMAJOR) {
+      const int r = 8 * g + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+      int64_t row = n0 + r;
+      row = row < p.N ? row : p.N - 1;
+      kb[i] = kt0 * BK + c * VEC;
+      pb[i] = B + row * p.ldb + kb[i];
+    } else {
+      constexpr int RB = BN * ES, RPG = 1024 / RB > 0 ? 1024 / RB : 1;
+      const int kl = g * RPG + (lane * 16) / RB, pc = ((lane * 16) % RB) / 16;
+      const int c = ES == 2 ? (pc ^ (4 * (kl & 3))) : pc;
+      int64_t n = n0 + (int64_t)c * VEC;
+      n = n < p.N ? n : p.N - VEC;
+      kb[i] = kt0 * BK + kl;
+      pb[i] = B + (int64_t)kb[i] * p.ldb + segaddr(n, p.b_seg, p.b_seg_stride);
+    }
+  }
+  const int64_t step_a = A_KMAJOR ? (int64_t)BK : (int64_t)BK * p.lda;
+  const int64_t step_b = B_KMAJOR ? (int64_t)BK : (int64_t)BK * p.ldb;
+
+  auto issue = [&](int kt, int stage) {
+    char* sbase = smem_raw + stage * STAGE_BYTES;
+    if (kt < kfull) {
+#pragma unroll
+      for (int i = 0; i < GA; ++i) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa[i],
+                                         (__attribute__((address_space(3))) void*)(sbase + (wave + NWAVES * i) * 1024), 16, 0, 0);
+        pa[i] += step_a;
+        ka[i] += BK;
+      }
+#pragma unroll
+      for (int i = 0; i < GB; ++i) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pb[i],
+                                         (__attribute__((address_space(3))) void*)(sbase + A_BYTES + (wave + NWAVES * i) * 1024), 16, 0, 0);
+        pb[i] += step_b;
+        kb[i] += BK;
+      }
+    } else {  // K tail: synchronous, zero-filled (runs at most once per workgroup)
+      const u32x4 zero = {0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < GA; ++i) {
+        const bool ok = ka[i] < p.K;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(ok ? pa[i] : A);
+        *reinterpret_cast<u32x4*>(sbase + (wave + NWAVES * i) * 1024 + lane * 16) = ok ? v : zero;
+        pa[i] += step_a;
+        ka[i] += BK;
+      }
+#pragma unroll
+      for (int i = 0; i < GB; ++i) {
+        const bool ok = kb[i] < p.K;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(ok ? pb[i] : B);
+        *reinterpret_cast<u32x4*>(sbase + A_BYTES + (wave + NWAVES * i) * 1024 + lane * 16) = ok ? v : zero;
+        pb[i] += step_b;
+        kb[i] += BK;
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int lrow = lane & 31, hi = lane >> 5;
+  constexpr int WROWS = TM * 32, WCOLS = TN * 32;
+  constexpr int G = GA + GB;  // DMA instructions per thread per tile
+
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nt) issue(kt0 + s, s);
+
+  for (int it = 0; it < nt; ++it) {
+    // tile `it` must have landed; up to NS-2 later tiles may stay in flight (steady state), fewer near the end
+    const int issued = (it + NS - 1 < nt) ? it + NS - 1 : nt;
+    if (NS > 2 && issued - it - 1 == NS - 2) wait_vmcnt<(NS - 2) * G>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // raw barrier: every wave's part of tile `it` is in LDS, and nobody still reads the stage
+                                   // that the next issue overwrites
+    if (it + NS - 1 < nt) issue(kt0 + it + NS - 1, (it + NS - 1) % NS);
+    const char* sbase = smem_raw + (it % NS) * STAGE_BYTES;
+    const T* sa = reinterpret_cast<const T*>(sbase);
+    const T* sb = reinterpret_cast<const T*>(sbase + A_BYTES);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 16) {
+      Frag<T> fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (A_KMAJOR) {
+          const int r = wm * WROWS + i * 32 + lrow;
+          frag_load_kswz(fa[i], sa, r, kk + 8 * hi);
+        } else {
+          frag_load_tr_swz(fa[i], sa, BM, wm * WROWS + i * 32, kk + 8 * hi, lane);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (B_KMAJOR) {
+          const int r = wn * WCOLS + j * 32 + lrow;
+          frag_load_kswz(fb[j], sb, r, kk + 8 * hi);
+        } else {
+          frag_load_tr_swz(fb[j], sb, BN, wn * WCOLS + j * 32, kk + 8 * hi, lane);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mma16(acc[i][j], fa[i], fb[j]);
+    }
+  }
+
+  // ---- epilogue (identical to gemm_kernel) ----
+  constexpr int LDC = BN + 4;
+  constexpr int VPR = BN / 8;
+  constexpr int NPASS = BM / 64;
+  constexpr int ITERS = 64 * VPR / NTHREADS;
+  float* stage = reinterpret_cast<float*>(smem_raw);
+  float* wsp = p.splits > 1 ? p.ws + ((int64_t)z) * p.M * p.N : nullptr;
+  const bool ws_vec = (p.N % 4) == 0;
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int trow = wm * WROWS + i * 32;
+      if (trow / 64 == ps) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            stage[(trow - 64 * ps + acc_row(r, lane)) * LDC + wn * WCOLS + j * 32 + lrow] = acc[i][j][r];
+      }
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int itv = 0; itv < ITERS; ++itv) {
+      const int v = tid + NTHREADS * itv;
+      const int rl = v / VPR, cl = (v % VPR) * 8;
+      const int64_t row = m0 + 64 * ps + rl, col = n0 + cl;
+      if (row >= p.M || col >= p.N) continue;
+      float x[8];
+      {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(stage + rl * LDC + cl);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(stage + rl * LDC + cl + 4);
+        x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
+      }
+      const bool full = col + 8 <= p.N;
+      if (wsp) {
+        if (full && ws_vec) store8(wsp + row * p.N + col, x);
+        else
+          for (int e = 0; e < 8 && col + e < p.N; ++e) wsp[row * p.N + col + e] = x[e];
+      } else if (full && p.vec_epi) {
+        epilogue_store8<T>(p, cofs, bofs, row, col, x);
+      } else {
+        for (int e = 0; e < 8 && col + e < p.N; ++e) epilogue_store<T>(p, cofs, bofs, row, col + e, x[e]);
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ void splitk_reduce_kernel(GemmParams p) {
   const int64_t total = p.M * p.N;
@@ -392,11 +640,35 @@ int launch(GemmParams p, int64_t M, int64_t N, int64_t nbatch, hipStream_t s) {
   return cst_check_launch("cst_gemm");
 }
 
+template <typename T, bool AK, bool BK_, typename C, int NS>
+int launch_glds(GemmParams p, int64_t M, int64_t N, int64_t nbatch, hipStream_t s) {
+  constexpr int ES = sizeof(T), BKc = 128 / ES;
+  constexpr int A_BYTES = AK ? C::BM * 128 : BKc * C::BM * ES, B_BYTES = BK_ ? C::BN * 128 : BKc * C::BN * ES;
+  size_t lds = (size_t)NS * (A_BYTES + B_BYTES);
+  const size_t stage_bytes = (size_t)64 * (C::BN + 4) * sizeof(float);
+  if (lds < stage_bytes) lds = stage_bytes;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<T, AK, BK_, C, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  p.tiles_m = (int)cst_ceil_div(M, C::BM);
+  p.tiles_n = (int)cst_ceil_div(N, C::BN);
+  dim3 grid(p.tiles_m * p.tiles_n, 1, (unsigned)(nbatch * p.splits));
+  hipLaunchKernelGGL((gemm_glds_kernel<T, AK, BK_, C, NS>), grid, dim3(C::NT), lds, s, p);
+  return cst_check_launch("cst_gemm");
+}
+
 // Large tiles when they still give every CU a workgroup (256 CUs, 1 large block each); else the small configuration.
 bool use_large(const cst_gemm_desc* d, int splits) {
   if ((d->a_kmajor && d->a_seg) || (d->b_kmajor && d->b_seg)) return false;
   const int64_t tiles = cst_ceil_div(d->M, 256) * cst_ceil_div(d->N, 256) * d->batch0 * d->batch1 * splits;
   return d->M >= 256 && d->N >= 256 && tiles >= 200;
+}
+
+bool getenv_no_glds() {
+  static const bool v = getenv("CST_GEMM_NO_GLDS") != nullptr;
+  return v;
 }
 
 int choose_splits(const cst_gemm_desc* d) {
@@ -500,11 +772,22 @@ extern "C" int cst_gemm(const cst_gemm_desc* d, cst_stream stream) {
 #define CST_GEMM_LAYOUT(T, SEGV, CFG)                                                                                   \
   (ak ? (bk ? launch<T, true, true, SEGV, CFG>(p, d->M, d->N, nbatch, s) : launch<T, true, false, SEGV, CFG>(p, d->M, d->N, nbatch, s)) \
       : (bk ? launch<T, false, true, SEGV, CFG>(p, d->M, d->N, nbatch, s) : launch<T, false, false, SEGV, CFG>(p, d->M, d->N, nbatch, s)))
-#define CST_GEMM_DISPATCH(T) (seg ? CST_GEMM_LAYOUT(T, true, CfgSmall) : (large ? CST_GEMM_LAYOUT(T, false, CfgLarge) : CST_GEMM_LAYOUT(T, false, CfgSmall)))
+#define CST_GLDS_LAYOUT(T, CFG, NS)                                                                                     \
+  (ak ? (bk ? launch_glds<T, true, true, CFG, NS>(p, d->M, d->N, nbatch, s) : launch_glds<T, true, false, CFG, NS>(p, d->M, d->N, nbatch, s)) \
+      : (bk ? launch_glds<T, false, true, CFG, NS>(p, d->M, d->N, nbatch, s) : launch_glds<T, false, false, CFG, NS>(p, d->M, d->N, nbatch, s)))
+  // measured on MI355X (tools/bench_kernels.py): the DMA path wins when both operands are k-major (716 vs 661 TF/s, fc1
+  // forward); with an mn-major operand the register-staged path + padded LDS rows is faster (690 vs 649, 562 vs 486).
+  const bool no_glds = getenv_no_glds() || !(ak && bk);
+  static const bool mid3 = getenv("CST_GEMM_MID3") != nullptr;  // A/B switch for benchmarking the two staging paths
+#define CST_GEMM_DISPATCH(T)                                                                         \
+  (seg ? CST_GEMM_LAYOUT(T, true, CfgSmall)                                                           \
+       : (no_glds ? (large ? CST_GEMM_LAYOUT(T, false, CfgLarge) : CST_GEMM_LAYOUT(T, false, CfgSmall)) \
+                  : (large ? (mid3 ? CST_GLDS_LAYOUT(T, CfgMid, 3) : CST_GLDS_LAYOUT(T, CfgLarge, 2)) : CST_GLDS_LAYOUT(T, CfgSmall, 2))))
   if (d->dtype == CST_BF16) rc = CST_GEMM_DISPATCH(bf16_t);
   else rc = CST_GEMM_DISPATCH(float);
 #undef CST_GEMM_DISPATCH
 #undef CST_GEMM_LAYOUT
+#undef CST_GLDS_LAYOUT
   if (rc != CST_OK) return rc;
   if (p.splits > 1) {
     const int64_t total = d->M * d->N;
