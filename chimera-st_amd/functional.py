@@ -85,6 +85,59 @@ def linear(x, weight, bias=None, act=None, resid=None):
     return _LinearFn.apply(x, weight, bias, resid, _ACT[act])
 
 
+class _FFNFn(torch.autograd.Function):
+    """y = W2 act(W1 x + b1) + b2 (+ resid): two GEMMs forward; in backward the activation derivative is the epilogue of
+    the dH GEMM (dz1 = (dy W2) * act'(z1)), so no separate act-backward pass over the [tokens, ffn] tensor."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, resid, act):
+        x2 = _flat2d(x)
+        M, d = x2.shape
+        F_ = w1.shape[0]
+        dout = w2.shape[0]
+        z1 = torch.empty(M, F_, dtype=x.dtype, device=x.device)
+        h = torch.empty_like(z1)
+        K.gemm(x2, w1, h, M, F_, d, a_kmajor=1, b_kmajor=1, lda=d, ldb=d, ldc=F_, bias=b1, act=act, aux_out=z1, ld_aux_out=F_, split_k=1)
+        y = torch.empty(M, dout, dtype=x.dtype, device=x.device)
+        r2 = _flat2d(resid) if resid is not None else None
+        K.gemm(h, w2, y, M, dout, F_, a_kmajor=1, b_kmajor=1, lda=F_, ldb=F_, ldc=dout, bias=b2, resid=r2, ld_resid=dout, split_k=1)
+        ctx.save_for_backward(x2, w1, w2, z1, h)
+        ctx.cfg = (act, b1 is not None, b2 is not None, resid is not None, x.shape)
+        return y.view(*x.shape[:-1], dout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1, w2, z1, h = ctx.saved_tensors
+        act, has_b1, has_b2, has_res, xshape = ctx.cfg
+        M, d = x2.shape
+        F_, dout = w1.shape[0], w2.shape[0]
+        dy2 = _flat2d(dy)
+        dz1 = torch.empty(M, F_, dtype=dy2.dtype, device=dy2.device)
+        K.gemm(dy2, w2, dz1, M, F_, dout, a_kmajor=1, b_kmajor=0, lda=dout, ldb=F_, ldc=F_, dact=act, aux_in=z1, ld_aux_in=F_, split_k=1)
+        dx = dw1 = db1 = dw2 = db2 = None
+        if ctx.needs_input_grad[3]:
+            dw2 = torch.empty(dout, F_, dtype=w2.dtype, device=w2.device)
+            K.gemm(dy2, h, dw2, dout, F_, M, a_kmajor=0, b_kmajor=0, lda=dout, ldb=F_, ldc=F_, split_k=-1)
+        if has_b2 and ctx.needs_input_grad[4]:
+            db2 = K.colsum(dy2).to(w2.dtype)
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, d, dtype=x2.dtype, device=x2.device)
+            K.gemm(dz1, w1, dx, M, d, F_, a_kmajor=1, b_kmajor=0, lda=F_, ldb=d, ldc=d, split_k=1)
+            dx = dx.view(xshape)
+        if ctx.needs_input_grad[1]:
+            dw1 = torch.empty(F_, d, dtype=w1.dtype, device=w1.device)
+            K.gemm(dz1, x2, dw1, F_, d, M, a_kmajor=0, b_kmajor=0, lda=F_, ldb=d, ldc=d, split_k=-1)
+        if has_b1 and ctx.needs_input_grad[2]:
+            db1 = K.colsum(dz1).to(w1.dtype)
+        return dx, dw1, db1, dw2, db2, (dy if has_res and ctx.needs_input_grad[5] else None), None
+
+
+def ffn(x, w1, b1, w2, b2, act, resid=None):
+    """Position-wise feed-forward block with fused epilogues (fc1: bias+activation, fc2: bias+residual)."""
+    assert _ACT[act] != L.ACT_NONE
+    return _FFNFn.apply(x, w1.contiguous(), b1, w2.contiguous(), b2, resid, _ACT[act])
+
+
 # ------------------------------------------------------------------------------------------------
 # LayerNorm with fused residual add
 # ------------------------------------------------------------------------------------------------

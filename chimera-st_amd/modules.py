@@ -428,10 +428,11 @@ class TransformerEncoderLayer(nn.Module):
             h, residual = self.final_layer_norm.forward_residual(x)
         else:
             h = x
-        h = self.fc1(to_batch_major(h), act=self.activation_fn)
         if fused:
-            x = to_time_major_view(self.fc2(h, resid=to_batch_major(residual)))
+            x = to_time_major_view(CF.ffn(to_batch_major(h), self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
+                                          self.activation_fn, resid=to_batch_major(residual)))
         else:
+            h = self.fc1(to_batch_major(h), act=self.activation_fn)
             x = residual + self.dropout_module(to_time_major_view(self.fc2(self.activation_dropout_module(h))))
         if not self.normalize_before:
             x = self.final_layer_norm(x)
@@ -523,10 +524,11 @@ class TransformerDecoderLayer(nn.Module):
             h, residual = self.final_layer_norm.forward_residual(x)
         else:
             h = x
-        h = self.fc1(to_batch_major(h), act=self.activation_fn)
         if fused:
-            x = to_time_major_view(self.fc2(h, resid=to_batch_major(residual)))
+            x = to_time_major_view(CF.ffn(to_batch_major(h), self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
+                                          self.activation_fn, resid=to_batch_major(residual)))
         else:
+            h = self.fc1(to_batch_major(h), act=self.activation_fn)
             x = residual + self.dropout_module(to_time_major_view(self.fc2(self.activation_dropout_module(h))))
         if not self.normalize_before:
             x = self.final_layer_norm(x)

@@ -93,8 +93,8 @@ class TransformerSentenceEncoderLayer(nn.Module):
                               resid=residual)  # x = residual + attn (out_proj epilogue)
         x = self.self_attn_layer_norm(x)
         residual = x
-        h = self.fc1(to_batch_major(x), act=self.activation_fn)
-        x = to_time_major_view(self.fc2(h, resid=to_batch_major(residual)))
+        x = to_time_major_view(CF.ffn(to_batch_major(x), self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
+                                      self.activation_fn, resid=to_batch_major(residual)))
         x = self.final_layer_norm(x)
         return x, None
 
