@@ -21,13 +21,16 @@
 namespace {
 
 // tile configurations: Cfg<BM, BN, WM, WN>: WM x WN waves, each (BM/WM) x (BN/WN) = (TM*32) x (TN*32)
-template <int BM_, int BN_, int WM_, int WN_>
+template <int BM_, int BN_, int WM_, int WN_, int KV_ = 8>
 struct Cfg {
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NT = 64 * WM_ * WN_, TM = BM_ / WM_ / 32, TN = BN_ / WN_ / 32;
+  static constexpr int KV = KV_;  // 16-byte vectors per k-major tile row: BK = KV * VEC (64 or 32 bf16)
 };
 using CfgSmall = Cfg<128, 128, 2, 2>;   // 4 waves, 2 blocks/CU: small / skinny problems, grouped conv
-using CfgMid = Cfg<256, 128, 4, 2>;     // 8 waves (wave tile 64 x 64): 48 KiB per stage -> 3-deep global_load_lds ring
-using CfgLarge = Cfg<256, 256, 2, 4>;   // 8 waves (wave tile 128 x 64), 1 block/CU: half the L2->LDS bytes per FLOP
+// 16 waves (wave tile 64 x 64), 1 block/CU, 4 waves/SIMD: half the L2->LDS bytes per FLOP of CfgSmall.  Measured
+// alternatives on MI355X at M=48k, K/N in {768, 3072} (tools/bench_kernels.py): 8 waves x (128 x 64) 660-690 TF/s (VGPR-capped,
+// 2 waves/SIMD); 256 x 128 x 64 8 waves with a 3-stage DMA ring 590; 256 x 128 x 32 4 waves 2 blocks/CU 590-660; this one 670-760.
+using CfgLarge = Cfg<256, 256, 4, 4>;   // 8 waves (wave tile 128 x 64), 1 block/CU: half the L2->LDS bytes per FLOP
 
 struct GemmParams {
   int64_t M, N, K;
@@ -110,7 +113,7 @@ template <typename T, bool A_KMAJOR, bool B_KMAJOR, bool SEG, typename C>
 __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmParams p) {
   constexpr int BM = C::BM, BN = C::BN, NTHREADS = C::NT, TM = C::TM, TN = C::TN;
   constexpr int VEC = DT<T>::VEC;
-  constexpr int BK = 8 * VEC;
+  constexpr int KV = C::KV, BK = KV * VEC;
   constexpr int LDK = BK + VEC;    // k-major LDS row stride (elements)
   // mn-major LDS row stride: bf16 rows are padded to (16 mod 64) dwords -> conflict-free ds_read_b64_tr_b16
   constexpr int LDMA = sizeof(T) == 2 ? BM + 32 : BM + VEC;
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmParams p) {
   constexpr int A_ELEMS = A_KMAJOR ? BM * LDK : BK * LDMA;
   constexpr int B_ELEMS = B_KMAJOR ? BN * LDK : BK * LDMB;
   constexpr int MVA = BM / VEC, MVB = BN / VEC;          // vectors per mn-major row
-  constexpr int NVA = BM * 8 / NTHREADS, NVB = BN * 8 / NTHREADS;  // 16-byte vectors per thread per K tile
+  constexpr int NVA = BM * KV / NTHREADS, NVB = BN * KV / NTHREADS;  // 16-byte vectors per thread per K tile
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
   // NOTE: stage addresses are formed as smem + cur * STAGE (never by selecting between two pointers): a pointer select
@@ -176,9 +179,9 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmParams p) {
   for (int i = 0; i < NVA; ++i) {
     const int v = tid + NTHREADS * i;
     if (A_KMAJOR) {
-      int64_t row = m0 + (v >> 3);
+      int64_t row = m0 + v / KV;
       row = row < p.M ? row : p.M - 1;
-      ka[i] = kt0 * BK + (v & 7) * VEC;
+      ka[i] = kt0 * BK + (v % KV) * VEC;
       if (SEG && p.a_seg) { aq[i] = ka[i] / (int)p.a_seg; ar[i] = ka[i] % (int)p.a_seg; pa[i] = A + row * p.lda; }
       else { aq[i] = 0; ar[i] = 0; pa[i] = A + row * p.lda + ka[i]; }
     } else {
@@ -193,9 +196,9 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmParams p) {
   for (int i = 0; i < NVB; ++i) {
     const int v = tid + NTHREADS * i;
     if (B_KMAJOR) {
-      int64_t row = n0 + (v >> 3);
+      int64_t row = n0 + v / KV;
       row = row < p.N ? row : p.N - 1;
-      kb[i] = kt0 * BK + (v & 7) * VEC;
+      kb[i] = kt0 * BK + (v % KV) * VEC;
       if (SEG && p.b_seg) { bq[i] = kb[i] / (int)p.b_seg; br[i] = kb[i] % (int)p.b_seg; pb[i] = B + row * p.ldb; }
       else { bq[i] = 0; br[i] = 0; pb[i] = B + row * p.ldb + kb[i]; }
     } else {
@@ -252,13 +255,13 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int i = 0; i < NVA; ++i) {
       const int v = tid + NTHREADS * i;
-      T* da = smem + buf * STAGE + (A_KMAJOR ? (v >> 3) * LDK + (v & 7) * VEC : (v / MVA) * LDMA + (v % MVA) * VEC);
+      T* da = smem + buf * STAGE + (A_KMAJOR ? (v / KV) * LDK + (v % KV) * VEC : (v / MVA) * LDMA + (v % MVA) * VEC);
       *reinterpret_cast<u32x4*>(da) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < NVB; ++i) {
       const int v = tid + NTHREADS * i;
-      T* db = smem + buf * STAGE + A_ELEMS + (B_KMAJOR ? (v >> 3) * LDK + (v & 7) * VEC : (v / MVB) * LDMB + (v % MVB) * VEC);
+      T* db = smem + buf * STAGE + A_ELEMS + (B_KMAJOR ? (v / KV) * LDK + (v % KV) * VEC : (v / MVB) * LDMB + (v % MVB) * VEC);
       *reinterpret_cast<u32x4*>(db) = rb[i];
     }
   };
@@ -621,7 +624,7 @@ __global__ void splitk_reduce_kernel(GemmParams p) {
 template <typename T, bool AK, bool BK_, bool SEG, typename C>
 int launch(GemmParams p, int64_t M, int64_t N, int64_t nbatch, hipStream_t s) {
   constexpr int VEC = DT<T>::VEC;
-  constexpr int BKc = 8 * VEC, LDK = BKc + VEC;
+  constexpr int BKc = C::KV * VEC, LDK = BKc + VEC;
   constexpr int LDMA = sizeof(T) == 2 ? C::BM + 32 : C::BM + VEC, LDMB = sizeof(T) == 2 ? C::BN + 32 : C::BN + VEC;
   constexpr int A_ELEMS = AK ? C::BM * LDK : BKc * LDMA;
   constexpr int B_ELEMS = BK_ ? C::BN * LDK : BKc * LDMB;
@@ -777,12 +780,12 @@ extern "C" int cst_gemm(const cst_gemm_desc* d, cst_stream stream) {
       : (bk ? launch_glds<T, false, true, CFG, NS>(p, d->M, d->N, nbatch, s) : launch_glds<T, false, false, CFG, NS>(p, d->M, d->N, nbatch, s)))
   // measured on MI355X (tools/bench_kernels.py): the DMA path wins when both operands are k-major (716 vs 661 TF/s, fc1
   // forward); with an mn-major operand the register-staged path + padded LDS rows is faster (690 vs 649, 562 vs 486).
-  const bool no_glds = getenv_no_glds() || !(ak && bk);
-  static const bool mid3 = getenv("CST_GEMM_MID3") != nullptr;  // A/B switch for benchmarking the two staging paths
+  static const bool glds_all = getenv("CST_GEMM_GLDS_ALL") != nullptr;
+  const bool no_glds = getenv_no_glds() || (!(ak && bk) && !glds_all);
 #define CST_GEMM_DISPATCH(T)                                                                         \
   (seg ? CST_GEMM_LAYOUT(T, true, CfgSmall)                                                           \
        : (no_glds ? (large ? CST_GEMM_LAYOUT(T, false, CfgLarge) : CST_GEMM_LAYOUT(T, false, CfgSmall)) \
-                  : (large ? (mid3 ? CST_GLDS_LAYOUT(T, CfgMid, 3) : CST_GLDS_LAYOUT(T, CfgLarge, 2)) : CST_GLDS_LAYOUT(T, CfgSmall, 2))))
+                  : (large ? CST_GLDS_LAYOUT(T, CfgLarge, 2) : CST_GLDS_LAYOUT(T, CfgSmall, 2))))
   if (d->dtype == CST_BF16) rc = CST_GEMM_DISPATCH(bf16_t);
   else rc = CST_GEMM_DISPATCH(float);
 #undef CST_GEMM_DISPATCH
