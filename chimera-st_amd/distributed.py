@@ -41,8 +41,9 @@ def distributed_init(backend=None):
 class BucketedGradAllReduce:
     """Overlapped, bucketed mean-all-reduce of a flat gradient buffer."""
 
-    def __init__(self, params, offsets, flat_grad, process_group=None, bucket_cap_mb=64):
+    def __init__(self, params, offsets, flat_grad, process_group=None, bucket_cap_mb=64, gather=None):
         self.pg = process_group
+        self.gather = gather  # callable(indices): copy those parameters' autograd-owned grads into the flat buffer
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.flat_grad = flat_grad
         self.params = list(params)
@@ -89,6 +90,8 @@ class BucketedGradAllReduce:
 
     def _launch(self, b):
         bk = self.buckets[b]
+        if self.gather is not None:
+            self.gather(bk["members"])
         g = self.flat_grad[bk["lo"]:bk["hi"]]
         g.div_(self.world)
         self._works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
@@ -117,7 +120,8 @@ class DistributedFairseqModel(torch.nn.Module):
         super().__init__()
         self.module = model
         self.reducer = BucketedGradAllReduce(buffers.params, buffers.offsets, buffers.flat_grad, process_group,
-                                             getattr(args, "bucket_cap_mb", 64) if args is not None else 64)
+                                             getattr(args, "bucket_cap_mb", 64) if args is not None else 64,
+                                             gather=getattr(buffers, "gather_grads", None))
 
     def __getattr__(self, name):
         try:

@@ -31,17 +31,37 @@ class FlatParamBuffers:
         self.total = total
         self.flat_param = torch.zeros(total, dtype=self.dtype, device=self.device)
         self.flat_grad = torch.zeros(total, dtype=self.dtype, device=self.device)
+        self.grad_views = []
         for p, o in zip(self.params, self.offsets):
             n = p.numel()
             self.flat_param[o:o + n].copy_(p.data.reshape(-1))
             p.data = self.flat_param[o:o + n].view(p.shape)
-            p.grad = self.flat_grad[o:o + n].view(p.shape)
+            self.grad_views.append(self.flat_grad[o:o + n].view(p.shape))
+            p.grad = None
 
     def zero_grad(self):
+        """Gradients are left to autograd as free-standing tensors (p.grad = None lets AccumulateGrad STEAL the tensor our
+        backward kernels wrote, instead of launching one `grad += new` kernel per parameter); they are gathered into the flat
+        buffer bucket-by-bucket (gather_grads) right before they are all-reduced / consumed by the fused optimizer."""
         self.flat_grad.zero_()
-        for p, o in zip(self.params, self.offsets):  # re-attach if something replaced .grad (e.g. set_to_none)
-            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + o * self.flat_grad.element_size():
-                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+        for p in self.params:
+            p.grad = None
+
+    def gather_grads(self, indices=None):
+        """Copy the autograd-owned gradients of the given parameters into their flat-buffer slots with ONE multi-tensor copy;
+        parameters without a gradient keep zeros (legacy_distributed_data_parallel.py:155-156)."""
+        idxs = range(len(self.params)) if indices is None else indices
+        dsts, srcs = [], []
+        for i in idxs:
+            g = self.params[i].grad
+            if g is not None and g.data_ptr() != self.grad_views[i].data_ptr():
+                dsts.append(self.grad_views[i])
+                srcs.append(g if g.shape == self.grad_views[i].shape else g.view(self.grad_views[i].shape))
+        if dsts:
+            torch._foreach_copy_(dsts, srcs)
+            for i in idxs:
+                if self.params[i].grad is not None:
+                    self.params[i].grad = self.grad_views[i]
 
 
 def inverse_sqrt_lr(num_updates, lr, warmup_updates, warmup_init_lr):

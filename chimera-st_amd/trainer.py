@@ -71,6 +71,8 @@ class Trainer:
             sample_size += ss
         if self.world > 1:
             self.model.all_reduce()  # waits for the overlapped bucket reductions; launches the stragglers
+        else:
+            self.buffers.gather_grads()  # one multi-tensor copy of every autograd-owned gradient into the flat buffer
         # logging scalars + sample_size: ONE fp64 device vector, one small all-reduce (C3-C5 folded), no host sync
         # before the optimizer kernels are queued.
         keys = sorted(k for k in logs[0].keys())

@@ -117,10 +117,13 @@ def test_flat_param_buffers_alias_and_zero():
         assert torch.equal(p, r) and o % optim.ALIGN == 0
         assert p.data_ptr() == buf.flat_param.data_ptr() + o * 4
     lin(torch.randn(2, 5)).sum().backward()
-    assert float(buf.flat_grad.abs().sum()) > 0
-    assert all(p.grad.data_ptr() == buf.flat_grad.data_ptr() + o * 4 for p, o in zip(lin.parameters(), buf.offsets))
+    want = [p.grad.clone() for p in lin.parameters()]
+    assert float(buf.flat_grad.abs().sum()) == 0  # autograd owns the fresh gradients until they are gathered
+    buf.gather_grads()
+    for p, w, v in zip(lin.parameters(), want, buf.grad_views):
+        assert torch.equal(v, w) and p.grad.data_ptr() == v.data_ptr()
     buf.zero_grad()
-    assert float(buf.flat_grad.abs().sum()) == 0
+    assert float(buf.flat_grad.abs().sum()) == 0 and all(p.grad is None for p in lin.parameters())
 
 
 def _free_port():
@@ -182,10 +185,12 @@ def test_bucketed_all_reduce_gloo_world2():
         xs = [torch.from_numpy(x) for x in res[r][3]]
         buf.zero_grad()
         net[:5](xs[0]).pow(2).sum().backward()
+        buf.gather_grads()
         want1 += buf.flat_grad / world
         buf.zero_grad()
         net(xs[1]).pow(2).sum().backward()
         net(xs[2]).pow(2).sum().backward()
+        buf.gather_grads()
         want2 += buf.flat_grad / world
     np.testing.assert_allclose(res[0][1], want1.numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(res[0][2], want2.numpy(), rtol=1e-5, atol=1e-6)
