@@ -311,23 +311,49 @@ def conv0_gn_gelu(wav, weight, gn_weight, gn_bias, stride, eps=1e-5):
 # ------------------------------------------------------------------------------------------------
 # channels-last conv1d as implicit GEMM (wav2vec2 conv layers 1.., subsampler)
 # ------------------------------------------------------------------------------------------------
+def _padded_base(t, L, C):
+    """If `t` [B, L, C] is the interior view of a [B, L+2, C] allocation (one spare row before and after every utterance),
+    return that allocation as a tensor, else None."""
+    if t.dim() == 3 and t.stride(2) == 1 and t.stride(1) == C and t.stride(0) == (L + 2) * C and t.storage_offset() >= C:
+        return torch.as_strided(t, (t.shape[0], L + 2, C), t.stride(), t.storage_offset() - C)
+    return None
+
+
 class _Conv1dCLFn(torch.autograd.Function):
+    """Channels-last conv1d as implicit GEMMs.
+    forward : y[b,t,:] = act(W . x[b, t*s : t*s+k, :])            one GEMM, A rows overlap (lda = s*Cin < K = k*Cin)
+    dW      : per-utterance [Cout, k*Cin] partials (both operands mn-major, B rows overlap), summed over the batch
+    dX      : pad == 0, k <= 2s (the wav2vec2 CNN): for every residue r of l mod s one GEMM
+                 dx[b, s*u + r, :] = sum_i dz[b, u - i, :] . W[:, :, r + s*i]
+              whose A rows are again overlapping windows of the (row-padded) dz and whose C rows are written with ldc = s*Cin
+              straight into dx — no [B, Lout, k*Cin] column buffer and no col2im pass; GELU'(prev_z) is the epilogue.
+              otherwise (padded subsampler convs): column-gradient GEMM + cst_col2im1d.
+    Layers whose incoming gradient is already d/dz (grad_is_dz) keep y / z / dx in a [B, L+2, C] allocation (interior views)
+    so the zero rows the dX windows need at utterance boundaries exist without copying."""
+
     @staticmethod
     def forward(ctx, x, w_cl, bias, k, stride, pad, act, prev_z, grad_is_dz):
-        """x [B, Lin, Cin] contiguous; w_cl [Cout, k*Cin]; -> y [B, Lout, Cout] (and saves z if act)."""
         B, Lin, Cin = x.shape
         Cout = w_cl.shape[0]
         if pad:
             xp = torch.zeros(B, Lin + 2 * pad, Cin, dtype=x.dtype, device=x.device)
             xp[:, pad:pad + Lin] = x
+        elif x.stride(2) == 1 and x.stride(1) == Cin:
+            xp = x  # contiguous or an interior view of a row-padded allocation: only the batch stride differs
         else:
-            xp = x if x.is_contiguous() else x.contiguous()
+            xp = x.contiguous()
         Lp = Lin + 2 * pad
         Lout = (Lp - k) // stride + 1
-        y = torch.empty(B, Lout, Cout, dtype=x.dtype, device=x.device)
-        z = torch.empty_like(y) if act != L.ACT_NONE else None
-        K.gemm(xp, w_cl, y, Lout, Cout, k * Cin, a_kmajor=1, b_kmajor=1, lda=stride * Cin, ldb=k * Cin, ldc=Cout, bias=bias,
-               act=act, aux_out=z, ld_aux_out=Cout, batch0=B, sa=(Lp * Cin, 0), sc=(Lout * Cout, 0), split_k=1)
+        padded_out = bool(grad_is_dz) and act != L.ACT_NONE
+        rows = Lout + 2 if padded_out else Lout
+        y_full = torch.empty(B, rows, Cout, dtype=x.dtype, device=x.device)
+        z_full = torch.empty_like(y_full) if act != L.ACT_NONE else None
+        coff = Cout if padded_out else 0
+        K.gemm(xp, w_cl, y_full, Lout, Cout, k * Cin, a_kmajor=1, b_kmajor=1, lda=stride * Cin, ldb=k * Cin, ldc=Cout, bias=bias,
+               act=act, aux_out=z_full, ld_aux_out=Cout, batch0=B, sa=(xp.stride(0), 0), sc=(rows * Cout, 0), split_k=1,
+               a_off=0, c_off=coff)
+        y = y_full[:, 1:1 + Lout] if padded_out else y_full
+        z = (z_full[:, 1:1 + Lout] if padded_out else z_full) if z_full is not None else None
         ctx.save_for_backward(xp, w_cl, z, prev_z)
         ctx.cfg = (B, Lin, Cin, Cout, k, stride, pad, Lout, act, bias is not None, grad_is_dz)
         if act != L.ACT_NONE:
@@ -339,23 +365,58 @@ class _Conv1dCLFn(torch.autograd.Function):
     def backward(ctx, dy, _dz_unused):
         xp, w_cl, z, prev_z = ctx.saved_tensors
         B, Lin, Cin, Cout, k, stride, pad, Lout, act, has_bias, grad_is_dz = ctx.cfg
-        Lp = Lin + 2 * pad
-        dy = dy.contiguous()
-        dz = K.act_bwd(dy, z, act) if (act != L.ACT_NONE and not grad_is_dz) else dy
-        dz2 = dz.view(B * Lout, Cout)
+        fast = pad == 0 and k <= stride + 1  # every dX window then stays inside the row-padded dz
+        # ---- dz, in a row-padded allocation when the windowed dX GEMMs will read it ----
+        dzp = _padded_base(dy, Lout, Cout) if (act == L.ACT_NONE or grad_is_dz) else None
+        if dzp is None:
+            dyc = dy if dy.is_contiguous() else dy.contiguous()
+            dzc = K.act_bwd(dyc, z if z.is_contiguous() else z.contiguous(), act) if (act != L.ACT_NONE and not grad_is_dz) else dyc
+            if fast:
+                dzp = torch.empty(B, Lout + 2, Cout, dtype=dy.dtype, device=dy.device)
+                dzp[:, 0].zero_()
+                dzp[:, Lout + 1].zero_()
+                dzp[:, 1:1 + Lout] = dzc
+            dz_rows, dz_bs, dz_off = dzc, Lout * Cout, 0
+        else:
+            dz_rows, dz_bs, dz_off = dzp, (Lout + 2) * Cout, Cout
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dcol = torch.empty(B * Lout, k * Cin, dtype=dy.dtype, device=dy.device)
-            K.gemm(dz2, w_cl, dcol, B * Lout, k * Cin, Cout, a_kmajor=1, b_kmajor=0, lda=Cout, ldb=k * Cin, ldc=k * Cin, split_k=1)
-            # prev_z: pre-activation of the producing conv layer -> fold its GELU' into the col2im pass
-            dx = K.col2im1d(dcol, prev_z, B, Lin, Lout, Cin, k, stride, pad, L.ACT_GELU if prev_z is not None else 0)
+            if fast:
+                dx_padded = prev_z is not None and _padded_base(prev_z, Lin, Cin) is not None
+                rows = Lin + 2 if dx_padded else Lin
+                dx_full = torch.empty(B, rows, Cin, dtype=dy.dtype, device=dy.device)
+                if dx_padded:
+                    dx_full[:, 0].zero_()
+                    dx_full[:, Lin + 1].zero_()
+                pz = prev_z if prev_z is None or dx_padded else (prev_z if prev_z.is_contiguous() else prev_z.contiguous())
+                pz_base = _padded_base(prev_z, Lin, Cin) if dx_padded else pz
+                w3 = w_cl.view(Cout, k, Cin)
+                for r in range(stride):
+                    taps = list(range(r, k, stride))
+                    n = len(taps)
+                    U = (Lin - r + stride - 1) // stride
+                    if n == 0 or U <= 0:
+                        continue
+                    # B_r[ci][q*Cout + co] = W[co][ci][r + s*(n-1-q)]   (window position q <-> dz[u - (n-1) + q])
+                    wr = w3[:, [taps[n - 1 - q] for q in range(n)], :].permute(2, 1, 0).reshape(Cin, n * Cout).contiguous()
+                    K.gemm(dzp, wr, dx_full, U, Cin, n * Cout, a_kmajor=1, b_kmajor=1, lda=Cout, ldb=n * Cout, ldc=stride * Cin,
+                           batch0=B, sa=((Lout + 2) * Cout, 0), sc=(rows * Cin, 0), a_off=(2 - n) * Cout,
+                           c_off=(Cin if dx_padded else 0) + r * Cin, dact=L.ACT_GELU if prev_z is not None else L.ACT_NONE,
+                           aux_in=pz_base, ld_aux_in=stride * Cin, split_k=1)
+                dx = dx_full[:, 1:1 + Lin] if dx_padded else dx_full
+            else:
+                dz2 = dz_rows.reshape(B * Lout, Cout) if dzp is None else dzp[:, 1:1 + Lout].reshape(B * Lout, Cout)
+                dcol = torch.empty(B * Lout, k * Cin, dtype=dy.dtype, device=dy.device)
+                K.gemm(dz2, w_cl, dcol, B * Lout, k * Cin, Cout, a_kmajor=1, b_kmajor=0, lda=Cout, ldb=k * Cin, ldc=k * Cin, split_k=1)
+                pzc = prev_z if prev_z is None or prev_z.is_contiguous() else prev_z.contiguous()
+                dx = K.col2im1d(dcol, pzc, B, Lin, Lout, Cin, k, stride, pad, L.ACT_GELU if prev_z is not None else 0)
         if ctx.needs_input_grad[1]:
             part = torch.empty(B, Cout, k * Cin, dtype=torch.float32, device=dy.device)
-            K.gemm(dz2, xp, part, Cout, k * Cin, Lout, a_kmajor=0, b_kmajor=0, lda=Cout, ldb=stride * Cin, ldc=k * Cin, batch0=B,
-                   sa=(Lout * Cout, 0), sb=(Lp * Cin, 0), sc=(Cout * k * Cin, 0), split_k=1)
+            K.gemm(dz_rows, xp, part, Cout, k * Cin, Lout, a_kmajor=0, b_kmajor=0, lda=Cout, ldb=stride * Cin, ldc=k * Cin, batch0=B,
+                   sa=(dz_bs, 0), sb=(xp.stride(0), 0), sc=(Cout * k * Cin, 0), a_off=dz_off, split_k=1)
             dw = part.sum(0).to(w_cl.dtype)
         if has_bias and ctx.needs_input_grad[2]:
-            db = K.colsum(dz2).to(w_cl.dtype)
+            db = K.colsum(dz_rows.reshape(B * Lout, Cout) if dzp is None else dzp[:, 1:1 + Lout].reshape(B * Lout, Cout)).to(w_cl.dtype)
         return dx, dw, db, None, None, None, None, None, None
 
 

@@ -355,3 +355,37 @@ def test_adam_and_sumsq(K):
         out = torch.zeros(1, device="cuda")
         k.sumsq(g, out)
         check(out, (g.float() ** 2).sum()[None], torch.float32, "sumsq")
+
+
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("Lin", [97, 200, 333])
+def test_conv_stack_windowed_dx(dt, Lin):
+    """wav2vec2 conv layers 1.. as implicit GEMMs: forward, dX through the residue-class windowed GEMMs (row-padded dz,
+    GELU' folded into the epilogue, no col2im) and dW, against torch autograd of conv1d+GELU on the same values."""
+    load_pkg()
+    from importlib import import_module
+    CF = import_module("chimera-st_amd.functional")
+    B, C = 3, 64
+    spec = [(3, 2), (3, 2), (2, 2), (2, 2)]
+    x = rnd(B, Lin, C, dt=dt, seed=5).requires_grad_(True)
+    ws = [(rnd(C, C, k, dt=dt, seed=10 + i, scale=1.0 / math.sqrt(C * k))).requires_grad_(True) for i, (k, s) in enumerate(spec)]
+    y, z = x, None
+    for i, (k, s) in enumerate(spec):
+        y, z = CF.conv1d_cl(y, ws[i], None, s, pad=0, act="gelu", prev_z=z, grad_is_dz=(i < len(spec) - 1))
+    g = rnd(*y.shape, dt=dt, seed=77)
+    y.backward(g)
+    xr = x.detach().float().requires_grad_(True)
+    wr = [w.detach().float().requires_grad_(True) for w in ws]
+    h = xr.transpose(1, 2)
+    for i, (k, s) in enumerate(spec):
+        h = F.gelu(F.conv1d(h, wr[i], stride=s))
+        if dt != torch.float32:
+            h = h.to(dt).float()  # the HIP path stores every layer's activation in bf16
+    ref = h.transpose(1, 2)
+    check(y, ref, dt, "conv stack fwd")
+    ref.backward(g.float())
+    # layer 0 of this stack has no GELU'(prev_z) folded in (prev_z=None), like layer 1 behind conv0
+    check(x.grad, xr.grad, dt, "conv stack dX", scale=float(xr.grad.abs().max()) * (1 if dt == torch.float32 else 2))
+    for i in range(len(spec)):
+        check(ws[i].grad, wr[i].grad, dt, "conv stack dW%d" % i, scale=float(wr[i].grad.abs().max()) * (1 if dt == torch.float32 else 2))
