@@ -14,11 +14,12 @@
 // consecutive mn -> conflict-free).
 // Workgroup -> tile map is XCD-aware (bijective remap so each XCD's L2 sees a contiguous
 // band of tiles sharing A rows).
-#include "cst_common.h"
+#include "gemm_common.h"
 #include <stdlib.h>
 #include <type_traits>
 
 namespace {
+using namespace cstg;
 
 // tile configurations: Cfg<BM, BN, WM, WN>: WM x WN waves, each (BM/WM) x (BN/WN) = (TM*32) x (TN*32)
 template <int BM_, int BN_, int WM_, int WN_, int KV_ = 8>
@@ -31,83 +32,6 @@ using CfgSmall = Cfg<128, 128, 2, 2>;   // 4 waves, 2 blocks/CU: small / skinny 
 // alternatives on MI355X at M=48k, K/N in {768, 3072} (tools/bench_kernels.py): 8 waves x (128 x 64) 660-690 TF/s (VGPR-capped,
 // 2 waves/SIMD); 256 x 128 x 64 8 waves with a 3-stage DMA ring 590; 256 x 128 x 32 4 waves 2 blocks/CU 590-660; this one 670-760.
 using CfgLarge = Cfg<256, 256, 4, 4>;   // 8 waves (wave tile 128 x 64), 1 block/CU: half the L2->LDS bytes per FLOP
-
-struct GemmParams {
-  int64_t M, N, K;
-  const void* A; int64_t lda, a_seg, a_seg_stride;
-  const void* B; int64_t ldb, b_seg, b_seg_stride;
-  void* C; int64_t ldc;
-  const void* bias; int bias_mode; int64_t sbias0, sbias1;
-  int act;
-  void* aux_out; int64_t ld_aux_out;
-  int dact;
-  const void* aux_in; int64_t ld_aux_in;
-  const void* resid; int64_t ld_resid;
-  float alpha;
-  int64_t batch1;
-  int64_t sa0, sa1, sb0, sb1, sc0, sc1;
-  int splits;
-  float* ws;  // split-K partials [batch][split][M][N]
-  int c_f32;
-  int vec_epi;  // all epilogue operands 16-byte aligned -> staged, vectorised epilogue
-  int tiles_m, tiles_n;
-};
-
-__device__ __forceinline__ int64_t segaddr(int64_t c, int64_t seg, int64_t seg_stride) {
-  return seg ? (c / seg) * seg_stride + (c % seg) : c;
-}
-
-template <typename T>
-__device__ __forceinline__ void epilogue_store(const GemmParams& p, int64_t cofs, int64_t bofs, int64_t row, int64_t col, float v) {
-  v *= p.alpha;
-  if (p.bias_mode == CST_BIAS_COL) v += DT<T>::ld((const T*)p.bias + bofs + col);
-  else if (p.bias_mode == CST_BIAS_ROW) v += DT<T>::ld((const T*)p.bias + bofs + row);
-  if (p.aux_out) DT<T>::st((T*)p.aux_out + cofs + row * p.ld_aux_out + col, v);
-  v = act_f(v, p.act);
-  if (p.dact) v *= dact_f(DT<T>::ld((const T*)p.aux_in + cofs + row * p.ld_aux_in + col), p.dact);
-  if (p.resid) v += DT<T>::ld((const T*)p.resid + cofs + row * p.ld_resid + col);
-  if (p.c_f32) ((float*)p.C)[cofs + row * p.ldc + col] = v;
-  else DT<T>::st((T*)p.C + cofs + row * p.ldc + col, v);
-}
-
-// 8 consecutive columns of one row: the same epilogue as epilogue_store, with 16-byte global accesses.
-template <typename T>
-__device__ __forceinline__ void epilogue_store8(const GemmParams& p, int64_t cofs, int64_t bofs, int64_t row, int64_t col, float (&v)[8]) {
-#pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
-  if (p.bias_mode == CST_BIAS_COL) {
-    float b[8];
-    load8((const T*)p.bias + bofs + col, b);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] += b[e];
-  } else if (p.bias_mode == CST_BIAS_ROW) {
-    const float b = DT<T>::ld((const T*)p.bias + bofs + row);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] += b;
-  }
-  if (p.aux_out) store8((T*)p.aux_out + cofs + row * p.ld_aux_out + col, v);
-  if (p.act == CST_ACT_RELU) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
-  } else if (p.act == CST_ACT_GELU) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
-  }
-  if (p.dact) {
-    float z[8];
-    load8((const T*)p.aux_in + cofs + row * p.ld_aux_in + col, z);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] *= dact_f(z[e], p.dact);
-  }
-  if (p.resid) {
-    float r[8];
-    load8((const T*)p.resid + cofs + row * p.ld_resid + col, r);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] += r[e];
-  }
-  if (p.c_f32) store8((float*)p.C + cofs + row * p.ldc + col, v);
-  else store8((T*)p.C + cofs + row * p.ldc + col, v);
-}
 
 template <typename T, bool A_KMAJOR, bool B_KMAJOR, bool SEG, typename C>
 __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmParams p) {
@@ -684,7 +608,9 @@ int choose_splits(const cst_gemm_desc* d) {
   if (d->M >= 256 && d->N >= 256) {
     const int64_t tl = cst_ceil_div(d->M, 256) * cst_ceil_div(d->N, 256) * nb;
     if (tl >= 200) return 1;
-    int64_t s = cst_ceil_div(256, tl);
+    // one workgroup per CU: the largest split count that still fits ONE round of 256 workgroups (288 would run as a full
+    // round plus a 12 %-occupied second one)
+    int64_t s = 256 / tl;
     if (s > ktiles / 8) s = ktiles / 8;
     if (s > 32) s = 32;
     if (s >= 1 && tl * s >= 200) return (int)s;
@@ -786,7 +712,14 @@ extern "C" int cst_gemm(const cst_gemm_desc* d, cst_stream stream) {
   (seg ? CST_GEMM_LAYOUT(T, true, CfgSmall)                                                           \
        : (no_glds ? (large ? CST_GEMM_LAYOUT(T, false, CfgLarge) : CST_GEMM_LAYOUT(T, false, CfgSmall)) \
                   : (large ? CST_GLDS_LAYOUT(T, CfgLarge, 2) : CST_GLDS_LAYOUT(T, CfgSmall, 2))))
-  if (d->dtype == CST_BF16) rc = CST_GEMM_DISPATCH(bf16_t);
+  // bf16 problems that fill the chip with 256 x 256 tiles take the 8-phase DMA-pipelined kernel (gemm8p.hip)
+  static const bool no_8p = getenv("CST_GEMM_NO_8P") != nullptr, force_8p = getenv("CST_GEMM_FORCE_8P") != nullptr;
+  // (A k-major only: with an mn-major A the register-staged 16-wave kernel measured 20-30 % faster on the dW shapes; and not
+  //  with an act'(aux_in) epilogue, whose 128 KiB-per-tile operand read is exposed at one workgroup per CU: 0.49 vs 0.42 ms)
+  static const bool all_8p = getenv("CST_GEMM_8P_ALL") != nullptr;
+  if (d->dtype == CST_BF16 && !seg && !no_8p && (ak || all_8p || force_8p) && (!d->dact || all_8p || force_8p) && (large || force_8p) && cst_gemm8p_supported(p, ak, bk, nbatch))
+    rc = cst_gemm8p_launch(p, ak, bk, nbatch, s);
+  else if (d->dtype == CST_BF16) rc = CST_GEMM_DISPATCH(bf16_t);
   else rc = CST_GEMM_DISPATCH(float);
 #undef CST_GEMM_DISPATCH
 #undef CST_GEMM_LAYOUT

@@ -1,0 +1,511 @@
+// gemm8p.hip — the large-problem bf16 GEMM of libcst_hip: 256 x 256 x 64 tile, 8 waves (2 x 4), v_mfma_f32_32x32x16_bf16,
+// operands streamed HBM/L2 -> LDS by buffer_load ... lds (16 B per lane, no staging registers, out-of-range lanes read 0),
+// an 8-phase K loop (2 K tiles x 4 phases) with counted vmcnt: three 16-KiB half-tiles stay in flight across barriers and
+// the DMA queue is never drained inside the loop.
+//
+// LDS (128 KiB): 2 K-tile buffers x 4 half-tile images of 16 KiB in CONSUMPTION order  B0 | A0 | B1 | A1
+//   (A0 = rows [0,128) of the 256-row A tile, A1 = rows [128,256); same for B columns).
+//   k-major operand  image [128 rows][128 B], 16-B chunk c of row r stored at chunk c ^ ((r >> 1) & 7) -> ds_read_b128
+//                    conflict-free; a lane still fetches one row's chunks from 8 consecutive lanes (full 128-B lines).  (A
+//                    chunk-major image with immediate-only addressing measured 20 % slower: its DMA touches 8 lines per 8 lanes.)
+//   mn-major operand image: 16 DMA groups of 4 k-rows x 256 B placed 1088 B apart (64 B of padding per group); k-row
+//                    k = 16a + 4b + c lives in group 4a + c, row slot b.  The four consecutive k-rows one ds_read_b64_tr_b16
+//                    gathers (c = 0..3) then sit in four groups whose bases differ by 64 B mod 256 -> conflict-free, and every
+//                    fragment address is one per-lane base + compile-time immediates (no swizzle arithmetic, no extra VGPRs).
+//   The DMA writes lane-linear (wave base + lane * 16): the layouts above are produced purely by choosing which source
+//   (row, chunk) each lane fetches.  Rows / columns / k beyond the matrix are fetched as zeros (descriptor range check).
+// Wave (wm, wn) owns rows {h*128 + wm*64 + [0,64)} x cols {h'*128 + wn*32 + [0,32)}, h,h' in {0,1}: four 64 x 32 quadrants,
+//   one per phase:   ph1 reads B0,A0 -> Q00 | ph2 reads B1 -> Q01 | ph3 reads A1 -> Q11 | ph4 reads nothing -> Q10.
+// Every phase = { ds_reads ; stage one half-tile (2 DMA / lane) ; s_barrier ; lgkmcnt(0) ; 8 MFMA ; s_barrier }.  The wm = 1
+//   waves run one barrier behind the wm = 0 waves (they share SIMDs pairwise), so one group's MFMA section overlaps the other
+//   group's LDS/DMA section.
+// Stream order of half-tiles s = 4*tile + q (q: 0=B0 1=A0 2=B1 3=A1); 7 are staged in the prologue, phase j stages s = 7 + j.
+//   WAR: a region is restaged >= 2 phases after its last ds_read (B0: 1 phase, its reads are retired by lgkmcnt(8) before ph1's
+//   first barrier).  RAW: vmcnt(6) in ph4 (before its first barrier) retires everything but the 3 newest half-tiles, i.e. the
+//   whole next K tile, which is first read one phase later.
+// Persistent: the grid is one workgroup per CU; each walks work items (batch/split z, output tile) v = blockIdx.x + i * gridDim.x.
+//   After an item's K loop the first K tile of the NEXT item is already streaming into buffer 0 while the epilogue runs out of
+//   the buffer-1 region, and the epilogue's global stores drain under the next item's MFMAs.
+// Epilogue: MFMA operands are swapped (D = B-frag x A-frag), so a lane holds 4 CONSECUTIVE output columns of one row per
+//   register quad.  bf16 outputs: alpha/bias in registers -> one bf16 rounding (this is the pre-activation z) -> ds_write_b64
+//   into a [128][256] bf16 image (2 passes) -> row-contiguous 16-byte read-back, activation / act' / residual on the way out.
+//   fp32 outputs and split-K slabs: fp32 image, 64 rows per pass.
+#include "gemm_common.h"
+#include <type_traits>
+
+namespace {
+using namespace cstg;
+using T = bf16_t;
+
+constexpr int BM = 256, BN = 256, BK = 64, NTHREADS = 512;
+constexpr int QB = 17408;           // one half-tile image (k-major images use the first 16 KiB)
+constexpr int GSTRIDE = 1088;       // byte distance of the DMA groups of an mn-major image (64 B pad)
+constexpr int KSTRIDE = 1024;       // k-major images are dense
+constexpr int BUFB = 4 * QB;        // one K tile: B0 | A0 | B1 | A1
+constexpr int LDS_BYTES = 2 * BUFB;
+constexpr unsigned OOB = 0x80000000u;  // >= num_records of every descriptor: the DMA writes zeros
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N>
+__device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, 0, 0, 0);
+}
+
+template <bool AK, bool BKM>
+__global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int lrow = lane & 31, hi = lane >> 5;
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int total = ntiles * p.nz;
+  const int ktiles = (int)((p.K + BK - 1) / BK);
+  const int per = (ktiles + p.splits - 1) / p.splits;
+  // The by-value argument block is re-read from the kernarg segment (scalar loads through an opaque pointer) at each use site
+  // outside the K loop, so that the ~70 SGPRs of launch parameters are not kept live across the MFMA loop.
+  typedef const __attribute__((address_space(4))) GemmParams* kparg_t;
+  kparg_t kp = (kparg_t)__builtin_amdgcn_kernarg_segment_ptr();
+
+  // ---- lane constants of the DMA source map ----
+  // k-major: group g covers rows 8g..8g+7 of the half; lane -> (row 8g + lane/8, stored chunk lane%8 = source chunk ^ swizzle)
+  const int ck = (lane & 7) ^ (((4 * wave) + (lane >> 4)) & 7);   // ((8g + lane/8) >> 1) & 7 is the same for g and g + 8
+  // mn-major: group G = 4a + c holds k-rows 16a + 4b + c (b = row slot = lane/16); lane -> chunk lane%16 of that row
+  const int klm = 16 * (wave >> 2) + 4 * (lane >> 4) + (wave & 3);
+  const int kla = AK ? ck * 8 : klm, klb = BKM ? ck * 8 : klm;    // k inside a K tile (mn-major group 1: +32)
+  const int pa = AK ? 8 * wave + (lane >> 3) : (lane & 15) * 8;   // row (k-major) / first column (mn-major)
+  const int pb = BKM ? 8 * wave + (lane >> 3) : (lane & 15) * 8;  //   inside a half, group 0
+  const unsigned step_a = AK ? (unsigned)(BK * 2) : (unsigned)(BK * p.lda * 2);
+  const unsigned step_b = BKM ? (unsigned)(BK * 2) : (unsigned)(BK * p.ldb * 2);
+  const bool fast_epi = !p.c_f32 && p.splits == 1 && p.vec_epi && (p.N % 8) == 0 && p.bias_mode != CST_BIAS_ROW &&
+                        (p.bias_mode == CST_BIAS_NONE || p.alpha == 1.0f);
+  const bool bias_in_acc = fast_epi && p.bias_mode == CST_BIAS_COL;  // the bias row seeds the accumulators
+  char* const bias_lds = smem + 2 * BUFB;                              // 512 B: bias[n0 .. n0 + 256) of the streamed item
+
+  // ---- state of the item whose operands are being streamed ----
+  __amdgpu_buffer_rsrc_t ra, rb;
+  unsigned va0 = 0, vb0 = 0;     // per-lane byte offset (half 0, group 0) from the descriptor base
+  int nt = 0, krem0 = 0, mrem = 0, nrem = 0;
+  unsigned lda2 = 0, ldb2 = 0;   // leading dimensions in bytes
+  int64_t m0 = 0, n0 = 0, cofs = 0, bofs = 0;
+  int zcur = 0;
+
+  // work item v -> tile (XCD-aware grouped order, same map as gemm.hip) and operand descriptors
+  auto setup = [&](int v) {
+    asm volatile("" : "+s"(kp));
+    struct { int64_t M, N, K, lda, ldb, batch1, sa0, sa1, sb0, sb1, sc0, sc1, sbias0, sbias1; const void *A, *B, *bias; int splits, tiles_m, tiles_n; } p;
+    p.M = kp->M; p.N = kp->N; p.K = kp->K; p.lda = kp->lda; p.ldb = kp->ldb; p.batch1 = kp->batch1;
+    p.sa0 = kp->sa0; p.sa1 = kp->sa1; p.sb0 = kp->sb0; p.sb1 = kp->sb1; p.sc0 = kp->sc0; p.sc1 = kp->sc1;
+    p.sbias0 = kp->sbias0; p.sbias1 = kp->sbias1; p.A = kp->A; p.B = kp->B; p.bias = kp->bias;
+    p.splits = kp->splits; p.tiles_m = kp->tiles_m; p.tiles_n = kp->tiles_n;
+    const int z = v / ntiles;
+    int id = v - z * ntiles;
+    {
+      const int q = ntiles / 8, r = ntiles % 8, xcd = id % 8, loc = id / 8;
+      id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * p.tiles_n;
+    const int grp = id / per_group, rem = id % per_group;
+    const int gm0 = grp * GROUP_M;
+    const int gsz = (p.tiles_m - gm0 < GROUP_M) ? (p.tiles_m - gm0) : GROUP_M;
+    const int tm = gm0 + rem % gsz, tn = rem / gsz;
+    m0 = (int64_t)tm * BM;
+    n0 = (int64_t)tn * BN;
+    zcur = z;
+    const int split = z % p.splits;
+    const int64_t bidx = z / p.splits;
+    const int64_t b0 = bidx / p.batch1, b1 = bidx % p.batch1;
+    const T* A = (const T*)p.A + b0 * p.sa0 + b1 * p.sa1;
+    const T* B = (const T*)p.B + b0 * p.sb0 + b1 * p.sb1;
+    cofs = b0 * p.sc0 + b1 * p.sc1;
+    bofs = b0 * p.sbias0 + b1 * p.sbias1;
+    const int kt0 = split * per;
+    const int kt1 = (kt0 + per < ktiles) ? kt0 + per : ktiles;
+    nt = kt1 > kt0 ? kt1 - kt0 : 0;
+    krem0 = (int)p.K - kt0 * BK;
+    const T* abase = AK ? A + m0 * p.lda + (int64_t)kt0 * BK : A + (int64_t)kt0 * BK * p.lda + m0;
+    const T* bbase = BKM ? B + n0 * p.ldb + (int64_t)kt0 * BK : B + (int64_t)kt0 * BK * p.ldb + n0;
+    ra = __builtin_amdgcn_make_buffer_rsrc((void*)abase, (short)0, (int)OOB, 0x00020000);
+    rb = __builtin_amdgcn_make_buffer_rsrc((void*)bbase, (short)0, (int)OOB, 0x00020000);
+    if (bias_in_acc) {  // bias[n0 .. n0+256) -> LDS (columns >= N read 0); consumed when this item's accumulators are seeded
+      const int64_t left = p.N - n0;
+      const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.bias + bofs + n0), (short)0,
+                                                                              (int)((left < 256 ? left : 256) * 2), 0x00020000);
+      dma16(rbias, bias_lds, (unsigned)lane * 16);
+    }
+    lda2 = (unsigned)(p.lda * 2);
+    ldb2 = (unsigned)(p.ldb * 2);
+    mrem = (int)(p.M - m0 < BM ? p.M - m0 : BM);
+    nrem = (int)(p.N - n0 < BN ? p.N - n0 : BN);
+    va0 = AK ? (unsigned)pa * lda2 + (unsigned)kla * 2 : (unsigned)klm * lda2 + (unsigned)pa * 2;
+    vb0 = BKM ? (unsigned)pb * ldb2 + (unsigned)klb * 2 : (unsigned)klm * ldb2 + (unsigned)pb * 2;
+  };
+
+  // stage half-tile Q of K tile `tau` into buffer BUF
+  auto stage = [&](auto qc, auto bufc, int tau) {
+    constexpr int Q = decltype(qc)::value, BUF = decltype(bufc)::value;
+    constexpr bool IS_A = (Q & 1) != 0;
+    constexpr int H = Q >> 1;
+    constexpr bool KM = IS_A ? AK : BKM;
+    constexpr int GS = KM ? KSTRIDE : GSTRIDE;
+    const int krem = krem0 - tau * BK;
+    const unsigned ld2 = IS_A ? lda2 : ldb2;
+    const unsigned base = (IS_A ? va0 : vb0) + (unsigned)tau * (IS_A ? step_a : step_b) + (KM ? (unsigned)(H * 128) * ld2 : (unsigned)(H * 256));
+    const int pos = (IS_A ? pa : pb) + H * 128;   // row / first column of this lane inside the 256-wide tile (group 0)
+    const int lim = IS_A ? mrem : nrem;
+    char* dst = smem + BUF * BUFB + Q * QB + wave * GS;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned v0 = base + (KM ? (unsigned)(64 * j) * ld2 : (unsigned)(32 * j) * ld2);
+      const bool ok = ((IS_A ? kla : klb) + (KM ? 0 : 32 * j) < krem) && (pos + (KM ? 64 * j : 0) < lim);
+      dma16(IS_A ? ra : rb, dst + j * 8 * GS, ok ? v0 : OOB);
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+
+  // ---- fragment reads ----
+  // k-major: per-lane byte offset of (row, chunk 2kk + hi) inside a half image; rows wm*64 + i*32 + lrow share one swizzle
+  const int swr = (lrow >> 1) & 7;
+  const int arow = (wm * 64 + lrow) * 128, brow = (wn * 32 + lrow) * 128;
+  // mn-major: lane s of a 16-lane group addresses the 8-byte piece (k-row c = s/4, mn 4*(s%4)..+3) of its 4 x 16 block
+  const int trl = ((lane & 15) >> 2) * GSTRIDE + hi * 512 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  auto read_tr = [&](Frag<T>& f, const char* q) {
+    const v4s_t x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_t __attribute__((address_space(3)))*)(q));
+    const v4s_t y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_t __attribute__((address_space(3)))*)(q + 256));
+    u16x8 t;
+    t[0] = (unsigned short)x[0]; t[1] = (unsigned short)x[1]; t[2] = (unsigned short)x[2]; t[3] = (unsigned short)x[3];
+    t[4] = (unsigned short)y[0]; t[5] = (unsigned short)y[1]; t[6] = (unsigned short)y[2]; t[7] = (unsigned short)y[3];
+    f.v = __builtin_bit_cast(bf16x8, t);
+  };
+  auto read_a = [&](Frag<T>& f, const char* img, int i, int kk) {
+    if (AK) f.v = *reinterpret_cast<const bf16x8*>(img + arow + i * 4096 + (((2 * kk + hi) ^ swr) << 4));
+    else read_tr(f, img + trl + wm * 128 + i * 64 + kk * 4 * GSTRIDE);
+  };
+  auto read_b = [&](Frag<T>& f, const char* img, int kk) {
+    if (BKM) f.v = *reinterpret_cast<const bf16x8*>(img + brow + (((2 * kk + hi) ^ swr) << 4));
+    else read_tr(f, img + trl + wn * 64 + kk * 4 * GSTRIDE);
+  };
+
+  // acc[m tile: h*2 + i][n tile: h'] in the SWAPPED layout (A-operand = B fragment): lane -> output row (lrow), register r ->
+  // output column 8*(r/4) + 4*hi + r%4 of the 32 x 32 tile.
+  f32x16 acc[4][2];
+  Frag<T> fa[2][4], fb0[4], fb1[4];
+
+  auto mfma_quadrant = [&](auto hmc, auto hnc) {
+    constexpr int HM = decltype(hmc)::value, HN = decltype(hnc)::value;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) mma16(acc[HM * 2 + i][HN], HN ? fb1[kk] : fb0[kk], fa[i][kk]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // one K tile = 4 phases; BUF = the buffer holding tile t
+  auto tile_body = [&](auto bufc, int t, int S) {
+    constexpr int BUF = decltype(bufc)::value;
+    using BC = std::integral_constant<int, BUF>;
+    using BN_ = std::integral_constant<int, BUF ^ 1>;
+    const char* img = smem + BUF * BUFB;
+    const int s0 = 7 + 4 * t;
+    // ---- phase 1: B0, A0 -> Q00 ----
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) read_b(fb0[kk], img + 0 * QB, kk);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) read_a(fa[i][kk], img + 1 * QB, i, kk);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s0 < S) stage(I3{}, BN_{}, t + 1);
+    wait_lgkm<AK ? 8 : 15>();  // the B0 reads (issued first) are retired: B0 may be restaged next phase
+    __builtin_amdgcn_s_barrier();
+    wait_lgkm<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_quadrant(I0{}, I0{});
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 2: B1 -> Q01 ----
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) read_b(fb1[kk], img + 2 * QB, kk);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s0 + 1 < S) stage(I0{}, BC{}, t + 2);
+    __builtin_amdgcn_s_barrier();
+    wait_lgkm<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_quadrant(I0{}, I1{});
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 3: A1 -> Q11 ----
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) read_a(fa[i][kk], img + 3 * QB, i, kk);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s0 + 2 < S) stage(I1{}, BC{}, t + 2);
+    __builtin_amdgcn_s_barrier();
+    wait_lgkm<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_quadrant(I1{}, I1{});
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 4: no reads -> Q10; the next K tile must have landed ----
+    if (s0 + 3 < S) stage(I2{}, BC{}, t + 2);
+    if (s0 + 4 <= S) wait_vm<6>();
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_quadrant(I1{}, I0{});
+    __builtin_amdgcn_s_barrier();
+  };
+
+  // the epilogue image lives in the buffer-1 region (buffer 0 is receiving the next item's first K tile)
+  char* const ebase = smem + BUFB;
+
+  int v = blockIdx.x;
+  if (v >= total) return;
+  setup(v);
+  {
+    const int S = 4 * nt;
+    if (0 < S) stage(I0{}, I0{}, 0);
+    if (1 < S) stage(I1{}, I0{}, 0);
+    if (2 < S) stage(I2{}, I0{}, 0);
+    if (3 < S) stage(I3{}, I0{}, 0);
+  }
+  while (true) {
+    // ---- the item being computed (its first K tile is in flight or landed) ----
+    const int64_t e_m0 = m0, e_n0 = n0, e_cofs = cofs, e_bofs = bofs;
+    const int e_z = zcur, e_nt = nt;
+    const int S = 4 * e_nt;
+    if (4 < S) stage(I0{}, I1{}, 1);
+    if (5 < S) stage(I1{}, I1{}, 1);
+    if (6 < S) stage(I2{}, I1{}, 1);
+    if (7 <= S) wait_vm<6>();
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if (bias_in_acc) {
+#pragma unroll
+      for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const uint2 raw = *reinterpret_cast<const uint2*>(bias_lds + (hn * 128 + wn * 32 + 8 * g + 4 * hi) * 2);
+          const float b0 = __uint_as_float(raw.x << 16), b1 = __uint_as_float(raw.x & 0xffff0000u);
+          const float b2 = __uint_as_float(raw.y << 16), b3 = __uint_as_float(raw.y & 0xffff0000u);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            acc[i][hn][4 * g] = b0; acc[i][hn][4 * g + 1] = b1; acc[i][hn][4 * g + 2] = b2; acc[i][hn][4 * g + 3] = b3;
+          }
+        }
+      wait_lgkm<0>();
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    }
+    if (wm == 1) __builtin_amdgcn_s_barrier();  // stagger: the wm = 1 waves run one barrier behind
+    for (int t = 0; t < e_nt; t += 2) {
+      tile_body(I0{}, t, S);
+      if (t + 1 < e_nt) tile_body(I1{}, t + 1, S);
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+
+    // ---- start streaming the next item before this one's epilogue ----
+    v += gridDim.x;
+    const bool has_next = v < total;
+    if (has_next) {
+      setup(v);
+      const int Sn = 4 * nt;
+      if (0 < Sn) stage(I0{}, I0{}, 0);
+      if (1 < Sn) stage(I1{}, I0{}, 0);
+      if (2 < Sn) stage(I2{}, I0{}, 0);
+      if (3 < Sn) stage(I3{}, I0{}, 0);
+    }
+
+    asm volatile("" : "+s"(kp));
+    GemmParams q;  // epilogue parameters, re-read after the K loop (only the fields used below are materialised)
+    q.M = kp->M; q.N = kp->N; q.C = kp->C; q.ldc = kp->ldc; q.bias = kp->bias; q.bias_mode = kp->bias_mode; q.act = kp->act;
+    q.aux_out = kp->aux_out; q.ld_aux_out = kp->ld_aux_out; q.dact = kp->dact; q.aux_in = kp->aux_in; q.ld_aux_in = kp->ld_aux_in;
+    q.resid = kp->resid; q.ld_resid = kp->ld_resid; q.alpha = kp->alpha; q.splits = kp->splits; q.ws = kp->ws;
+    q.c_f32 = kp->c_f32; q.vec_epi = kp->vec_epi;
+    if (fast_epi) {
+      // bf16 image [128 rows][256 cols], row stride 528 B; pass hm = rows [128 hm, 128 hm + 128) of the tile
+      constexpr int ERS = 528;
+#pragma unroll
+      for (int hm = 0; hm < 2; ++hm) {
+        if (hm) __builtin_amdgcn_s_barrier();  // previous pass fully read back
+        // the pass's extra operand (act'(aux_in), or the residual when there is no aux_in) is fetched first: 8 independent
+        // 16-byte loads per lane in flight under the LDS staging instead of one dependent load per output vector
+        const T* exsrc = q.dact ? (const T*)q.aux_in : (const T*)q.resid;
+        const int64_t exld = q.dact ? q.ld_aux_in : q.ld_resid;
+        auto ex_load = [&](int it) -> u32x4 {
+          const int vi = tid + NTHREADS * it;
+          const int64_t row = e_m0 + hm * 128 + (vi >> 5), col = e_n0 + (vi & 31) * 8;
+          u32x4 r = {0, 0, 0, 0};
+          if (exsrc && it < 8 && row < q.M && col < q.N) r = *reinterpret_cast<const u32x4*>(exsrc + e_cofs + row * exld + col);
+          return r;
+        };
+        u32x4 ex0 = ex_load(0), ex1 = ex_load(1), ex2 = ex_load(2), ex3 = ex_load(3);  // rotating 4-deep window
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+              bf16x4_t pk;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) pk[e] = static_cast<__bf16>(acc[hm * 2 + i][hn][4 * g + e] * q.alpha);
+              *reinterpret_cast<bf16x4_t*>(ebase + (wm * 64 + i * 32 + lrow) * ERS + (hn * 128 + wn * 32 + 8 * g + 4 * hi) * 2) = pk;
+            }
+        wait_lgkm<0>();
+        __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+        for (int it = 0; it < 8; ++it) {
+          const u32x4 exv = ex0;
+          ex0 = ex1; ex1 = ex2; ex2 = ex3; ex3 = ex_load(it + 4);
+          const int vi = tid + NTHREADS * it;
+          const int rl = vi >> 5, cl = (vi & 31) * 8;
+          const int64_t row = e_m0 + hm * 128 + rl, col = e_n0 + cl;
+          if (row >= q.M || col >= q.N) continue;
+          const u32x4 zraw = *reinterpret_cast<const u32x4*>(ebase + rl * ERS + cl * 2);
+          if (q.aux_out) *reinterpret_cast<u32x4*>((T*)q.aux_out + e_cofs + row * q.ld_aux_out + col) = zraw;
+          T* cdst = (T*)q.C + e_cofs + row * q.ldc + col;
+          if (q.act == CST_ACT_NONE && !exsrc) {
+            *reinterpret_cast<u32x4*>(cdst) = zraw;
+            continue;
+          }
+          float x[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            x[2 * e] = __uint_as_float(zraw[e] << 16);
+            x[2 * e + 1] = __uint_as_float(zraw[e] & 0xffff0000u);
+          }
+          if (q.act == CST_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.0f);
+          } else if (q.act == CST_ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = gelu_f(x[e]);
+          }
+          if (q.dact) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              x[2 * e] *= dact_f(__uint_as_float(exv[e] << 16), q.dact);
+              x[2 * e + 1] *= dact_f(__uint_as_float(exv[e] & 0xffff0000u), q.dact);
+            }
+            if (q.resid) {
+              float rr[8];
+              load8((const T*)q.resid + e_cofs + row * q.ld_resid + col, rr);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) x[e] += rr[e];
+            }
+          } else if (q.resid) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              x[2 * e] += __uint_as_float(exv[e] << 16);
+              x[2 * e + 1] += __uint_as_float(exv[e] & 0xffff0000u);
+            }
+          }
+          store8(cdst, x);
+        }
+      }
+    } else {
+      // fp32 image, 64 rows x (BN + 4) per pass; pass ps = rows [64 ps, 64 ps + 64) = half ps/2 of the wm = ps%2 waves
+      constexpr int LDC = BN + 4;
+      constexpr int VPR = BN / 8;
+      constexpr int ITERS = 64 * VPR / NTHREADS;
+      float* stg = reinterpret_cast<float*>(ebase);
+      float* wsp = q.splits > 1 ? q.ws + ((int64_t)e_z) * q.M * q.N : nullptr;
+      const bool ws_vec = (q.N % 4) == 0;
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        if (ps) __builtin_amdgcn_s_barrier();
+        if (wm == (ps & 1)) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                f32x4 q;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) q[e] = acc[(ps >> 1) * 2 + i][hn][4 * g + e];
+                *reinterpret_cast<f32x4*>(stg + (i * 32 + lrow) * LDC + hn * 128 + wn * 32 + 8 * g + 4 * hi) = q;
+              }
+        }
+        wait_lgkm<0>();
+        __builtin_amdgcn_s_barrier();
+#pragma unroll 2
+        for (int itv = 0; itv < ITERS; ++itv) {
+          const int vi = tid + NTHREADS * itv;
+          const int rl = vi / VPR, cl = (vi % VPR) * 8;
+          const int64_t row = e_m0 + 64 * ps + rl, col = e_n0 + cl;
+          if (row >= q.M || col >= q.N) continue;
+          float x[8];
+          {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(stg + rl * LDC + cl);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(stg + rl * LDC + cl + 4);
+            x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
+          }
+          const bool full = col + 8 <= q.N;
+          if (wsp) {
+            if (full && ws_vec) store8(wsp + row * q.N + col, x);
+            else
+              for (int e = 0; e < 8 && col + e < q.N; ++e) wsp[row * q.N + col + e] = x[e];
+          } else if (full && q.vec_epi) {
+            epilogue_store8<T>(q, e_cofs, e_bofs, row, col, x);
+          } else {
+            for (int e = 0; e < 8 && col + e < q.N; ++e) epilogue_store<T>(q, e_cofs, e_bofs, row, col + e, x[e]);
+          }
+        }
+      }
+    }
+    if (!has_next) break;
+    __builtin_amdgcn_s_barrier();  // the image is fully read back: buffer 1 may receive the next item's second K tile
+  }
+}
+
+template <bool AK, bool BKM>
+int launch8p(GemmParams p, int64_t nbatch, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_kernel<AK, BKM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  p.tiles_m = (int)cst_ceil_div(p.M, BM);
+  p.tiles_n = (int)cst_ceil_div(p.N, BN);
+  p.nz = (int)(nbatch * p.splits);
+  const int64_t total = (int64_t)p.tiles_m * p.tiles_n * p.nz;
+  static const int ncu = [] {
+    int dev = 0, n = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  dim3 grid((unsigned)(total < ncu ? total : ncu), 1, 1);
+  hipLaunchKernelGGL((gemm8p_kernel<AK, BKM>), grid, dim3(NTHREADS), LDS_BYTES + 1024, s, p);
+  return cst_check_launch("cst_gemm (8-phase)");
+}
+
+}  // namespace
+
+// The per-lane DMA offsets are 32-bit byte offsets from the tile's first element and must stay below the descriptors' 2 GiB.
+bool cst_gemm8p_supported(const cstg::GemmParams& p, bool ak, bool bk, int64_t nbatch) {
+  (void)nbatch;
+  if (p.a_seg || p.b_seg) return false;
+  const int64_t lim = (int64_t)1 << 31;
+  const int64_t ea = ak ? (256 * p.lda + p.K) * 2 : (p.K + 64) * p.lda * 2;
+  const int64_t eb = bk ? (256 * p.ldb + p.K) * 2 : (p.K + 64) * p.ldb * 2;
+  return ea < lim && eb < lim && p.lda > 0 && p.ldb > 0;
+}
+
+int cst_gemm8p_launch(cstg::GemmParams p, bool ak, bool bk, int64_t nbatch, hipStream_t s) {
+  if (ak) return bk ? launch8p<true, true>(p, nbatch, s) : launch8p<true, false>(p, nbatch, s);
+  return bk ? launch8p<false, true>(p, nbatch, s) : launch8p<false, false>(p, nbatch, s);
+}

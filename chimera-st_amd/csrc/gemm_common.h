@@ -1,0 +1,89 @@
+// gemm_common.h — launch parameters and the fused epilogue shared by every GEMM kernel of libcst_hip (gemm.hip, gemm8p.hip).
+#pragma once
+#include "cst_common.h"
+
+namespace cstg {
+
+struct GemmParams {
+  int64_t M, N, K;
+  const void* A; int64_t lda, a_seg, a_seg_stride;
+  const void* B; int64_t ldb, b_seg, b_seg_stride;
+  void* C; int64_t ldc;
+  const void* bias; int bias_mode; int64_t sbias0, sbias1;
+  int act;
+  void* aux_out; int64_t ld_aux_out;
+  int dact;
+  const void* aux_in; int64_t ld_aux_in;
+  const void* resid; int64_t ld_resid;
+  float alpha;
+  int64_t batch1;
+  int64_t sa0, sa1, sb0, sb1, sc0, sc1;
+  int splits;
+  float* ws;  // split-K partials [batch][split][M][N]
+  int c_f32;
+  int vec_epi;  // all epilogue operands 16-byte aligned -> staged, vectorised epilogue
+  int tiles_m, tiles_n;
+  int nz;  // persistent kernels: number of (batch, split) slices
+};
+
+__device__ __forceinline__ int64_t segaddr(int64_t c, int64_t seg, int64_t seg_stride) {
+  return seg ? (c / seg) * seg_stride + (c % seg) : c;
+}
+
+template <typename T>
+__device__ __forceinline__ void epilogue_store(const GemmParams& p, int64_t cofs, int64_t bofs, int64_t row, int64_t col, float v) {
+  v *= p.alpha;
+  if (p.bias_mode == CST_BIAS_COL) v += DT<T>::ld((const T*)p.bias + bofs + col);
+  else if (p.bias_mode == CST_BIAS_ROW) v += DT<T>::ld((const T*)p.bias + bofs + row);
+  if (p.aux_out) DT<T>::st((T*)p.aux_out + cofs + row * p.ld_aux_out + col, v);
+  v = act_f(v, p.act);
+  if (p.dact) v *= dact_f(DT<T>::ld((const T*)p.aux_in + cofs + row * p.ld_aux_in + col), p.dact);
+  if (p.resid) v += DT<T>::ld((const T*)p.resid + cofs + row * p.ld_resid + col);
+  if (p.c_f32) ((float*)p.C)[cofs + row * p.ldc + col] = v;
+  else DT<T>::st((T*)p.C + cofs + row * p.ldc + col, v);
+}
+
+// 8 consecutive columns of one row: the same epilogue as epilogue_store, with 16-byte global accesses.
+template <typename T>
+__device__ __forceinline__ void epilogue_store8(const GemmParams& p, int64_t cofs, int64_t bofs, int64_t row, int64_t col, float (&v)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+  if (p.bias_mode == CST_BIAS_COL) {
+    float b[8];
+    load8((const T*)p.bias + bofs + col, b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += b[e];
+  } else if (p.bias_mode == CST_BIAS_ROW) {
+    const float b = DT<T>::ld((const T*)p.bias + bofs + row);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += b;
+  }
+  if (p.aux_out) store8((T*)p.aux_out + cofs + row * p.ld_aux_out + col, v);
+  if (p.act == CST_ACT_RELU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
+  } else if (p.act == CST_ACT_GELU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+  }
+  if (p.dact) {
+    float z[8];
+    load8((const T*)p.aux_in + cofs + row * p.ld_aux_in + col, z);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= dact_f(z[e], p.dact);
+  }
+  if (p.resid) {
+    float r[8];
+    load8((const T*)p.resid + cofs + row * p.ld_resid + col, r);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += r[e];
+  }
+  if (p.c_f32) store8((float*)p.C + cofs + row * p.ldc + col, v);
+  else store8((T*)p.C + cofs + row * p.ldc + col, v);
+}
+
+}  // namespace cstg
+
+// gemm8p.hip: 256 x 256 x 64 bf16 tile, 8 waves, 8-phase DMA pipeline.  Returns CST_OK after the launch.
+int cst_gemm8p_launch(cstg::GemmParams p, bool a_kmajor, bool b_kmajor, int64_t nbatch, hipStream_t s);
+bool cst_gemm8p_supported(const cstg::GemmParams& p, bool a_kmajor, bool b_kmajor, int64_t nbatch);

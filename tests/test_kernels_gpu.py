@@ -389,3 +389,21 @@ def test_conv_stack_windowed_dx(dt, Lin):
     check(x.grad, xr.grad, dt, "conv stack dX", scale=float(xr.grad.abs().max()) * (1 if dt == torch.float32 else 2))
     for i in range(len(spec)):
         check(ws[i].grad, wr[i].grad, dt, "conv stack dW%d" % i, scale=float(wr[i].grad.abs().max()) * (1 if dt == torch.float32 else 2))
+
+
+@pytest.mark.parametrize("ak,bk", [(1, 1), (1, 0), (0, 1), (0, 0)])
+@pytest.mark.parametrize("M,N,K_", [(3608, 3592, 328), (512, 1024, 16648), (4096, 4096, 64)])
+def test_gemm_8phase_large(K, ak, bk, M, N, K_):
+    """bf16 problems that fill the chip take the 256x256x64 8-phase DMA kernel (gemm8p.hip): ragged M/N/K edges, a K
+    shorter than the prologue depth, and split-K with empty trailing splits."""
+    k, L = K
+    dt = torch.bfloat16
+    A = rnd(M, K_, dt=dt, seed=1) if ak else rnd(K_, M, dt=dt, seed=1)
+    B = rnd(N, K_, dt=dt, seed=2) if bk else rnd(K_, N, dt=dt, seed=2)
+    bias = rnd(N, dt=dt, seed=3)
+    C = torch.empty(M, N, dtype=dt, device="cuda")
+    k.gemm(A, B, C, M, N, K_, a_kmajor=ak, b_kmajor=bk, lda=A.shape[1], ldb=B.shape[1], ldc=N, bias=bias, act=L.ACT_RELU)
+    Af = A.float() if ak else A.float().t()
+    Bf = B.float() if bk else B.float().t()
+    ref = torch.relu(Af @ Bf.t() + bias.float())
+    check(C, ref, dt, "8-phase gemm %d%d %dx%dx%d" % (ak, bk, M, N, K_))
