@@ -35,15 +35,20 @@ def build(args, device):
     reg = importlib.import_module("chimera-st_amd.registry")
     w2v = importlib.import_module("chimera-st_amd.wav2vec2")
     Trainer = importlib.import_module("chimera-st_amd.trainer").Trainer
-    # wav2vec_small hyper-parameters; dropout/layerdrop 0 so every layer runs every step
-    w2t.SYNTHETIC_W2V["wav2vec_small_bench"] = w2v.wav2vec_small_args(dropout=0.0, attention_dropout=0.0, activation_dropout=0.0,
-                                                                     encoder_layerdrop=0.0, dropout_input=0.0, dropout_features=0.0)
+    # wav2vec_small hyper-parameters.  --dropout 0.1 (default) is the training recipe: dropout = attention_dropout
+    # = 0.1, dropout_input 0.1 in wav2vec2 (activation_dropout 0.0 there), dropout = attention = activation 0.1 in the
+    # s2t transformer (w2v2_transformer.py:458-460); --dropout 0 switches every site off (the parity configuration).
+    # layerdrop (wav2vec_small: 0.05) is off by default so that every step executes the same, full amount of work.
+    dp = float(getattr(args, "dropout", 0.1))
+    w2t.SYNTHETIC_W2V["wav2vec_small_bench"] = w2v.wav2vec_small_args(
+        dropout=dp, attention_dropout=dp, activation_dropout=0.0, encoder_layerdrop=float(getattr(args, "layerdrop", 0.0)),
+        dropout_input=dp, dropout_features=dp)
     chimera = args.model == "chimera"
     ns = Namespace(
         arch="s2t_transformer_w2v2_interlingua_base" if chimera else "s2t_transformer_w2v2",
         task="triplet", criterion="triplet_st_mt_contrastive" if chimera else "label_smoothed_cross_entropy",
         w2v2_model_path="synthetic:wav2vec_small_bench", data=None, synthetic_vocab_size=10000,
-        dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, share_decoder_input_output_embed=True,
+        dropout=dp, attention_dropout=dp, activation_dropout=dp, share_decoder_input_output_embed=True,
         max_source_positions=2000000, max_target_positions=1024, label_smoothing=0.1,
         bf16=(args.dtype == "bf16"), lr=[2e-4], adam_betas="(0.9, 0.98)", adam_eps=1e-8, weight_decay=0.0, clip_norm=10.0,
         warmup_updates=4000, warmup_init_lr=1e-7, seed=1, bucket_cap_mb=64,
@@ -117,6 +122,8 @@ def main():
     ap.add_argument("--lengths", default="uniform", choices=["uniform", "max"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--model", default="s2t_w2v2", choices=["s2t_w2v2", "chimera"])
+    ap.add_argument("--dropout", type=float, default=0.1, help="training-recipe dropout (0 = every dropout site off)")
+    ap.add_argument("--layerdrop", type=float, default=0.0, help="wav2vec2 encoder_layerdrop (wav2vec_small: 0.05)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=30.0)
     ap.add_argument("--no-roofline", action="store_true")
@@ -189,7 +196,7 @@ def main():
                                     "Chimera s2t_transformer_w2v2_interlingua_base (6 enc + 3 memory layers, M=64) + wav2vec2-small, "
                                     "triplet_st_mt_contrastive, Adam"),
                        "batch_per_gpu": args.batch, "global_batch": world * args.batch, "max_audio_s": args.seconds,
-                       "audio_lengths": args.lengths, "target_tokens": "16-128", "vocab": 10000, "dropout": 0.0,
+                       "audio_lengths": args.lengths, "target_tokens": "16-128", "vocab": 10000, "dropout": args.dropout, "w2v_layerdrop": args.layerdrop,
                        "parallelism": "dp%d" % world, "loss": float(out["loss"])},
             "roofline": roof, "cpu_baseline": cpu,
         }

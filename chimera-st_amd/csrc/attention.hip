@@ -36,6 +36,7 @@ struct AttnParams {
   void *dQ, *dK, *dV;
   int64_t dq_sb, dq_sh, dq_st, dk_sb, dk_sh, dk_st, dv_sb, dv_sh, dv_st;
   float* delta;
+  uint32_t drop_thr, drop_key; float drop_scale;  // attention-probability dropout (drop_thr == 0: none)
 };
 
 // the row (within a 32-row MFMA tile) that k-slot j of half-wave `hi` holds for the 16-row step t
@@ -95,7 +96,7 @@ __device__ __forceinline__ void store_dcol(T* g, const f32x16& acc, int d0, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-template <typename T, int D>
+template <typename T, int D, bool DROP>
 __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_fwd_kernel(AttnParams p) {
   constexpr int VEC = DT<T>::VEC, LD = D + VEC, TILE = KT * LD;
   // dynamic LDS: 2 stages x {K tile, V tile} + 2 x KT mask bytes; stage addresses are always smem + stage * 2*TILE
@@ -111,6 +112,11 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_fwd_ke
   const T* Vg = (const T*)p.V + b * p.v_sb + h * p.v_sh;
   const int cshift = (int)(p.Tk - p.Tq);  // causal: key j visible to query i iff j <= i + cshift
   const float c2 = p.scale * 1.4426950408889634f;  // softmax in the exp2 domain: p = 2^(s*c2 - m)
+  // attention dropout (modules/multihead_attention.py:359): element (b,h,q,k) of the probability tensor has index
+  // ((b*H + h)*Tq + q) * Tkp + k with Tkp = Tk rounded up to even, so one mask word serves keys (2j, 2j+1) of a query
+  const uint32_t dkey2 = cst_drop_key2(p.drop_key);
+  const uint32_t hp = (uint32_t)((p.Tk + 1) >> 1);
+  const uint32_t rowpair = (uint32_t)((b * p.H + h) * p.Tq + q) * hp;
 
   Frag<T> fq[D / 16];
   load_row_frags<T, D>(fq, Qg, p.q_st, q, (int)p.Tq, lane);
@@ -200,6 +206,19 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_fwd_ke
         }
       l_run = l_run * alpha + ls;
       m_run = m_new;
+      if (DROP) {  // dropped probabilities leave the PV product; the row sum (normaliser) keeps them
+        const uint32_t base = rowpair + (uint32_t)((j0 >> 1) + 2 * hi);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const uint32_t bits = cst_drop_bits32(p.drop_key, dkey2, base + ks * 16 + 4 * g + t);
+              s[ks][4 * g + 2 * t] = (bits & 0xffffU) >= p.drop_thr ? s[ks][4 * g + 2 * t] : 0.0f;
+              s[ks][4 * g + 2 * t + 1] = (bits >> 16) >= p.drop_thr ? s[ks][4 * g + 2 * t + 1] : 0.0f;
+            }
+      }
     } else {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -233,7 +252,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_fwd_ke
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   if (q < p.Tq) {
-    const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+    const float inv = l_tot > 0.0f ? p.drop_scale / l_tot : 0.0f;
     T* Og = (T*)p.O + b * p.o_sb + h * p.o_sh + (int64_t)q * p.o_st;
 #pragma unroll
     for (int dt = 0; dt < D / 32; ++dt) store_dcol<T>(Og, o[dt], dt * 32, lane, inv);
@@ -264,7 +283,7 @@ __global__ void attn_delta_kernel(AttnParams p) {
 
 // ---------------------------------------------------------------------------------------------
 // dQ: per wave 32 queries (lane-local query column), loop over KV tiles.
-template <typename T, int D>
+template <typename T, int D, bool DROP>
 __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_bwd_dq_kernel(AttnParams p) {
   constexpr int VEC = DT<T>::VEC, LD = D + VEC, TILE = KT * LD;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -280,6 +299,9 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_bwd_dq
   const T* dOg = (const T*)p.dO + b * p.do_sb + h * p.do_sh;
   const int cshift = (int)(p.Tk - p.Tq);
   const float c2 = p.scale * 1.4426950408889634f;
+  const uint32_t dkey2 = cst_drop_key2(p.drop_key);
+  const uint32_t hp = (uint32_t)((p.Tk + 1) >> 1);
+  const uint32_t rowpair = (uint32_t)((b * p.H + h) * p.Tq + q) * hp;
 
   Frag<T> fq[D / 16], fdo[D / 16];
   load_row_frags<T, D>(fq, Qg, p.q_st, q, (int)p.Tq, lane);
@@ -342,6 +364,17 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_bwd_dq
         mma16(s, fk, fq[kk]);     // S^T[key][q]
         mma16(dp, fv, fdo[kk]);   // dP^T[key][q] = V dO^T
       }
+      if (DROP) {  // dP = (dO V^T) * keep / (1 - p): the same mask words as the forward pass
+        const uint32_t base = rowpair + (uint32_t)((j0 >> 1) + 2 * hi) + ks * 16;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const uint32_t bits = cst_drop_bits32(p.drop_key, dkey2, base + 4 * g + t);
+            dp[4 * g + 2 * t] = (bits & 0xffffU) >= p.drop_thr ? dp[4 * g + 2 * t] * p.drop_scale : 0.0f;
+            dp[4 * g + 2 * t + 1] = (bits >> 16) >= p.drop_thr ? dp[4 * g + 2 * t + 1] * p.drop_scale : 0.0f;
+          }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float pr = row_dead ? 0.0f : __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse));
@@ -378,7 +411,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_bwd_dq
 }
 
 // dK,dV: per wave 32 keys (lane-local key column), loop over Q tiles of 64 queries.
-template <typename T, int D>
+template <typename T, int D, bool DROP>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnParams p) {
   constexpr int VEC = DT<T>::VEC, LD = D + VEC, TILE = KT * LD;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -394,6 +427,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnParams p) 
   const T* dOg = (const T*)p.dO + b * p.do_sb + h * p.do_sh;
   const int cshift = (int)(p.Tk - p.Tq);
   const float c2 = p.scale * 1.4426950408889634f;
+  // here a lane owns one key and its registers run over queries, so every element needs its own mask word (the word of the
+  // key pair (key & ~1, key | 1) in that query's row); this lane's half of the word is `dsh`
+  const uint32_t dkey2 = cst_drop_key2(p.drop_key);
+  const uint32_t hp = (uint32_t)((p.Tk + 1) >> 1);
+  const uint32_t dsh = (uint32_t)(key & 1) * 16;
+  const uint32_t rowpair0 = (uint32_t)((b * p.H + h) * p.Tq) * hp + (uint32_t)(key >> 1) + (uint32_t)(4 * hi) * hp;
 
   Frag<T> fk[D / 16], fv[D / 16];
   load_row_frags<T, D>(fk, Kg, p.k_st, key, (int)p.Tk, lane);
@@ -453,6 +492,22 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnParams p) 
       }
       f32x16 pr;
       const bool diag = p.causal && (k_blk0 + wave * QB + QB - 1 > (int)i0 + qs * 32 + cshift);  // wave-uniform: tile touches the future
+      // dropout: lanes (2i, 2i+1) own keys (k, k+1) = the two halves of ONE mask word per query.  Each lane hashes the words of
+      // half of the register pairs' queries (even lane: registers 2j, odd lane: 2j+1) and the neighbours swap them by DPP.
+      uint32_t keepbits = 0;  // bit r: element r of this tile column is kept
+      if (DROP) {
+        const uint32_t odd = (uint32_t)lane & 1u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r0 = 2 * j;  // query rows of registers r0 and r0 + 1 differ by one
+          const uint32_t qrow = (uint32_t)((int)i0 + qs * 32 + (r0 & 3) + 8 * (r0 >> 2)) + odd;
+          const uint32_t mine = cst_drop_bits32(p.drop_key, dkey2, rowpair0 + qrow * hp);
+          const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+          const uint32_t w0 = odd ? other : mine, w1 = odd ? mine : other;
+          keepbits |= (((w0 >> dsh) & 0xffffU) >= p.drop_thr ? 1u : 0u) << r0;
+          keepbits |= (((w1 >> dsh) & 0xffffU) >= p.drop_thr ? 1u : 0u) << (r0 + 1);
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int qr = qs * 32 + acc_row(r, lane);
@@ -460,8 +515,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnParams p) 
         float e = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -l));  // l = -inf (dead / out-of-range row): handled below
         e = (key_masked || l == -INFINITY) ? 0.0f : e;
         if (diag) e = (key > (int)i0 + qr + cshift) ? 0.0f : e;
-        pr[r] = e;
-        s[r] = e * (dp[r] - sD[qr]);  // dS[q][key]
+        float dpr = dp[r];
+        if (DROP) {
+          const bool keep = (keepbits >> r) & 1u;
+          dpr = keep ? dpr * p.drop_scale : 0.0f;
+          pr[r] = keep ? e * p.drop_scale : 0.0f;   // dV uses the dropped, rescaled probabilities
+        } else {
+          pr[r] = e;
+        }
+        s[r] = e * (dpr - sD[qr]);  // dS[q][key]
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -515,6 +577,11 @@ int fill_params(const cst_attn_desc* d, AttnParams& p, bool bwd) {
   p.o_sb = d->o_sb; p.o_sh = d->o_sh; p.o_st = d->o_st;
   p.lse = d->lse; p.kpm = d->key_padding_mask; p.kpm_stride = d->kpm_stride;
   p.causal = d->causal; p.scale = d->scale;
+  CST_REQUIRE(d->drop_p >= 0.0f && d->drop_p < 1.0f, "cst_attn: drop_p must be in [0, 1)");
+  CST_REQUIRE(d->drop_p == 0.0f || (double)d->B * d->H * d->Tq * ((d->Tk + 1) / 2) < 4294967296.0, "cst_attn: dropout index space exceeds 2^33 elements");
+  p.drop_thr = d->drop_p > 0.0f ? cst_drop_thr16(d->drop_p) : 0u;
+  p.drop_key = d->drop_key;
+  p.drop_scale = d->drop_p > 0.0f ? 1.0f / (1.0f - d->drop_p) : 1.0f;
   p.dO = d->dO; p.do_sb = d->do_sb; p.do_sh = d->do_sh; p.do_st = d->do_st;
   p.dQ = d->dQ; p.dK = d->dK; p.dV = d->dV;
   p.dq_sb = d->dq_sb; p.dq_sh = d->dq_sh; p.dq_st = d->dq_st;
@@ -553,11 +620,13 @@ extern "C" int cst_attn_fwd(const cst_attn_desc* d, cst_stream stream) {
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)cst_ceil_div(d->Tq, NW * QB), (unsigned)d->H, (unsigned)d->B);
   CstProfScope prof(CST_K_ATTN_FWD, s, attn_flops(d, 2.0), 0.0);
-#define CST_FWD(T, DD) do { const size_t lds = attn_lds_bytes<T, DD>(); attn_set_lds(reinterpret_cast<const void*>(&attn_fwd_kernel<T, DD>)); \
-    hipLaunchKernelGGL((attn_fwd_kernel<T, DD>), grid, dim3(NW * 64), lds, s, p); } while (0)
+#define CST_FWD1(T, DD, DR) do { const size_t lds = attn_lds_bytes<T, DD>(); attn_set_lds(reinterpret_cast<const void*>(&attn_fwd_kernel<T, DD, DR>)); \
+    hipLaunchKernelGGL((attn_fwd_kernel<T, DD, DR>), grid, dim3(NW * 64), lds, s, p); } while (0)
+#define CST_FWD(T, DD) do { if (p.drop_thr) CST_FWD1(T, DD, true); else CST_FWD1(T, DD, false); } while (0)
   if (d->dtype == CST_BF16) { if (d->D == 64) CST_FWD(bf16_t, 64); else CST_FWD(bf16_t, 32); }
   else { if (d->D == 64) CST_FWD(float, 64); else CST_FWD(float, 32); }
 #undef CST_FWD
+#undef CST_FWD1
   return cst_check_launch("cst_attn_fwd");
 }
 
@@ -570,17 +639,19 @@ extern "C" int cst_attn_bwd(const cst_attn_desc* d, cst_stream stream) {
   const int64_t rows = d->B * d->H * d->Tq;
   dim3 gq((unsigned)cst_ceil_div(d->Tq, NW * QB), (unsigned)d->H, (unsigned)d->B);
   dim3 gk((unsigned)cst_ceil_div(d->Tk, NW * QB), (unsigned)d->H, (unsigned)d->B);
-#define CST_BWD(T, DD)                                                                                     \
+#define CST_BWD1(T, DD, DR)                                                                                \
   do {                                                                                                     \
     hipLaunchKernelGGL((attn_delta_kernel<T, DD>), dim3((unsigned)cst_ceil_div(rows, 256)), dim3(256), 0, s, p); \
     const size_t lds = attn_lds_bytes<T, DD>();                                                              \
-    attn_set_lds(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<T, DD>));                                 \
-    attn_set_lds(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<T, DD>));                                \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DD>), gq, dim3(NW * 64), lds, s, p);                          \
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DD>), gk, dim3(NW * 64), lds, s, p);                         \
+    attn_set_lds(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<T, DD, DR>));                             \
+    attn_set_lds(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<T, DD, DR>));                            \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DD, DR>), gq, dim3(NW * 64), lds, s, p);                      \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DD, DR>), gk, dim3(NW * 64), lds, s, p);                     \
   } while (0)
+#define CST_BWD(T, DD) do { if (p.drop_thr) CST_BWD1(T, DD, true); else CST_BWD1(T, DD, false); } while (0)
   if (d->dtype == CST_BF16) { if (d->D == 64) CST_BWD(bf16_t, 64); else CST_BWD(bf16_t, 32); }
   else { if (d->D == 64) CST_BWD(float, 64); else CST_BWD(float, 32); }
 #undef CST_BWD
+#undef CST_BWD1
   return cst_check_launch("cst_attn_bwd");
 }

@@ -105,6 +105,47 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---------------------------------------------------------------------------------------
+// Dropout masks are COUNTER-BASED: the keep/drop decision of element `idx` of a dropout site is a pure function of
+// (key, idx), so backward kernels and fused epilogues regenerate the forward mask instead of storing it (the reference's
+// modules/fairseq_dropout.py stores nothing either: autograd keeps the mask tensor; here no mask tensor exists).
+//   x = (lo32(idx/2) ^ key) + hi32(idx/2) * 0x9E3779B1;  x *= 0x9E3779B1;  x = (x ^ x >> 15) + key2;  x *= 0x85EBCA77;  x ^= x >> 13
+//   (key2 = key * 0x2C1B3C6D + 0x297A2D39: the key enters twice, so two sites are not index-permutations of one sequence);
+//   one 32-bit word serves the element pair (idx & ~1, idx | 1):
+//   keep  = 16-bit half (idx & 1) of x >= thr16,  thr16 = round(p * 65536);   kept values are scaled by 1 / (1 - p).
+// 7 integer VALU ops per pair: the masks are regenerated inside VALU-bound kernels (attention softmax, GEMM epilogues).
+// `key` = host-side mix of (seed + update number, site ordinal): see chimera-st_amd/rng.py (same function in numpy).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t cst_drop_bits(uint32_t key, uint64_t pair) {
+  uint32_t x = ((uint32_t)pair ^ key) + (uint32_t)(pair >> 32) * 0x9E3779B1U;
+  x *= 0x9E3779B1U;
+  x = (x ^ (x >> 15)) + (key * 0x2C1B3C6DU + 0x297A2D39U);
+  x *= 0x85EBCA77U;
+  return x ^ (x >> 13);
+}
+// 32-bit pair index variant (tensors below 2^33 elements: attention probabilities, activations)
+__device__ __forceinline__ uint32_t cst_drop_bits32(uint32_t key, uint32_t key2, uint32_t pair) {
+  uint32_t x = (pair ^ key) * 0x9E3779B1U;
+  x = (x ^ (x >> 15)) + key2;
+  x *= 0x85EBCA77U;
+  return x ^ (x >> 13);
+}
+__device__ __forceinline__ uint32_t cst_drop_key2(uint32_t key) { return key * 0x2C1B3C6DU + 0x297A2D39U; }
+// multiply 8 consecutive elements starting at the (even) element index idx0 by their dropout factors
+__device__ __forceinline__ void cst_drop8(float (&v)[8], uint32_t key, uint64_t idx0, uint32_t thr16, float scale) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t b = cst_drop_bits(key, (idx0 >> 1) + j);
+    v[2 * j] *= (b & 0xffffU) >= thr16 ? scale : 0.0f;
+    v[2 * j + 1] *= (b >> 16) >= thr16 ? scale : 0.0f;
+  }
+}
+__device__ __forceinline__ float cst_drop1(uint32_t key, uint64_t idx, uint32_t thr16, float scale) {
+  const uint32_t b = cst_drop_bits(key, idx >> 1);
+  return (((idx & 1) ? (b >> 16) : (b & 0xffffU)) >= thr16) ? scale : 0.0f;
+}
+__host__ __device__ inline uint32_t cst_drop_thr16(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
+
 // exact GELU (erf form, modules/gelu.py:25) and its derivative.  erf via Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, below
 // fp32 rounding of the products it feeds): 1 + erf(u) = 2 - P(t) E for u >= 0 and P(t) E for u < 0, with t = 1/(1 + p|u|),
 // E = exp(-u^2) = exp(-x^2/2) — the same exponential the derivative's density term needs.  ~14 VALU ops instead of libm erff's

@@ -152,6 +152,20 @@ __global__ void mask_rows_kernel(const T* x, const uint8_t* mask, T* y, int64_t 
   }
 }
 
+// y = x * keep(key, idx) / (1 - p): FairseqDropout (modules/fairseq_dropout.py) forward AND backward (same call on dy)
+template <typename T>
+__global__ void dropout_kernel(const T* x, T* y, int64_t n, uint32_t key, uint32_t thr16, float scale) {
+  const int64_t n8 = n / 8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    float v[8];
+    load8(x + i * 8, v);
+    cst_drop8(v, key, (uint64_t)i * 8, thr16, scale);
+    store8(y + i * 8, v);
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = n8 * 8 + threadIdx.x; i < n; i += blockDim.x) DT<T>::st(y + i, DT<T>::ld(x + i) * cst_drop1(key, (uint64_t)i, thr16, scale));
+}
+
 }  // namespace
 
 #define CST_EW_DISPATCH(kern, grid, block, s, dtype, ...)                                        \
@@ -239,4 +253,18 @@ extern "C" int cst_mask_rows(const void* x, const uint8_t* mask, void* y, int64_
   if (dtype == CST_BF16) hipLaunchKernelGGL(mask_rows_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, mask, (bf16_t*)y, rows, cols);
   else hipLaunchKernelGGL(mask_rows_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, mask, (float*)y, rows, cols);
   return cst_check_launch("cst_mask_rows");
+}
+
+extern "C" int cst_dropout(const void* x, void* y, int64_t n, float p, uint32_t key, int dtype, cst_stream stream) {
+  CST_REQUIRE(x && y && n > 0 && p >= 0.0f && p < 1.0f, "cst_dropout: bad args");
+  CST_REQUIRE(dtype == CST_F32 || dtype == CST_BF16, "cst_dropout: bad dtype");
+  CST_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0), "cst_dropout: x/y must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  CstProfScope prof(CST_K_ELEMENTWISE, s, 0.0, 2.0 * n * cst_dtype_size(dtype));
+  const int blocks = ew_blocks(cst_ceil_div(n, 8));
+  const uint32_t thr = cst_drop_thr16(p);
+  const float scale = 1.0f / (1.0f - p);
+  if (dtype == CST_BF16) hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, n, key, thr, scale);
+  else hipLaunchKernelGGL(dropout_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, (float*)y, n, key, thr, scale);
+  return cst_check_launch("cst_dropout");
 }

@@ -660,6 +660,11 @@ extern "C" int cst_gemm(const cst_gemm_desc* d, cst_stream stream) {
   p.dact = d->dact; p.aux_in = d->aux_in; p.ld_aux_in = d->ld_aux_in;
   p.resid = d->resid; p.ld_resid = d->ld_resid;
   p.alpha = d->alpha;
+  CST_REQUIRE(d->drop_p >= 0.0f && d->drop_p < 1.0f, "cst_gemm: drop_p must be in [0, 1)");
+  CST_REQUIRE(d->drop_p == 0.0f || d->batch0 * d->batch1 == 1, "cst_gemm: fused dropout needs an unbatched problem");
+  p.drop_thr = d->drop_p > 0.0f ? cst_drop_thr16(d->drop_p) : 0u;
+  p.drop_key = d->drop_key;
+  p.drop_scale = d->drop_p > 0.0f ? 1.0f / (1.0f - d->drop_p) : 1.0f;
   p.batch1 = d->batch1;
   p.sa0 = d->sa0; p.sa1 = d->sa1; p.sb0 = d->sb0; p.sb1 = d->sb1; p.sc0 = d->sc0; p.sc1 = d->sc1;
   p.c_f32 = (d->c_dtype == CST_F32 && d->dtype != CST_F32) ? 1 : 0;
@@ -671,6 +676,7 @@ extern "C" int cst_gemm(const cst_gemm_desc* d, cst_stream stream) {
     if (d->aux_out) ok = ok && d->ld_aux_out % 8 == 0;
     if (d->aux_in) ok = ok && d->ld_aux_in % 8 == 0;
     if (d->resid) ok = ok && d->ld_resid % 8 == 0;
+    if (d->drop_p > 0.0f) ok = ok && (d->N % 2 == 0);  // pair-aligned mask words
     p.vec_epi = ok ? 1 : 0;
   }
   p.tiles_m = p.tiles_n = 0;  // set per configuration in launch()

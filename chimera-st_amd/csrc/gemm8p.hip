@@ -332,7 +332,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
     q.M = kp->M; q.N = kp->N; q.C = kp->C; q.ldc = kp->ldc; q.bias = kp->bias; q.bias_mode = kp->bias_mode; q.act = kp->act;
     q.aux_out = kp->aux_out; q.ld_aux_out = kp->ld_aux_out; q.dact = kp->dact; q.aux_in = kp->aux_in; q.ld_aux_in = kp->ld_aux_in;
     q.resid = kp->resid; q.ld_resid = kp->ld_resid; q.alpha = kp->alpha; q.splits = kp->splits; q.ws = kp->ws;
-    q.c_f32 = kp->c_f32; q.vec_epi = kp->vec_epi;
+    q.c_f32 = kp->c_f32; q.vec_epi = kp->vec_epi; q.drop_thr = kp->drop_thr; q.drop_key = kp->drop_key; q.drop_scale = kp->drop_scale;
     if (fast_epi) {
       // bf16 image [128 rows][256 cols], row stride 528 B; pass hm = rows [128 hm, 128 hm + 128) of the tile
       constexpr int ERS = 528;
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
           const u32x4 zraw = *reinterpret_cast<const u32x4*>(ebase + rl * ERS + cl * 2);
           if (q.aux_out) *reinterpret_cast<u32x4*>((T*)q.aux_out + e_cofs + row * q.ld_aux_out + col) = zraw;
           T* cdst = (T*)q.C + e_cofs + row * q.ldc + col;
-          if (q.act == CST_ACT_NONE && !exsrc) {
+          if (q.act == CST_ACT_NONE && !exsrc && !q.drop_thr) {
             *reinterpret_cast<u32x4*>(cdst) = zraw;
             continue;
           }
@@ -393,6 +393,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = gelu_f(x[e]);
           }
+          if (q.drop_thr) cst_drop8(x, q.drop_key, (uint64_t)(row * q.N + col), q.drop_thr, q.drop_scale);
           if (q.dact) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {

@@ -38,6 +38,18 @@ def distributed_init(backend=None):
     return rank, world
 
 
+_UNUSED_LISTENERS = []
+
+
+def notify_unused_parameters(params):
+    """Called from the forward pass when a sub-module is skipped for this update (wav2vec2 layerdrop, wav2vec2.py:836-840):
+    its parameters will never fire a gradient hook, so the reducer counts them as arrived and keeps launching buckets in
+    order during backward instead of stalling every later bucket until finish()."""
+    params = list(params)
+    for cb in _UNUSED_LISTENERS:
+        cb(params)
+
+
 class BucketedGradAllReduce:
     """Overlapped, bucketed mean-all-reduce of a flat gradient buffer."""
 
@@ -66,15 +78,30 @@ class BucketedGradAllReduce:
                 self.param_bucket[idx] = b
         self.enabled = True
         self._hooks = []
+        self._index = {id(p): idx for idx, p in enumerate(self.params)}
         for idx, p in enumerate(self.params):
             self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(idx)))
+        _UNUSED_LISTENERS.append(self._on_unused)
         self.reset()
+
+    def _on_unused(self, params):
+        if not self.enabled or self.world == 1:
+            return
+        for p in params:
+            idx = self._index.get(id(p))
+            if idx is not None and idx not in self._skipped:
+                self._skipped.add(idx)
+                b = self.param_bucket[idx]
+                self._pending[b] -= 1
+                if self._pending[b] == 0:
+                    self._ready[b] = True  # launched from the next gradient hook (never during forward)
 
     def reset(self):
         self._pending = [len(b["members"]) for b in self.buckets]
         self._ready = [False] * len(self.buckets)
         self._next = 0
         self._works = []
+        self._skipped = set()
 
     def _make_hook(self, idx):
         def hook(param):
@@ -84,7 +111,7 @@ class BucketedGradAllReduce:
             self._pending[b] -= 1
             if self._pending[b] == 0:
                 self._ready[b] = True
-                self._launch_ready()
+            self._launch_ready()
 
         return hook
 

@@ -24,7 +24,8 @@ def _vec(dtype):
 
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, resid, act):
+    def forward(ctx, x, weight, bias, resid, act, drop_p, drop_key):
+        """y = dropout(act(x W^T + b)) + resid  (dropout fused into the GEMM epilogue, before the residual add)."""
         x2 = _flat2d(x)
         M, Kd = x2.shape
         N = weight.shape[0]
@@ -40,14 +41,15 @@ class _LinearFn(torch.autograd.Function):
                 bp = torch.zeros(Np, dtype=bias.dtype, device=bias.device)
                 bp[:N] = bias
                 bias = bp
-            assert resid is None
+            assert resid is None and drop_p == 0.0
         y = torch.empty(M, Np, dtype=x.dtype, device=x.device)
         z = torch.empty_like(y) if act != L.ACT_NONE else None
         r2 = _flat2d(resid) if resid is not None else None
         K.gemm(x2, w, y, M, Np, Kd, a_kmajor=1, b_kmajor=1, lda=Kd, ldb=Kd, ldc=Np, bias=bias, act=act, aux_out=z, ld_aux_out=Np,
-               resid=r2, ld_resid=Np, split_k=1)
+               resid=r2, ld_resid=Np, split_k=1, drop_p=drop_p, drop_key=drop_key)
         ctx.save_for_backward(x2, w, z)
         ctx.act, ctx.has_bias, ctx.has_resid = act, bias is not None, resid is not None
+        ctx.drop = (drop_p, drop_key)
         ctx.xshape, ctx.N = x.shape, N
         if Np != N:
             y = y[:, :N].contiguous()
@@ -63,6 +65,8 @@ class _LinearFn(torch.autograd.Function):
             dyp = torch.zeros(M, Np, dtype=dy2.dtype, device=dy2.device)
             dyp[:, :N] = dy2
             dy2 = dyp
+        if ctx.drop[0] > 0.0:  # gradient of the dropped branch: the same mask, regenerated
+            dy2 = K.dropout(dy2 if dy2.is_contiguous() else dy2.contiguous(), *ctx.drop)
         dz = K.act_bwd(dy2, z, ctx.act) if ctx.act != L.ACT_NONE else dy2
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
@@ -77,12 +81,12 @@ class _LinearFn(torch.autograd.Function):
             db = K.colsum(dz).to(w.dtype)[:N]
         if ctx.has_resid and ctx.needs_input_grad[3]:
             dres = dy
-        return dx, dw, db, dres, None
+        return dx, dw, db, dres, None, None, None
 
 
-def linear(x, weight, bias=None, act=None, resid=None):
-    """y = act(x W^T + b) (+ resid)."""
-    return _LinearFn.apply(x, weight, bias, resid, _ACT[act])
+def linear(x, weight, bias=None, act=None, resid=None, dropout_p=0.0):
+    """y = dropout(act(x W^T + b)) (+ resid)."""
+    return _LinearFn.apply(x, weight, bias, resid, _ACT[act], *_drop_args(dropout_p))
 
 
 class _FFNFn(torch.autograd.Function):
@@ -90,19 +94,23 @@ class _FFNFn(torch.autograd.Function):
     the dH GEMM (dz1 = (dy W2) * act'(z1)), so no separate act-backward pass over the [tokens, ffn] tensor."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, resid, act):
+    def forward(ctx, x, w1, b1, w2, b2, resid, act, p_act, key_act, p_out, key_out):
+        """y = resid + dropout_out(W2 dropout_act(act(W1 x + b1)) + b2): both dropouts are GEMM epilogues."""
         x2 = _flat2d(x)
         M, d = x2.shape
         F_ = w1.shape[0]
         dout = w2.shape[0]
         z1 = torch.empty(M, F_, dtype=x.dtype, device=x.device)
         h = torch.empty_like(z1)
-        K.gemm(x2, w1, h, M, F_, d, a_kmajor=1, b_kmajor=1, lda=d, ldb=d, ldc=F_, bias=b1, act=act, aux_out=z1, ld_aux_out=F_, split_k=1)
+        K.gemm(x2, w1, h, M, F_, d, a_kmajor=1, b_kmajor=1, lda=d, ldb=d, ldc=F_, bias=b1, act=act, aux_out=z1, ld_aux_out=F_, split_k=1,
+               drop_p=p_act, drop_key=key_act)
         y = torch.empty(M, dout, dtype=x.dtype, device=x.device)
         r2 = _flat2d(resid) if resid is not None else None
-        K.gemm(h, w2, y, M, dout, F_, a_kmajor=1, b_kmajor=1, lda=F_, ldb=F_, ldc=dout, bias=b2, resid=r2, ld_resid=dout, split_k=1)
+        K.gemm(h, w2, y, M, dout, F_, a_kmajor=1, b_kmajor=1, lda=F_, ldb=F_, ldc=dout, bias=b2, resid=r2, ld_resid=dout, split_k=1,
+               drop_p=p_out, drop_key=key_out)
         ctx.save_for_backward(x2, w1, w2, z1, h)
         ctx.cfg = (act, b1 is not None, b2 is not None, resid is not None, x.shape)
+        ctx.drop = (p_act, key_act, p_out, key_out)
         return y.view(*x.shape[:-1], dout)
 
     @staticmethod
@@ -112,8 +120,12 @@ class _FFNFn(torch.autograd.Function):
         M, d = x2.shape
         F_, dout = w1.shape[0], w2.shape[0]
         dy2 = _flat2d(dy)
+        p_act, key_act, p_out, key_out = ctx.drop
+        if p_out > 0.0:  # d(fc2 output) = dy * mask_out
+            dy2 = K.dropout(dy2 if dy2.is_contiguous() else dy2.contiguous(), p_out, key_out)
         dz1 = torch.empty(M, F_, dtype=dy2.dtype, device=dy2.device)
-        K.gemm(dy2, w2, dz1, M, F_, dout, a_kmajor=1, b_kmajor=0, lda=dout, ldb=F_, ldc=F_, dact=act, aux_in=z1, ld_aux_in=F_, split_k=1)
+        K.gemm(dy2, w2, dz1, M, F_, dout, a_kmajor=1, b_kmajor=0, lda=dout, ldb=F_, ldc=F_, dact=act, aux_in=z1, ld_aux_in=F_, split_k=1,
+               drop_p=p_act, drop_key=key_act)
         dx = dw1 = db1 = dw2 = db2 = None
         if ctx.needs_input_grad[3]:
             dw2 = torch.empty(dout, F_, dtype=w2.dtype, device=w2.device)
@@ -129,13 +141,13 @@ class _FFNFn(torch.autograd.Function):
             K.gemm(dz1, x2, dw1, F_, d, M, a_kmajor=0, b_kmajor=0, lda=F_, ldb=d, ldc=d, split_k=-1)
         if has_b1 and ctx.needs_input_grad[2]:
             db1 = K.colsum(dz1).to(w1.dtype)
-        return dx, dw1, db1, dw2, db2, (dy if has_res and ctx.needs_input_grad[5] else None), None
+        return dx, dw1, db1, dw2, db2, (dy if has_res and ctx.needs_input_grad[5] else None), None, None, None, None, None
 
 
-def ffn(x, w1, b1, w2, b2, act, resid=None):
-    """Position-wise feed-forward block with fused epilogues (fc1: bias+activation, fc2: bias+residual)."""
+def ffn(x, w1, b1, w2, b2, act, resid=None, activation_dropout_p=0.0, dropout_p=0.0):
+    """Position-wise feed-forward block with fused epilogues (fc1: bias+activation+dropout, fc2: bias+dropout+residual)."""
     assert _ACT[act] != L.ACT_NONE
-    return _FFNFn.apply(x, w1.contiguous(), b1, w2.contiguous(), b2, resid, _ACT[act])
+    return _FFNFn.apply(x, w1.contiguous(), b1, w2.contiguous(), b2, resid, _ACT[act], *_drop_args(activation_dropout_p), *_drop_args(dropout_p))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -151,6 +163,7 @@ class _LayerNormFn(torch.autograd.Function):
         ctx.save_for_backward(src, gamma, mean, rstd)
         ctx.has_res = res is not None
         ctx.shape = x.shape
+        ctx.set_materialize_grads(False)  # an unused second output must not cost a zero-filled [rows, cols] gradient
         if res is not None:
             return y.view(x.shape), s.view(x.shape)
         return y.view(x.shape), None
@@ -158,6 +171,8 @@ class _LayerNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, ds):
         src, gamma, mean, rstd = ctx.saved_tensors
+        if dy is None:  # only the sum output was consumed
+            return ds, (ds if ctx.has_res else None), None, None, None
         dy2 = _flat2d(dy)
         dres = _flat2d(ds) if ds is not None else None
         dx, dg, db = K.layernorm_bwd(dy2, src, gamma, mean, rstd, dres)
@@ -185,6 +200,7 @@ class _LayerNormPassFn(torch.autograd.Function):
         y, _, mean, rstd = K.layernorm_fwd(x2, None, gamma, beta, eps)
         ctx.save_for_backward(x2, gamma, mean, rstd)
         ctx.shape = x.shape
+        ctx.set_materialize_grads(False)
         return y.view(x.shape), x.view_as(x)
 
     @staticmethod
@@ -207,34 +223,42 @@ def layer_norm_residual(x, gamma, beta, eps=1e-5):
 # ------------------------------------------------------------------------------------------------
 class _AttnFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, kpm, H, causal, scale, layout_q, layout_kv):
+    def forward(ctx, q, k, v, kpm, H, causal, scale, layout_q, layout_kv, drop_p, drop_key):
         D = q.shape[-1] // H
-        o, lse = K.attn_fwd(q, k, v, H, D, kpm, causal, scale, layout_q, layout_kv)
+        o, lse = K.attn_fwd(q, k, v, H, D, kpm, causal, scale, layout_q, layout_kv, drop_p, drop_key)
         ctx.save_for_backward(q, k, v, o, lse, kpm)
-        ctx.cfg = (H, D, causal, scale, layout_q, layout_kv)
+        ctx.cfg = (H, D, causal, scale, layout_q, layout_kv, drop_p, drop_key)
         return o
 
     @staticmethod
     def backward(ctx, do):
         q, k, v, o, lse, kpm = ctx.saved_tensors
-        H, D, causal, scale, lq, lkv = ctx.cfg
+        H, D, causal, scale, lq, lkv, drop_p, drop_key = ctx.cfg
         if do.stride() != o.stride():
             tmp = torch.empty_like(o)
             tmp.copy_(do)
             do = tmp
-        dq, dk, dv = K.attn_bwd(do, q, k, v, o, lse, H, D, kpm, causal, scale, lq, lkv)
-        return dq, dk, dv, None, None, None, None, None, None
+        dq, dk, dv = K.attn_bwd(do, q, k, v, o, lse, H, D, kpm, causal, scale, lq, lkv, drop_p, drop_key)
+        return dq, dk, dv, None, None, None, None, None, None, None, None
 
 
-def attention(q, k, v, num_heads, key_padding_mask=None, causal=False, scale=None, layout_q="bt", layout_kv="bt"):
+def _drop_args(dropout_p):
+    """(p, key) of one dropout site: a fresh key of the process-wide stream when p > 0."""
+    if dropout_p and dropout_p > 0.0:
+        from . import rng
+        return float(dropout_p), rng.next_key()
+    return 0.0, 0
+
+
+def attention(q, k, v, num_heads, key_padding_mask=None, causal=False, scale=None, layout_q="bt", layout_kv="bt", dropout_p=0.0):
     """q [B,Tq,C] / k,v [B,Tk,C] (layout "bt") or time-major ("tb"); channels of head h at [h*D,(h+1)*D).
-    key_padding_mask: bool/uint8 [B,Tk], True = pad."""
+    key_padding_mask: bool/uint8 [B,Tk], True = pad.  dropout_p > 0: attention-probability dropout inside the kernels."""
     if scale is None:
         scale = (q.shape[-1] // num_heads) ** -0.5
     if key_padding_mask is not None:
         key_padding_mask = key_padding_mask.to(torch.uint8).contiguous()
     assert q.stride(-1) == 1 and k.stride(-1) == 1 and v.stride(-1) == 1
-    return _AttnFn.apply(q, k, v, key_padding_mask, num_heads, bool(causal), float(scale), layout_q, layout_kv)
+    return _AttnFn.apply(q, k, v, key_padding_mask, num_heads, bool(causal), float(scale), layout_q, layout_kv, *_drop_args(dropout_p))
 
 
 class _AttnPackedFn(torch.autograd.Function):
@@ -242,36 +266,36 @@ class _AttnPackedFn(torch.autograd.Function):
     into ONE [B, T, 3C] buffer, so the projection's dX / dW are single GEMMs and x receives a single gradient."""
 
     @staticmethod
-    def forward(ctx, qkv, kpm, H, causal, scale):
+    def forward(ctx, qkv, kpm, H, causal, scale, drop_p, drop_key):
         C = qkv.shape[-1] // 3
         D = C // H
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
         B, T = qkv.shape[0], qkv.shape[1]
         o = torch.empty(B, T, C, dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
-        d = K.attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, "bt", "bt")
+        d = K.attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, "bt", "bt", drop_p, drop_key)
         K.attn_fwd_desc(d)
         ctx.save_for_backward(qkv, o, lse, kpm)
-        ctx.cfg = (H, D, C, causal, scale)
+        ctx.cfg = (H, D, C, causal, scale, drop_p, drop_key)
         return o
 
     @staticmethod
     def backward(ctx, do):
         qkv, o, lse, kpm = ctx.saved_tensors
-        H, D, C, causal, scale = ctx.cfg
+        H, D, C, causal, scale, drop_p, drop_key = ctx.cfg
         if not do.is_contiguous():
             do = do.contiguous()
         dqkv = torch.empty_like(qkv)
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
         dq, dk, dv = dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:]
         delta = torch.empty_like(lse)
-        d = K.attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, "bt", "bt")
+        d = K.attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, "bt", "bt", drop_p, drop_key)
         K.attn_bwd_fill(d, do, dq, dk, dv, delta, D, "bt", "bt")
         K.attn_bwd_desc(d)
-        return dqkv, None, None, None, None
+        return dqkv, None, None, None, None, None, None
 
 
-def attention_packed(qkv, num_heads, key_padding_mask=None, causal=False, scale=None):
+def attention_packed(qkv, num_heads, key_padding_mask=None, causal=False, scale=None, dropout_p=0.0):
     """qkv [B, T, 3C] contiguous -> [B, T, C]."""
     C = qkv.shape[-1] // 3
     if scale is None:
@@ -279,7 +303,7 @@ def attention_packed(qkv, num_heads, key_padding_mask=None, causal=False, scale=
     if key_padding_mask is not None:
         key_padding_mask = key_padding_mask.to(torch.uint8).contiguous()
     assert qkv.is_contiguous()
-    return _AttnPackedFn.apply(qkv, key_padding_mask, num_heads, bool(causal), float(scale))
+    return _AttnPackedFn.apply(qkv, key_padding_mask, num_heads, bool(causal), float(scale), *_drop_args(dropout_p))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -356,6 +380,7 @@ class _Conv1dCLFn(torch.autograd.Function):
         z = (z_full[:, 1:1 + Lout] if padded_out else z_full) if z_full is not None else None
         ctx.save_for_backward(xp, w_cl, z, prev_z)
         ctx.cfg = (B, Lin, Cin, Cout, k, stride, pad, Lout, act, bias is not None, grad_is_dz)
+        ctx.set_materialize_grads(False)  # the pre-activation output never carries a gradient
         if act != L.ACT_NONE:
             ctx.mark_non_differentiable(z)
             return y, z
@@ -531,6 +556,29 @@ class _MaskRowsFn(torch.autograd.Function):
 def mask_rows(x, mask):
     """x[mask] = 0 over the leading dims (wav2vec2.py:820-821)."""
     return _MaskRowsFn.apply(x, mask)
+
+
+class _DropoutFn(torch.autograd.Function):
+    """FairseqDropout (modules/fairseq_dropout.py): y = x * keep / (1 - p); backward re-evaluates the same counter-based mask."""
+
+    @staticmethod
+    def forward(ctx, x, p, key):
+        ctx.p, ctx.key = p, key
+        xc = x if x.is_contiguous() else x.contiguous()
+        return K.dropout(xc, p, key).view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dc = dy if dy.is_contiguous() else dy.contiguous()
+        return K.dropout(dc, ctx.p, ctx.key).view(dy.shape), None, None
+
+
+def dropout(x, p, key=None):
+    """Training-mode dropout on the HIP path; `key` defaults to the next site key of the process-wide stream (rng.py)."""
+    if p <= 0.0:
+        return x
+    from . import rng
+    return _DropoutFn.apply(x, float(p), rng.next_key() if key is None else key)
 
 
 class _LsCeFn(torch.autograd.Function):

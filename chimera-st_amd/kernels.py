@@ -28,7 +28,7 @@ def _2d(t):
 def gemm(A, B, C, M, N, K, *, a_kmajor, b_kmajor, lda, ldb, ldc, bias=None, bias_mode=L.BIAS_COL, act=L.ACT_NONE,
          aux_out=None, ld_aux_out=0, dact=L.ACT_NONE, aux_in=None, ld_aux_in=0, resid=None, ld_resid=0, alpha=1.0,
          batch0=1, batch1=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), sbias=(0, 0), a_seg=0, a_seg_stride=0, b_seg=0,
-         b_seg_stride=0, split_k=-1, a_off=0, b_off=0, c_off=0):
+         b_seg_stride=0, split_k=-1, a_off=0, b_off=0, c_off=0, drop_p=0.0, drop_key=0):
     """C = epilogue(alpha * Aop @ Bop); see include/cst.h.  Offsets *_off are in elements."""
     lib = L.load()
     d = L.GemmDesc()
@@ -59,6 +59,7 @@ def gemm(A, B, C, M, N, K, *, a_kmajor, b_kmajor, lda, ldb, ldc, bias=None, bias
     d.resid = None if resid is None else resid.data_ptr() + c_off * es
     d.ld_resid = ld_resid
     d.alpha = alpha
+    d.drop_p, d.drop_key = float(drop_p), int(drop_key) & 0xFFFFFFFF
     d.batch0, d.batch1 = batch0, batch1
     d.sa0, d.sa1 = sa
     d.sb0, d.sb1 = sb
@@ -107,7 +108,7 @@ def _bhtd_strides(t, layout):
     return t.stride(1), None, t.stride(0)  # [T, B, C]
 
 
-def attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, layout_q="bt", layout_kv="bt"):
+def attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, layout_q="bt", layout_kv="bt", drop_p=0.0, drop_key=0):
     """q,o: [B,Tq,H*D] (layout "bt") or [Tq,B,H*D] ("tb"); k,v likewise with Tk.  Head h at channel offset h*D."""
     d = L.AttnDesc()
     d.dtype = L.dtype_code(q.dtype)
@@ -133,17 +134,18 @@ def attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, layout_q="bt", layout_k
     else:
         d.key_padding_mask, d.kpm_stride = None, 0
     d.causal, d.scale = int(causal), scale
+    d.drop_p, d.drop_key = float(drop_p), int(drop_key) & 0xFFFFFFFF
     return d
 
 
-def attn_fwd(q, k, v, H, D, kpm, causal, scale, layout_q="bt", layout_kv="bt"):
+def attn_fwd(q, k, v, H, D, kpm, causal, scale, layout_q="bt", layout_kv="bt", drop_p=0.0, drop_key=0):
     o = torch.empty_like(q)
     if layout_q == "bt":
         B, Tq = q.shape[0], q.shape[1]
     else:
         Tq, B = q.shape[0], q.shape[1]
     lse = torch.empty(B, H, Tq, dtype=torch.float32, device=q.device)
-    d = attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, layout_q, layout_kv)
+    d = attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, layout_q, layout_kv, drop_p, drop_key)
     L.check(L.load().cst_attn_fwd(ctypes.byref(d), L.stream_ptr()), "cst_attn_fwd")
     return o, lse
 
@@ -169,10 +171,10 @@ def attn_bwd_fill(d, do, dq, dk, dv, delta, D, layout_q="bt", layout_kv="bt"):
     d.delta = delta.data_ptr()
 
 
-def attn_bwd(do, q, k, v, o, lse, H, D, kpm, causal, scale, layout_q="bt", layout_kv="bt"):
+def attn_bwd(do, q, k, v, o, lse, H, D, kpm, causal, scale, layout_q="bt", layout_kv="bt", drop_p=0.0, drop_key=0):
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     delta = torch.empty_like(lse)
-    d = attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, layout_q, layout_kv)
+    d = attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, layout_q, layout_kv, drop_p, drop_key)
     attn_bwd_fill(d, do, dq, dk, dv, delta, D, layout_q, layout_kv)
     L.check(L.load().cst_attn_bwd(ctypes.byref(d), L.stream_ptr()), "cst_attn_bwd")
     return dq, dk, dv
@@ -258,6 +260,15 @@ def mask_rows(x, mask_u8):
     y = torch.empty_like(x)
     L.check(L.load().cst_mask_rows(L.ptr(x), L.ptr(mask_u8), L.ptr(y), x.shape[0], x.shape[1], L.dtype_code(x.dtype),
                                    L.stream_ptr()), "cst_mask_rows")
+    return y
+
+
+def dropout(x, p, key):
+    """y = x * keep(key, idx) / (1 - p); x contiguous."""
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    L.check(L.load().cst_dropout(L.ptr(x), L.ptr(y), x.numel(), float(p), int(key) & 0xFFFFFFFF, L.dtype_code(x.dtype), L.stream_ptr()),
+            "cst_dropout")
     return y
 
 

@@ -33,6 +33,7 @@ class GemmDesc(ctypes.Structure):
         ("aux_in", c_p), ("ld_aux_in", c_i64),
         ("resid", c_p), ("ld_resid", c_i64),
         ("alpha", c_f),
+        ("drop_p", c_f), ("drop_key", ctypes.c_uint32),
         ("batch0", c_i64), ("batch1", c_i64),
         ("sa0", c_i64), ("sa1", c_i64), ("sb0", c_i64), ("sb1", c_i64), ("sc0", c_i64), ("sc1", c_i64),
         ("split_k", c_int),
@@ -51,6 +52,7 @@ class AttnDesc(ctypes.Structure):
         ("lse", c_p),
         ("key_padding_mask", c_p), ("kpm_stride", c_i64),
         ("causal", c_int), ("scale", c_f),
+        ("drop_p", c_f), ("drop_key", ctypes.c_uint32),
         ("dO", c_p), ("do_sb", c_i64), ("do_sh", c_i64), ("do_st", c_i64),
         ("dQ", c_p), ("dq_sb", c_i64), ("dq_sh", c_i64), ("dq_st", c_i64),
         ("dK", c_p), ("dk_sb", c_i64), ("dk_sh", c_i64), ("dk_st", c_i64),
@@ -83,6 +85,7 @@ SYMBOLS = [
     ("cst_colsum", c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_int, c_p]),
     ("cst_col2im1d", c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, c_p]),
     ("cst_mask_rows", c_int, [c_p, c_p, c_p, c_i64, c_i64, c_int, c_p]),
+    ("cst_dropout", c_int, [c_p, c_p, c_i64, c_f, ctypes.c_uint32, c_int, c_p]),
     ("cst_ls_ce_fwd", c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_f, c_i64, c_int, c_p]),
     ("cst_ls_ce_bwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_f, c_i64, c_int, c_p]),
     ("cst_sumsq_workspace", c_i64, []),

@@ -87,13 +87,13 @@ class Linear(nn.Module):
         else:
             self.register_parameter("bias", None)
 
-    def forward(self, x, act=None, resid=None):
-        return CF.linear(x, self.weight, self.bias, act=act, resid=resid)
+    def forward(self, x, act=None, resid=None, dropout_p=0.0):
+        return CF.linear(x, self.weight, self.bias, act=act, resid=resid, dropout_p=dropout_p)
 
 
 class FairseqDropout(nn.Module):
-    """modules/fairseq_dropout.py.  p = 0 is the identity; p > 0 in training uses torch's dropout for now
-    (a Philox-fused epilogue is a later round)."""
+    """modules/fairseq_dropout.py.  p = 0 is the identity; p > 0 in training runs cst_dropout with a counter-based mask
+    (rng.py) — the mask is a function of (update seed, site ordinal, element index), not of torch's generator."""
 
     def __init__(self, p, module_name=None):
         super().__init__()
@@ -103,7 +103,7 @@ class FairseqDropout(nn.Module):
 
     def forward(self, x, inplace: bool = False):
         if self.p > 0 and (self.training or self.apply_during_inference):
-            return F.dropout(x, p=self.p, training=True, inplace=inplace)
+            return CF.dropout(x, self.p)
         return x
 
 
@@ -243,13 +243,14 @@ class MultiheadAttention(FairseqIncrementalState, nn.Module):
             nn.init.constant_(self.out_proj.bias, 0.0)
 
     def forward(self, query, key, value, key_padding_mask=None, incremental_state=None, need_weights=True,
-                static_kv=False, attn_mask=None, before_softmax=False, need_head_weights=False, resid=None):
+                static_kv=False, attn_mask=None, before_softmax=False, need_head_weights=False, resid=None, out_dropout_p=0.0):
         """Input shape: Time x Batch x Channel.  Returns (attn [T,B,C], None).
-        `resid` (extension): tensor added to the output inside out_proj's GEMM epilogue."""
+        `resid` / `out_dropout_p` (extensions): out = resid + dropout(out_proj(attn)) inside out_proj's GEMM epilogue — the
+        caller's `residual + self.dropout_module(x)` (transformer_layer.py:139-141) without a separate pass.
+        Attention-probability dropout (self.dropout_module, :359) runs inside the attention kernels."""
         if need_head_weights or before_softmax:
             raise NotImplementedError("attention weights never leave the fused kernel (need_weights is ignored)")
-        if self.dropout_module.p > 0 and self.training:
-            raise NotImplementedError("attention dropout inside the fused kernel is not built yet; use --attention-dropout 0")
+        attn_p = self.dropout_module.p if (self.training and self.dropout_module.p > 0) else 0.0
         tgt_len, bsz, embed_dim = query.size()
         assert embed_dim == self.embed_dim
         qb = to_batch_major(query)  # [B,Tq,C]
@@ -278,8 +279,8 @@ class MultiheadAttention(FairseqIncrementalState, nn.Module):
             qkv = CF.linear(qb, w, bqkv)
             if key_padding_mask is not None and key_padding_mask.dim() == 0:
                 key_padding_mask = None
-            attn = CF.attention_packed(qkv, self.num_heads, key_padding_mask, causal, self.scaling)
-            out = self.out_proj(attn, resid=to_batch_major(resid) if resid is not None else None)
+            attn = CF.attention_packed(qkv, self.num_heads, key_padding_mask, causal, self.scaling, dropout_p=attn_p)
+            out = self.out_proj(attn, resid=to_batch_major(resid) if resid is not None else None, dropout_p=out_dropout_p)
             return to_time_major_view(out), None
         q = self.q_proj(qb)
         k = v = None
@@ -311,8 +312,8 @@ class MultiheadAttention(FairseqIncrementalState, nn.Module):
         if key_padding_mask is not None:
             assert key_padding_mask.size(0) == bsz and key_padding_mask.size(1) == k.size(1)
         # q is NOT pre-scaled (reference: q *= scaling, :225); the kernel applies `scale` to QK^T in fp32.
-        attn = CF.attention(q, k, v, self.num_heads, key_padding_mask, causal, self.scaling, "bt", "bt")
-        out = self.out_proj(attn, resid=to_batch_major(resid) if resid is not None else None)
+        attn = CF.attention(q, k, v, self.num_heads, key_padding_mask, causal, self.scaling, "bt", "bt", dropout_p=attn_p)
+        out = self.out_proj(attn, resid=to_batch_major(resid) if resid is not None else None, dropout_p=out_dropout_p)
         return to_time_major_view(out), None
 
     @staticmethod
@@ -402,8 +403,11 @@ class TransformerEncoderLayer(nn.Module):
         self.fc2 = Linear(args.encoder_ffn_embed_dim, self.embed_dim)
         self.final_layer_norm = LayerNorm(self.embed_dim)
 
-    def _fused(self):
-        return not (self.training and (self.dropout_module.p > 0 or self.activation_dropout_module.p > 0))
+    def _drop_ps(self):
+        """(dropout, activation_dropout) probabilities in effect: every dropout of the layer is a GEMM epilogue."""
+        if not self.training:
+            return 0.0, 0.0
+        return float(self.dropout_module.p), float(self.activation_dropout_module.p)
 
     def forward(self, x, encoder_padding_mask, attn_mask: Optional[torch.Tensor] = None, kv=None):
         """x: (T,B,C).  `kv` (extension used by the memory module): separate key/value rows (Tk,B,C) that go through
@@ -414,13 +418,12 @@ class TransformerEncoderLayer(nn.Module):
             hk = self.self_attn_layer_norm(kv) if kv is not None else h
         else:
             h, hk = x, (kv if kv is not None else x)
-        fused = self._fused()
+        p_drop, p_act = self._drop_ps()
         if kv is None:
-            a, _ = self.self_attn(h, h, h, key_padding_mask=encoder_padding_mask, attn_mask=attn_mask,
-                                  resid=residual if fused else None)
+            x, _ = self.self_attn(h, h, h, key_padding_mask=encoder_padding_mask, attn_mask=attn_mask,
+                                  resid=residual, out_dropout_p=p_drop)  # residual + dropout(attn)
         else:
-            a, _ = self._cross(h, hk, encoder_padding_mask, residual if fused else None)
-        x = a if fused else residual + self.dropout_module(a)
+            x, _ = self._cross(h, hk, encoder_padding_mask, residual, p_drop)
         if not self.normalize_before:
             x = self.self_attn_layer_norm(x)
         residual = x
@@ -428,23 +431,21 @@ class TransformerEncoderLayer(nn.Module):
             h, residual = self.final_layer_norm.forward_residual(x)
         else:
             h = x
-        if fused:
-            x = to_time_major_view(CF.ffn(to_batch_major(h), self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
-                                          self.activation_fn, resid=to_batch_major(residual)))
-        else:
-            h = self.fc1(to_batch_major(h), act=self.activation_fn)
-            x = residual + self.dropout_module(to_time_major_view(self.fc2(self.activation_dropout_module(h))))
+        x = to_time_major_view(CF.ffn(to_batch_major(h), self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
+                                      self.activation_fn, resid=to_batch_major(residual), activation_dropout_p=p_act,
+                                      dropout_p=p_drop))
         if not self.normalize_before:
             x = self.final_layer_norm(x)
         return x
 
-    def _cross(self, q_in, kv_in, key_padding_mask, resid):
+    def _cross(self, q_in, kv_in, key_padding_mask, resid, out_dropout_p=0.0):
         """self_attn's own projections with separate query / key-value rows (memory layers)."""
         sa = self.self_attn
         qb, kb = to_batch_major(q_in), to_batch_major(kv_in)
         q, k, v = sa.q_proj(qb), sa.k_proj(kb), sa.v_proj(kb)
-        attn = CF.attention(q, k, v, sa.num_heads, key_padding_mask, False, sa.scaling, "bt", "bt")
-        out = sa.out_proj(attn, resid=to_batch_major(resid) if resid is not None else None)
+        attn_p = sa.dropout_module.p if (self.training and sa.dropout_module.p > 0) else 0.0
+        attn = CF.attention(q, k, v, sa.num_heads, key_padding_mask, False, sa.scaling, "bt", "bt", dropout_p=attn_p)
+        out = sa.out_proj(attn, resid=to_batch_major(resid) if resid is not None else None, dropout_p=out_dropout_p)
         return to_time_major_view(out), None
 
     def upgrade_state_dict_named(self, state_dict, name):
@@ -489,22 +490,23 @@ class TransformerDecoderLayer(nn.Module):
         self.need_attn = True
         self.onnx_trace = False
 
-    def _fused(self):
-        return not (self.training and (self.dropout_module.p > 0 or self.activation_dropout_module.p > 0))
+    def _drop_ps(self):
+        if not self.training:
+            return 0.0, 0.0
+        return float(self.dropout_module.p), float(self.activation_dropout_module.p)
 
     def forward(self, x, encoder_out=None, encoder_padding_mask=None, incremental_state=None, prev_self_attn_state=None,
                 prev_attn_state=None, self_attn_mask=None, self_attn_padding_mask=None, need_attn=False,
                 need_head_weights=False):
-        fused = self._fused()
+        p_drop, p_act = self._drop_ps()
         residual = x
         if self.normalize_before:
             h, residual = self.self_attn_layer_norm.forward_residual(x)
         else:
             h = x
-        a, _ = self.self_attn(query=h, key=h, value=h, key_padding_mask=self_attn_padding_mask,
+        x, _ = self.self_attn(query=h, key=h, value=h, key_padding_mask=self_attn_padding_mask,
                               incremental_state=incremental_state, need_weights=False, attn_mask=self_attn_mask,
-                              resid=residual if fused else None)
-        x = a if fused else residual + self.dropout_module(a)
+                              resid=residual, out_dropout_p=p_drop)
         if not self.normalize_before:
             x = self.self_attn_layer_norm(x)
         if self.encoder_attn is not None and encoder_out is not None:
@@ -513,10 +515,9 @@ class TransformerDecoderLayer(nn.Module):
                 h, residual = self.encoder_attn_layer_norm.forward_residual(x)
             else:
                 h = x
-            a, _ = self.encoder_attn(query=h, key=encoder_out, value=encoder_out, key_padding_mask=encoder_padding_mask,
+            x, _ = self.encoder_attn(query=h, key=encoder_out, value=encoder_out, key_padding_mask=encoder_padding_mask,
                                      incremental_state=incremental_state, static_kv=True, need_weights=False,
-                                     resid=residual if fused else None)
-            x = a if fused else residual + self.dropout_module(a)
+                                     resid=residual, out_dropout_p=p_drop)
             if not self.normalize_before:
                 x = self.encoder_attn_layer_norm(x)
         residual = x
@@ -524,12 +525,9 @@ class TransformerDecoderLayer(nn.Module):
             h, residual = self.final_layer_norm.forward_residual(x)
         else:
             h = x
-        if fused:
-            x = to_time_major_view(CF.ffn(to_batch_major(h), self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
-                                          self.activation_fn, resid=to_batch_major(residual)))
-        else:
-            h = self.fc1(to_batch_major(h), act=self.activation_fn)
-            x = residual + self.dropout_module(to_time_major_view(self.fc2(self.activation_dropout_module(h))))
+        x = to_time_major_view(CF.ffn(to_batch_major(h), self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
+                                      self.activation_fn, resid=to_batch_major(residual), activation_dropout_p=p_act,
+                                      dropout_p=p_drop))
         if not self.normalize_before:
             x = self.final_layer_norm(x)
         return x, None, None

@@ -1,0 +1,63 @@
+"""Dropout randomness of the HIP path.
+
+The reference draws dropout masks from torch's global generator, re-seeded every update with
+`seed + num_updates` (trainer.py:934-938 -> utils.set_torch_seed).  Here every dropout SITE (one call of
+FairseqDropout / one fused epilogue / one attention-probability dropout) gets a 32-bit key derived from
+(that same seed, the site's ordinal inside the step), and the kernels evaluate keep(key, element index)
+on the fly (csrc/cst_common.h: cst_drop_bits) — forward and backward regenerate the same mask, nothing is
+stored.  `keep_mask_numpy` is the same function in numpy (used by the tests as the checker)."""
+import numpy as np
+
+_M32 = 0xFFFFFFFF
+
+
+def _hash32(x):
+    x &= _M32
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & _M32
+    x ^= x >> 15
+    x = (x * 0x846CA68B) & _M32
+    x ^= x >> 16
+    return x
+
+
+class DropoutState:
+    """Per-process dropout stream: reseed(seed) at the start of every update, next_key() once per dropout site."""
+
+    def __init__(self):
+        self.seed = 1
+        self.site = 0
+
+    def reseed(self, seed):
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.site = 0
+
+    def next_key(self):
+        self.site += 1
+        return _hash32((self.seed & _M32) ^ _hash32(self.site * 0x9E3779B1 + (self.seed >> 32)))
+
+
+STATE = DropoutState()
+
+
+def reseed(seed):
+    STATE.reseed(seed)
+
+
+def next_key():
+    return STATE.next_key()
+
+
+def keep_mask_numpy(key, n, p):
+    """Boolean keep mask of elements [0, n) of the site `key` at drop probability p (bit-exact with cst_drop_bits)."""
+    u = np.uint64
+    idx = np.arange(n, dtype=np.uint64)
+    pair = idx >> u(1)
+    key2 = (int(key) * 0x2C1B3C6D + 0x297A2D39) & _M32
+    x = (((pair & u(_M32)) ^ u(key)) + (pair >> u(32)) * u(0x9E3779B1)) & u(_M32)
+    x = (x * u(0x9E3779B1)) & u(_M32)
+    x = ((x ^ (x >> u(15))) + u(key2)) & u(_M32)
+    x = (x * u(0x85EBCA77)) & u(_M32)
+    x ^= x >> u(13)
+    half = np.where((idx & u(1)) == 1, x >> u(16), x & u(0xFFFF))
+    return half >= u(int(p * 65536.0 + 0.5))

@@ -10,6 +10,7 @@ import torch
 import torch.distributed as dist
 
 from .distributed import DistributedFairseqModel, all_reduce_stats
+from . import rng
 from .optim import FlatParamBuffers, FusedAdam
 
 
@@ -43,6 +44,7 @@ class Trainer:
             torch.cuda.manual_seed(seed)
         np.random.seed(seed)
         random.seed(seed)
+        rng.reseed(seed)  # dropout sites of the HIP path: keys = f(seed, site ordinal)
 
     def _prepare_sample(self, sample):
         """trainer.py:896-932: H2D; the waveform stays fp32 (conv0 reads it directly), token tensors stay int64."""

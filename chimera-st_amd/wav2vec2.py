@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as CF
+from .distributed import notify_unused_parameters
 from .modules import LayerNorm, Linear, MultiheadAttention, to_batch_major, to_time_major_view
 from .registry import register_model, register_model_architecture
 
@@ -86,15 +87,16 @@ class TransformerSentenceEncoderLayer(nn.Module):
         self.final_layer_norm = LayerNorm(embedding_dim)
 
     def forward(self, x, self_attn_mask=None, self_attn_padding_mask=None, need_weights=False, att_args=None):
-        if self.training and (self.dropout > 0 or self.activation_dropout > 0):
-            raise NotImplementedError("wav2vec2 encoder dropout > 0 in training is not built yet (set dropout 0 in the w2v args)")
+        p_drop = float(self.dropout) if self.training else 0.0             # dropout1 / dropout3 (wav2vec2.py:940-955)
+        p_act = float(self.activation_dropout) if self.training else 0.0   # dropout2
         residual = x
         x, _ = self.self_attn(query=x, key=x, value=x, key_padding_mask=self_attn_padding_mask, need_weights=False,
-                              resid=residual)  # x = residual + attn (out_proj epilogue)
+                              resid=residual, out_dropout_p=p_drop)  # x = residual + dropout1(attn) (out_proj epilogue)
         x = self.self_attn_layer_norm(x)
         residual = x
         x = to_time_major_view(CF.ffn(to_batch_major(x), self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
-                                      self.activation_fn, resid=to_batch_major(residual)))
+                                      self.activation_fn, resid=to_batch_major(residual), activation_dropout_p=p_act,
+                                      dropout_p=p_drop))
         x = self.final_layer_norm(x)
         return x, None
 
@@ -157,12 +159,14 @@ class TransformerEncoder(nn.Module):
         x = CF.pos_conv_gelu_residual(x, self.pos_conv_weight(), pc.bias, self.conv_pos_groups)  # x += GELU(SamePad(conv(x)))
         x = self.layer_norm(x)
         if self.training and self.dropout > 0:
-            raise NotImplementedError("wav2vec2 encoder dropout > 0 in training is not built yet")
+            x = CF.dropout(x, self.dropout)  # F.dropout(x, p=self.dropout) (:830)
         x = to_time_major_view(x)
         for layer in self.layers:
             dropout_probability = np.random.random()  # same RNG call order as the reference (:836-840)
             if not self.training or (dropout_probability > self.layerdrop):
                 x, _ = layer(x, self_attn_padding_mask=padding_mask, need_weights=False)
+            else:
+                notify_unused_parameters(layer.parameters())  # keeps the overlapped bucket order moving (distributed.py)
         return to_batch_major(x), padding_mask
 
 
@@ -216,7 +220,7 @@ class Wav2Vec2Model(nn.Module):
         if self.post_extract_proj is not None:
             feats = self.post_extract_proj(feats)
         if self.training and self.dropout_input_p > 0:
-            raise NotImplementedError("dropout_input > 0 is not built yet")
+            feats = CF.dropout(feats, self.dropout_input_p)  # self.dropout_input (:553)
         x, padding_mask = self.encoder(feats, padding_mask=padding_mask)
         return {"x": x, "padding_mask": padding_mask}
 

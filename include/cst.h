@@ -113,6 +113,9 @@ typedef struct {
   const void* aux_in; int64_t ld_aux_in;
   const void* resid; int64_t ld_resid;
   float alpha;
+  float drop_p; uint32_t drop_key;   /* drop_p > 0: v *= keep(drop_key, row*N + col) / (1 - drop_p) after `act`, before dact /
+                                        resid (FairseqDropout fused: residual + dropout(linear(x)), dropout(act(fc1 x)) and the
+                                        matching mask in the dX-through-activation GEMM); needs batch0*batch1 == 1 */
   int64_t batch0, batch1;            /* >= 1 */
   int64_t sa0, sa1, sb0, sb1, sc0, sc1; /* batch strides (elements) for A, B, C(+aux/resid) */
   int split_k;                       /* 0/1 = none; >1 explicit; -1 = let the library choose */
@@ -145,6 +148,8 @@ typedef struct {
   const uint8_t* key_padding_mask; int64_t kpm_stride;
   int causal;
   float scale;
+  float drop_p; uint32_t drop_key;   /* attention dropout (multihead_attention.py:359): P * keep(drop_key, ((b*H+h)*Tq+q)*Tkp + k) / (1-p),
+                                        Tkp = Tk rounded up to even; the backward call must carry the same two values */
   /* backward only */
   const void* dO; int64_t do_sb, do_sh, do_st;
   void* dQ; int64_t dq_sb, dq_sh, dq_st;
@@ -197,6 +202,11 @@ int cst_col2im1d(const void* dcol, const void* z, void* dx, int64_t B, int64_t L
                  int64_t C, int k, int stride, int pad, int dact, int dtype, cst_stream stream);
 /* y[r,:] = mask[r] ? 0 : x[r,:]   (x[padding_mask] = 0, wav2vec2.py:820-821) */
 int cst_mask_rows(const void* x, const uint8_t* mask, void* y, int64_t rows, int64_t cols, int dtype, cst_stream stream);
+
+/* y = x * keep / (1 - p): FairseqDropout (modules/fairseq_dropout.py:20-37) forward; the same call on dy is its backward.
+ * The mask is counter-based — keep(key, element index), csrc/cst_common.h — so nothing is stored between the two calls and
+ * fused epilogues (cst_gemm / cst_attn_*) regenerate the identical mask from the same key.  n elements, contiguous. */
+int cst_dropout(const void* x, void* y, int64_t n, float p, uint32_t key, int dtype, cst_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Label-smoothed cross entropy over vocabulary logits — replaces fp32 log_softmax

@@ -407,3 +407,84 @@ def test_gemm_8phase_large(K, ak, bk, M, N, K_):
     Bf = B.float() if bk else B.float().t()
     ref = torch.relu(Af @ Bf.t() + bias.float())
     check(C, ref, dt, "8-phase gemm %d%d %dx%dx%d" % (ak, bk, M, N, K_))
+
+
+# --------------------------------------------------------------------------------------------
+# dropout: the kernels' counter-based masks against the numpy statement of the same function (chimera-st_amd/rng.py)
+# --------------------------------------------------------------------------------------------
+def _keep(key, n, p):
+    from importlib import import_module
+    rng = import_module("chimera-st_amd.rng")
+    return torch.from_numpy(rng.keep_mask_numpy(key, n, p))
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("n", [8, 1000, 4099, 1 << 20])
+def test_dropout_elementwise(K, dt, n):
+    k, L = K
+    p, key = 0.1, 0x1234ABCD
+    x = rnd(n, dt=dt, seed=3)
+    y = k.dropout(x, p, key)
+    keep = _keep(key, n, p).cuda()
+    ref = torch.where(keep, x.float() / (1 - p), torch.zeros_like(x.float()))
+    check(y, ref, dt, "dropout n=%d" % n)
+    assert abs(float(keep.float().mean()) - 0.9) < (0.35 if n < 100 else 0.03)
+    # backward of the same site = the same call on the gradient
+    g = rnd(n, dt=dt, seed=4)
+    check(k.dropout(g, p, key), torch.where(keep, g.float() / (1 - p), torch.zeros_like(g.float())), dt, "dropout bwd")
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("big", [False, True])
+def test_gemm_epilogue_dropout(K, dt, big):
+    """C = resid + dropout(relu(A B^T + bias)): mask index = row * N + col (old kernels and the 8-phase kernel)."""
+    k, L = K
+    if big and dt != torch.bfloat16:
+        pytest.skip("8-phase kernel is bf16")
+    M, N, K_ = (3608, 3592, 136) if big else (304, 200, 136)
+    p, key = 0.25, 77
+    A, B = rnd(M, K_, dt=dt, seed=1), rnd(N, K_, dt=dt, seed=2)
+    bias, resid = rnd(N, dt=dt, seed=3), rnd(M, N, dt=dt, seed=4)
+    C = torch.empty(M, N, dtype=dt, device="cuda")
+    k.gemm(A, B, C, M, N, K_, a_kmajor=1, b_kmajor=1, lda=K_, ldb=K_, ldc=N, bias=bias, act=L.ACT_RELU, resid=resid, ld_resid=N,
+           drop_p=p, drop_key=key)
+    keep = _keep(key, M * N, p).view(M, N).cuda()
+    z = torch.relu(A.float() @ B.float().t() + bias.float())
+    ref = resid.float() + torch.where(keep, z / (1 - p), torch.zeros_like(z))
+    check(C, ref, dt, "gemm dropout epilogue", scale=float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("Tq,Tk,causal", [(100, 100, False), (77, 131, False), (64, 64, True)])
+def test_attention_dropout(K, dt, Tq, Tk, causal):
+    """Attention-probability dropout inside the fused kernels, forward and all three gradients, against explicit
+    softmax -> mask -> PV in fp32 with the mask from rng.keep_mask_numpy (index ((b*H+h)*Tq+q)*Tkp + k, Tkp = even(Tk))."""
+    k, L = K
+    B, H, D = 2, 3, 64
+    p, key = 0.2, 4242
+    q = rnd(B, Tq, H * D, dt=dt, seed=1).requires_grad_(True)
+    kk = rnd(B, Tk, H * D, dt=dt, seed=2).requires_grad_(True)
+    v = rnd(B, Tk, H * D, dt=dt, seed=3).requires_grad_(True)
+    kpm = torch.zeros(B, Tk, dtype=torch.uint8, device="cuda")
+    kpm[1, Tk - 9:] = 1
+    scale = D ** -0.5
+    o, lse = k.attn_fwd(q.detach(), kk.detach(), v.detach(), H, D, kpm, causal, scale, "bt", "bt", p, key)
+    do = rnd(B, Tq, H * D, dt=dt, seed=5)
+    dq, dk, dv = k.attn_bwd(do, q.detach(), kk.detach(), v.detach(), o, lse, H, D, kpm, causal, scale, "bt", "bt", p, key)
+    Tkp = (Tk + 1) // 2 * 2
+    keep = _keep(key, B * H * Tq * Tkp, p).view(B, H, Tq, Tkp)[..., :Tk].cuda()
+    qf, kf, vf = (t.detach().float().requires_grad_(True) for t in (q, kk, v))
+    qh = qf.view(B, Tq, H, D).transpose(1, 2); kh = kf.view(B, Tk, H, D).transpose(1, 2); vh = vf.view(B, Tk, H, D).transpose(1, 2)
+    s = (qh @ kh.transpose(-1, -2)) * scale
+    s = s.masked_fill(kpm.bool()[:, None, None, :], float("-inf"))
+    if causal:
+        s = s.masked_fill(torch.triu(torch.ones(Tq, Tk, dtype=torch.bool, device="cuda"), 1 + Tk - Tq), float("-inf"))
+    pr = torch.softmax(s, -1)
+    prd = torch.where(keep, pr / (1 - p), torch.zeros_like(pr))
+    ref = (prd @ vh).transpose(1, 2).reshape(B, Tq, H * D)
+    check(o, ref, dt, "attn dropout fwd")
+    ref.backward(do.float())
+    sc = 2.0 if dt == torch.bfloat16 else 1.0
+    check(dq, qf.grad, dt, "attn dropout dq", scale=float(qf.grad.abs().max()) * sc)
+    check(dk, kf.grad, dt, "attn dropout dk", scale=float(kf.grad.abs().max()) * sc)
+    check(dv, vf.grad, dt, "attn dropout dv", scale=float(vf.grad.abs().max()) * sc)

@@ -21,7 +21,7 @@ from conftest import golden_cfg, golden_params, golden_sample, load_golden, load
 pytestmark = pytest.mark.gpu
 
 
-def build_from_golden(g, kind, dtype=torch.float32):
+def build_from_golden(g, kind, dtype=torch.float32, dropout=None):
     load_pkg()
     w2t = import_module("chimera-st_amd.w2v2_transformer")
     inter = import_module("chimera-st_amd.w2v2_transformer_interlingua")
@@ -29,6 +29,9 @@ def build_from_golden(g, kind, dtype=torch.float32):
     Dictionary = import_module("chimera-st_amd.dictionary").Dictionary
     w = ast.literal_eval(str(g["meta/w2v_args"]))
     m = ast.literal_eval(str(g["meta/model_args"]))
+    if dropout is not None:  # the training recipe's dropout sites (the goldens were generated with every p = 0)
+        w.update(dropout=dropout, attention_dropout=dropout, dropout_input=dropout)
+        m.update(dropout=dropout, attention_dropout=dropout, activation_dropout=dropout)
     w2t.SYNTHETIC_W2V["golden_tiny"] = Namespace(**w)
     args = Namespace(**m)
     args.w2v2_model_path = "synthetic:golden_tiny"
@@ -160,3 +163,55 @@ def test_against_oracle_fresh_inputs():
     (lg, _), mem = model.forward_with_internal(**to_cuda(sample)["net_input"])
     assert_close(lg, ref["st_logits"].numpy(), 1e-3, "st logits (fresh)")
     assert_close(mem, ref["memory_audio"].numpy(), 1e-3, "memory (fresh)")
+
+
+def test_dropout_training_step_consistency():
+    """Every dropout site on (p = 0.2: GEMM epilogues, attention probabilities, feature / embedding dropouts): the masks are a
+    function of (seed, site ordinal, element), so (a) the same seed reproduces the loss and the gradients, (b) another seed does
+    not, and (c) the analytic gradient equals the central finite difference of the loss ALONG a random direction with the seed
+    held fixed — which only holds if every backward kernel regenerates exactly the mask its forward kernel applied."""
+    rng = import_module("chimera-st_amd.rng")
+    g = load_golden("chimera_tiny.npz")
+    model, task, args = build_from_golden(g, "chimera", torch.float32, dropout=0.2)
+    # ST term only: the MT / contrastive terms and the wav2vec2 CNN (feature_grad_mult = 0.1) carry deliberately scaled or
+    # stopped gradients, which a finite difference of the loss cannot reproduce
+    crit = import_module("chimera-st_amd.criterions").TripletSTMTContrastiveCriterion(task, False, 0.1, [1.0, 0.0, 0.0], 0.1)
+    sample = to_cuda(golden_sample(g))
+    model.train()
+
+    def run(seed, backward=True):
+        rng.reseed(seed)
+        np.random.seed(seed)
+        model.zero_grad()
+        loss, _, log = crit(model, sample)
+        if backward:
+            loss.backward()
+            return float(loss.detach()), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        return float(loss.detach()), None
+
+    l0, g0 = run(5)
+    l1, g1 = run(5)
+    l2, _ = run(6, backward=False)
+    lref = float(g["loss/st_loss"])
+    assert abs(l0 - l1) <= 1e-5 * abs(l0), "same seed, different loss: %r vs %r" % (l0, l1)
+    num = sum(float(((g0[n] - g1[n]).double() ** 2).sum()) for n in g0)
+    den = sum(float((g0[n].double() ** 2).sum()) for n in g0)
+    assert (num / den) ** 0.5 <= 1e-5, "same seed, gradients differ: rel-L2 %.3e" % ((num / den) ** 0.5)  # (atomics: not bitwise)
+    assert abs(l0 - l2) > 1e-4 * abs(l0), "different seeds gave the same loss"
+    assert abs(l0 - lref) > 1e-4 * abs(lref), "dropout 0.2 left the loss unchanged"
+    # directional finite difference at fixed seed
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    params = [(n, p) for n, p in model.named_parameters() if n in g0 and "feature_extractor" not in n]
+    dirs = {n: torch.randn(p.shape, generator=gen).to(p.device) * float(p.detach().abs().mean() + 1e-3) for n, p in params}
+    analytic = sum(float((g0[n].double() * dirs[n].double()).sum()) for n, _ in params)
+    eps = 1e-3
+    with torch.no_grad():
+        for n, p in params:
+            p.add_(eps * dirs[n])
+    lp, _ = run(5, backward=False)
+    with torch.no_grad():
+        for n, p in params:
+            p.sub_(2 * eps * dirs[n])
+    lm, _ = run(5, backward=False)
+    numeric = (lp - lm) / (2 * eps)
+    assert abs(numeric - analytic) <= 2e-2 * abs(analytic) + 1e-3, "directional derivative %.6f vs analytic %.6f" % (numeric, analytic)

@@ -9,7 +9,7 @@ import bench
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="s2t_w2v2"); ap.add_argument("--batch", type=int, default=32)
-ap.add_argument("--seconds", type=float, default=30.0); ap.add_argument("--dtype", default="bf16"); ap.add_argument("--lengths", default="uniform")
+ap.add_argument("--seconds", type=float, default=30.0); ap.add_argument("--dtype", default="bf16"); ap.add_argument("--lengths", default="uniform"); ap.add_argument("--dropout", type=float, default=0.1); ap.add_argument("--layerdrop", type=float, default=0.0)
 args = ap.parse_args()
 device = torch.device("cuda", 0)
 trainer, task, tasks, ns = bench.build(args, device)

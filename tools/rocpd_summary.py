@@ -13,6 +13,12 @@ def short(n):
 
 
 def main(path, out=None):
+    import glob, os
+    if os.path.isdir(path):  # rocprofv3 -d <dir>: take the (first) *.db below it
+        found = sorted(glob.glob(os.path.join(path, "**", "*.db"), recursive=True))
+        if not found:
+            sys.exit("no .db under " + path)
+        path = found[0]
     db = sqlite3.connect(path)
     rows = db.execute("select name, count(*), sum(duration), avg(duration) from kernels group by name order by sum(duration) desc").fetchall()
     total = sum(r[2] for r in rows)
