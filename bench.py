@@ -78,6 +78,47 @@ def make_batch(tasks, task, args, rank, device):
     return tasks.synthetic_sample(task.target_dictionary, args.batch, audio, tgt, src, seed=1 + rank, device=device)
 
 
+def dominant_gemm_launch(args, device):
+    """The single most expensive GEMM launch of the step — wav2vec2 fc1 forward, [B*T1, 768] x [3072, 768]^T with the
+    bias + GELU + pre-activation epilogue (12 launches per update) — timed alone with HIP events on the launch stream, with
+    the HBM-side traffic of the same launch from the committed PMC pass (profiles/r01_pmc_gemm.json: TCC_EA0_RDREQ/WRREQ,
+    64 B per request, reads doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950)."""
+    K = importlib.import_module("chimera-st_amd.kernels")
+    Lb = importlib.import_module("chimera-st_amd.lib")
+    t1 = int(args.seconds * 16000)
+    for (k, s_) in [(10, 5), (3, 2), (3, 2), (3, 2), (3, 2), (2, 2), (2, 2)]:
+        t1 = (t1 - k) // s_ + 1
+    M, D, F = args.batch * t1, 768, 3072
+    x = torch.randn(M, D, device=device).to(torch.bfloat16)
+    w = (torch.randn(F, D, device=device) * 0.02).to(torch.bfloat16)
+    b = torch.zeros(F, device=device, dtype=torch.bfloat16)
+    h, z = torch.empty(M, F, device=device, dtype=torch.bfloat16), torch.empty(M, F, device=device, dtype=torch.bfloat16)
+
+    def launch():
+        K.gemm(x, w, h, M, F, D, a_kmajor=1, b_kmajor=1, lda=D, ldb=D, ldc=F, bias=b, act=Lb.ACT_GELU, aux_out=z, ld_aux_out=F, split_k=1)
+
+    for _ in range(3):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    flops = 2.0 * M * F * D
+    out = {"kernel": "gemm8p_kernel<k-major, k-major>", "shape": [M, F, D], "epilogue": "bias+gelu+aux_out", "avg_launch_ms": ms,
+           "achieved": flops / ms / 1e9, "unit": "TFLOP/s", "frac": flops / ms / 1e9 / PEAK["bf16"],
+           "algorithmic_bytes": 2.0 * (M * D + F * D + 2 * M * F), "traffic": None}
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_gemm.json")
+    if os.path.exists(pmc):
+        rec = json.load(open(pmc))
+        if rec.get("shape") == [47968, F, D] and M == 47968:
+            out["traffic"] = rec["traffic_bytes_per_launch"]
+            out["traffic_note"] = rec["note"]
+    return out
+
+
 def cpu_baseline(trainer, task, tasks, ns, args):
     """The oracle (CPU fp32 restatement pinned to the reference, oracle/chimera_oracle.py) timed on this box's host
     cores on a bounded sample of the same workload: ONE full update (fwd + bwd + Adam) on one 30 s utterance."""
@@ -179,6 +220,8 @@ def main():
             roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                     "traffic": None, "launches": r["launches"], "avg_launch_ms": r["ms"] / max(r["launches"], 1)}
         roof["per_class_ms"] = {k: round(v["ms"], 3) for k, v in table.items() if v["launches"]}
+        if name == "gemm" and args.dtype == "bf16":
+            roof["dominant_launch"] = dominant_gemm_launch(args, device)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(trainer, task, tasks, ns, args)

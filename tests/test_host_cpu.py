@@ -147,7 +147,10 @@ def _ddp_worker(rank, world, port, q):
     xs = [torch.randn(5, 6, generator=g) for _ in range(3)]
     # step 1: plain update; every rank uses its own data
     buf.zero_grad()
+    distributed.notify_unused_parameters(net[5].parameters())  # what wav2vec2 layerdrop reports for a skipped layer
     net[:5](xs[0]).pow(2).sum().backward()  # net[5] gets NO gradient -> must be all-reduced as zeros
+    # net[5]'s bucket is the first in launch order: without the notification nothing could start before finish()
+    assert model.reducer._next == len(model.reducer.buckets), "buckets were not launched during backward"
     model.all_reduce()
     step1 = buf.flat_grad.clone()
     # step 2: gradient accumulation over two micro-batches, collective only on the last one
