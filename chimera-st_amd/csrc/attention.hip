@@ -126,7 +126,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_fwd_ke
   for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.0f;
-  float m_run = -INFINITY, l_run = 0.0f;
+  float m_run = -1.0e30f, l_run = 0.0f;
 
   int64_t kend = p.Tk;
   if (p.causal) {
@@ -191,20 +191,24 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_fwd_ke
 #pragma unroll
       for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[ks][r]);
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * c2;  // c2 > 0: max commutes with the scale; -inf stays -inf
+    // m_run starts at a large negative FINITE value: a tile whose keys are all masked gives m_new = m_run, alpha = 1 and
+    // e = exp2(-inf) = 0 without a special case (a -inf running max would need one to avoid inf - inf)
     const float m_new = fmaxf(m_run, mt);
-    float alpha = 1.0f;
-    if (m_new != -INFINITY) {
-      alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // m_run = -inf -> 0
-      float ls = 0.0f;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    {
+      float ls0 = 0.0f, ls1 = 0.0f;  // two partial sums: the adds pair up into v_pk_add_f32
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float e = __builtin_amdgcn_exp2f(fmaf(s[ks][r], c2, -m_new));
-          s[ks][r] = e;
-          ls += e;
+        for (int r = 0; r < 16; r += 2) {
+          const float e0 = __builtin_amdgcn_exp2f(fmaf(s[ks][r], c2, -m_new));
+          const float e1 = __builtin_amdgcn_exp2f(fmaf(s[ks][r + 1], c2, -m_new));
+          s[ks][r] = e0;
+          s[ks][r + 1] = e1;
+          ls0 += e0;
+          ls1 += e1;
         }
-      l_run = l_run * alpha + ls;
+      l_run = l_run * alpha + (ls0 + ls1);
       m_run = m_new;
       if (DROP) {  // dropped probabilities leave the PV product; the row sum (normaliser) keeps them
         const uint32_t base = rowpair + (uint32_t)((j0 >> 1) + 2 * hi);
@@ -219,11 +223,6 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_fwd_ke
               s[ks][4 * g + 2 * t + 1] = (bits >> 16) >= p.drop_thr ? s[ks][4 * g + 2 * t + 1] : 0.0f;
             }
       }
-    } else {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[ks][r] = 0.0f;
     }
 #pragma unroll
     for (int dt = 0; dt < D / 32; ++dt)
@@ -306,12 +305,13 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_bwd_dq
   Frag<T> fq[D / 16], fdo[D / 16];
   load_row_frags<T, D>(fq, Qg, p.q_st, q, (int)p.Tq, lane);
   load_row_frags<T, D>(fdo, dOg, p.do_st, q, (int)p.Tq, lane);
-  float lse = -INFINITY, dlt = 0.0f;
+  // log2 domain.  Rows beyond Tq and fully masked rows (lse = -inf) get +inf: exp2(s - inf) = 0 without a per-element select
+  float lse = INFINITY, dlt = 0.0f;
   if (q < p.Tq) {
-    lse = p.lse[(b * p.H + h) * p.Tq + q] * 1.4426950408889634f;  // log2 domain; -inf (fully masked row) stays -inf
+    const float l = p.lse[(b * p.H + h) * p.Tq + q];
+    lse = l == -INFINITY ? INFINITY : l * 1.4426950408889634f;
     dlt = p.delta[(b * p.H + h) * p.Tq + q];
   }
-  const bool row_dead = lse == -INFINITY;
   f32x16 dq[D / 32];
 #pragma unroll
   for (int dt = 0; dt < D / 32; ++dt)
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_bwd_dq
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float pr = row_dead ? 0.0f : __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse));
+        float pr = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse));
         if (need_mask) {
           const int kb = ks * 32 + (r & 3) + 8 * (r >> 2);
           pr = (((mbl >> kb) & 1ull) || (kb + 4 * hi > lim)) ? 0.0f : pr;
@@ -458,7 +458,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnParams p) 
     rq.fetch(Qg + i0 * p.q_st, p.q_st, nq, tid);
     rdo.fetch(dOg + i0 * p.do_st, p.do_st, nq, tid);
     if (tid < KT) {
-      rl = tid < nq ? p.lse[(b * p.H + h) * p.Tq + i0 + tid] * 1.4426950408889634f : -INFINITY;  // log2 domain; -inf -> P = 0
+      // log2 domain; out-of-range and fully masked rows (lse = -inf) are staged as +inf: exp2(s - inf) = 0, no per-element select
+      const float l = tid < nq ? p.lse[(b * p.H + h) * p.Tq + i0 + tid] : -INFINITY;
+      rl = l == -INFINITY ? INFINITY : l * 1.4426950408889634f;
       rd = tid < nq ? p.delta[(b * p.H + h) * p.Tq + i0 + tid] : 0.0f;
     }
   };
@@ -512,8 +514,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnParams p) 
       for (int r = 0; r < 16; ++r) {
         const int qr = qs * 32 + acc_row(r, lane);
         const float l = sL[qr];
-        float e = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -l));  // l = -inf (dead / out-of-range row): handled below
-        e = (key_masked || l == -INFINITY) ? 0.0f : e;
+        float e = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -l));  // l = +inf for dead / out-of-range rows -> 0
+        // (a masked key's lane computes unused values: they only reach that key's own dK / dV column, zeroed at the store)
         if (diag) e = (key > (int)i0 + qr + cshift) ? 0.0f : e;
         float dpr = dp[r];
         if (DROP) {
@@ -546,6 +548,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnParams p) 
     if (more) stage(cur ^ 1);
     __syncthreads();
     cur ^= 1;
+  }
+  if (key_masked) {
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.0f; dv[dt][r] = 0.0f; }
   }
   if (key < p.Tk) {
     T* gk = (T*)p.dK + b * p.dk_sb + h * p.dk_sh + (int64_t)key * p.dk_st;
