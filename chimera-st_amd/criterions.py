@@ -136,16 +136,12 @@ class TripletSTMTContrastiveCriterion(LabelSmoothedCrossEntropyCriterion):
         return loss, sample_size, logging_output
 
     def compute_contrastive(self, input1, input2, reduce):
-        """:154-169 — per-utterance M x M cosine-similarity CE (class dim = audio slot).  B*M*M logits (0.13 M values at
-        B=32): left to torch ops this round; cst_contrastive_fwd/bwd is a next-round row."""
+        """:154-169 — per-utterance M x M cosine-similarity CE (class dim = audio slot): cst_contrastive_fwd/bwd."""
         assert input1.shape == input2.shape
-        input1 = input1.transpose(0, 1)
-        input2 = input2.transpose(0, 1)
-        batch_size, seqlen, _ = input1.shape
-        logits = torch.cosine_similarity(input1.float().unsqueeze(2), input2.float().unsqueeze(1), dim=-1)
-        logits = logits / self.contrastive_temp
-        target = torch.arange(seqlen, device=logits.device)[None].repeat(batch_size, 1)
-        return F.cross_entropy(logits, target, reduction="sum" if reduce else "none")
+        if not reduce:
+            raise NotImplementedError("compute_contrastive(reduce=False) is not on the training path")
+        from . import functional as CF
+        return CF.contrastive_loss(input1.transpose(0, 1), input2.transpose(0, 1), self.contrastive_temp)
 
     @staticmethod
     def logging_outputs_can_be_summed() -> bool:

@@ -124,6 +124,145 @@ __global__ void adam_kernel(float* master, float* m, float* v, const TG* grad, T
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Contrastive term of the triplet criterion (criterions/triplet_st_mt_contrastive.py:154-169): per utterance
+//   c[i][j] = cos(a[i,:], t[j,:]) (audio slot i, text slot j), logits L = c / temp, class dim = AUDIO slot, target(j) = j:
+//   loss = sum_b sum_j ( logsumexp_i L[i][j] - L[j][j] ).
+// One workgroup per utterance (M <= 64 memory slots, C channels); 8 KFLOP-scale work: plain FMA, LDS tiles of 32 channels.
+// ---------------------------------------------------------------------------------------
+constexpr int CM = 64, CK = 32;
+
+template <typename T>
+__global__ __launch_bounds__(256) void contrastive_fwd_kernel(const T* a, const T* t, float* loss, float* sim, float* na, float* nt,
+                                                              int M, int C, float inv_temp) {
+  __shared__ float sA[CM][CK + 1], sT[CM][CK + 1], sS[CM][CM + 1], red[4];
+  const int b = blockIdx.x, tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const T* ab = a + (int64_t)b * M * C;
+  const T* tb = t + (int64_t)b * M * C;
+  float acc[4][4] = {}, qa[4] = {}, qt[4] = {};
+  for (int k0 = 0; k0 < C; k0 += CK) {
+    for (int e = tid; e < CM * CK; e += 256) {
+      const int r = e / CK, c = e % CK;
+      const bool ok = r < M && k0 + c < C;
+      sA[r][c] = ok ? DT<T>::ld(ab + (int64_t)r * C + k0 + c) : 0.0f;
+      sT[r][c] = ok ? DT<T>::ld(tb + (int64_t)r * C + k0 + c) : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int c = 0; c < CK; ++c) {
+      float x[4], y[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { x[u] = sA[ty * 4 + u][c]; y[u] = sT[tx * 4 + u][c]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        qa[u] = fmaf(x[u], x[u], qa[u]);
+        qt[u] = fmaf(y[u], y[u], qt[u]);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = fmaf(x[u], y[v], acc[u][v]);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int i = ty * 4 + u, j = tx * 4 + v;
+      const float c = acc[u][v] / fmaxf(sqrtf(qa[u]) * sqrtf(qt[v]), 1e-8f);  // torch.cosine_similarity, eps = 1e-8
+      sS[i][j] = c;
+      if (i < M && j < M) sim[((int64_t)b * M + i) * M + j] = c;
+    }
+  if (tx == 0)
+    for (int u = 0; u < 4; ++u) if (ty * 4 + u < M) na[(int64_t)b * M + ty * 4 + u] = sqrtf(qa[u]);
+  if (ty == 0)
+    for (int v = 0; v < 4; ++v) if (tx * 4 + v < M) nt[(int64_t)b * M + tx * 4 + v] = sqrtf(qt[v]);
+  __syncthreads();
+  float l = 0.0f;
+  if (tid < M) {  // text slot j = tid: log-sum-exp over the audio slots
+    float mx = -INFINITY;
+    for (int i = 0; i < M; ++i) mx = fmaxf(mx, sS[i][tid] * inv_temp);
+    float se = 0.0f;
+    for (int i = 0; i < M; ++i) se += __expf(sS[i][tid] * inv_temp - mx);
+    l = mx + __logf(se) - sS[tid][tid] * inv_temp;
+  }
+  l = block_sum(l, red);
+  if (tid == 0) atomicAdd(loss, l);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void contrastive_bwd_kernel(const T* a, const T* t, const float* sim, const float* na, const float* nt,
+                                                              const float* gscale, T* da, T* dt, int M, int C, float inv_temp) {
+  __shared__ float sW[CM][CM + 1], sRa[CM], sRt[CM], sNa[CM], sNt[CM];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float g = gscale[0] * inv_temp;
+  const float* S = sim + (int64_t)b * M * M;
+  if (tid < M) { sNa[tid] = fmaxf(na[(int64_t)b * M + tid], 1e-12f); sNt[tid] = fmaxf(nt[(int64_t)b * M + tid], 1e-12f); }
+  __syncthreads();
+  if (tid < M) {  // column j = tid: G[i][j] = g * (softmax_i(L[:, j]) - [i == j]);  W = G / (|a_i| |t_j|);  r_t[j] = sum_i G c
+    const int j = tid;
+    float mx = -INFINITY;
+    for (int i = 0; i < M; ++i) mx = fmaxf(mx, S[i * M + j] * inv_temp);
+    float se = 0.0f;
+    for (int i = 0; i < M; ++i) se += __expf(S[i * M + j] * inv_temp - mx);
+    float rt = 0.0f;
+    for (int i = 0; i < M; ++i) {
+      const float c = S[i * M + j];
+      const float G = g * (__expf(c * inv_temp - mx) / se - (i == j ? 1.0f : 0.0f));
+      rt += G * c;
+      sW[i][j] = G;
+    }
+    sRt[j] = rt;
+  }
+  __syncthreads();
+  if (tid < M) {  // row i = tid: r_a[i] = sum_j G c
+    float ra = 0.0f;
+    for (int j = 0; j < M; ++j) ra += sW[tid][j] * S[tid * M + j];
+    sRa[tid] = ra;
+  }
+  __syncthreads();
+  for (int e = tid; e < M * M; e += 256) { const int i = e / M, j = e % M; sW[i][j] /= fmaxf(sNa[i] * sNt[j], 1e-8f); }
+  __syncthreads();
+  // this workgroup's 64-channel slice of a and t -> LDS; 4 x 4 register blocks of da / dt
+  __shared__ float sA[CM][CM + 1], sT[CM][CM + 1];
+  const int d0 = blockIdx.y * CM;
+  const T* ab = a + (int64_t)b * M * C;
+  const T* tb = t + (int64_t)b * M * C;
+  for (int e = tid; e < CM * CM; e += 256) {
+    const int r = e / CM, c = e % CM;
+    const bool ok = r < M && d0 + c < C;
+    sA[r][c] = ok ? DT<T>::ld(ab + (int64_t)r * C + d0 + c) : 0.0f;
+    sT[r][c] = ok ? DT<T>::ld(tb + (int64_t)r * C + d0 + c) : 0.0f;
+  }
+  for (int e = tid; e < CM * CM; e += 256) { const int i = e / CM, j = e % CM; if (i >= M || j >= M) sW[i][j] = 0.0f; }
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;
+  float xa[4][4] = {}, xt[4][4] = {};
+  for (int j = 0; j < M; ++j) {
+    float w[4], wt[4], tv[4], av[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { w[u] = sW[ty * 4 + u][j]; wt[u] = sW[j][ty * 4 + u]; tv[u] = sT[j][tx * 4 + u]; av[u] = sA[j][tx * 4 + u]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        xa[u][v] = fmaf(w[u], tv[v], xa[u][v]);    // da[i][d] += W[i][j] t[j][d]
+        xt[u][v] = fmaf(wt[u], av[v], xt[u][v]);   // dt[i'][d] += W[j][i'] a[j][d]   (i' = text slot)
+      }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int r = ty * 4 + u;
+    if (r >= M) continue;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int d = d0 + tx * 4 + v;
+      if (d >= C) continue;
+      DT<T>::st(da + ((int64_t)b * M + r) * C + d, xa[u][v] - sRa[r] * sA[r][tx * 4 + v] / (sNa[r] * sNa[r]));
+      DT<T>::st(dt + ((int64_t)b * M + r) * C + d, xt[u][v] - sRt[r] * sT[r][tx * 4 + v] / (sNt[r] * sNt[r]));
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int cst_ls_ce_fwd(const void* logits, const int64_t* target, float* out2, float* lse, int64_t rows, int64_t V,
@@ -180,4 +319,26 @@ extern "C" int cst_adam_step(float* master, float* exp_avg, float* exp_avg_sq, c
   else CST_REQUIRE(false, "cst_adam_step: bad dtypes %d/%d", grad_dtype, param_dtype);
 #undef CST_ADAM
   return cst_check_launch("cst_adam_step");
+}
+
+extern "C" int cst_contrastive_fwd(const void* a, const void* t, float* loss, float* sim, float* na, float* nt, int64_t B, int64_t M,
+                                   int64_t C, float temp, int dtype, cst_stream stream) {
+  CST_REQUIRE(a && t && loss && sim && na && nt && B > 0 && M > 0 && M <= 64 && C > 0 && temp > 0.0f, "cst_contrastive_fwd: bad args (M <= 64)");
+  CST_REQUIRE(dtype == CST_F32 || dtype == CST_BF16, "cst_contrastive_fwd: bad dtype");
+  hipStream_t s = (hipStream_t)stream;
+  CstProfScope prof(CST_K_LOSS, s, 2.0 * B * M * M * C, 2.0 * B * M * C * cst_dtype_size(dtype));
+  if (dtype == CST_BF16) hipLaunchKernelGGL(contrastive_fwd_kernel<bf16_t>, dim3((unsigned)B), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)t, loss, sim, na, nt, (int)M, (int)C, 1.0f / temp);
+  else hipLaunchKernelGGL(contrastive_fwd_kernel<float>, dim3((unsigned)B), dim3(256), 0, s, (const float*)a, (const float*)t, loss, sim, na, nt, (int)M, (int)C, 1.0f / temp);
+  return cst_check_launch("cst_contrastive_fwd");
+}
+
+extern "C" int cst_contrastive_bwd(const void* a, const void* t, const float* sim, const float* na, const float* nt, const float* gscale,
+                                   void* da, void* dt, int64_t B, int64_t M, int64_t C, float temp, int dtype, cst_stream stream) {
+  CST_REQUIRE(a && t && sim && na && nt && gscale && da && dt && B > 0 && M > 0 && M <= 64 && C > 0 && temp > 0.0f, "cst_contrastive_bwd: bad args");
+  CST_REQUIRE(dtype == CST_F32 || dtype == CST_BF16, "cst_contrastive_bwd: bad dtype");
+  hipStream_t s = (hipStream_t)stream;
+  CstProfScope prof(CST_K_LOSS, s, 4.0 * B * M * M * C, 4.0 * B * M * C * cst_dtype_size(dtype));
+  if (dtype == CST_BF16) hipLaunchKernelGGL(contrastive_bwd_kernel<bf16_t>, dim3((unsigned)B, (unsigned)cst_ceil_div(C, 64)), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)t, sim, na, nt, gscale, (bf16_t*)da, (bf16_t*)dt, (int)M, (int)C, 1.0f / temp);
+  else hipLaunchKernelGGL(contrastive_bwd_kernel<float>, dim3((unsigned)B, (unsigned)cst_ceil_div(C, 64)), dim3(256), 0, s, (const float*)a, (const float*)t, sim, na, nt, gscale, (float*)da, (float*)dt, (int)M, (int)C, 1.0f / temp);
+  return cst_check_launch("cst_contrastive_bwd");
 }

@@ -604,3 +604,27 @@ def label_smoothed_nll_loss(logits, target, eps, pad):
     """Returns (loss_sum [differentiable], nll_sum [detached]); fp32 scalars on device."""
     loss, out2 = _LsCeFn.apply(logits, target, float(eps), int(pad))
     return loss, out2[1]
+
+
+class _ContrastiveFn(torch.autograd.Function):
+    """compute_contrastive (criterions/triplet_st_mt_contrastive.py:154-169), summed over utterances and text slots."""
+
+    @staticmethod
+    def forward(ctx, a, t, temp):
+        a, t = a.contiguous(), t.contiguous()
+        loss, sim, na, nt = K.contrastive_fwd(a, t, temp)
+        ctx.save_for_backward(a, t, sim, na, nt)
+        ctx.temp = temp
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        a, t, sim, na, nt = ctx.saved_tensors
+        da, dt = K.contrastive_bwd(a, t, sim, na, nt, dloss.reshape(1).float().contiguous(), ctx.temp)
+        return da, dt, None
+
+
+def contrastive_loss(mem_audio_bm, mem_text_bm, temp):
+    """mem_* [B, M, C] batch-major (same dtype) -> fp32 scalar, sum over utterances and text slots."""
+    assert mem_audio_bm.shape == mem_text_bm.shape and mem_audio_bm.dtype == mem_text_bm.dtype
+    return _ContrastiveFn.apply(mem_audio_bm, mem_text_bm, float(temp))

@@ -297,6 +297,26 @@ def sumsq(x, out):
     L.check(lib.cst_sumsq(L.ptr(x), x.numel(), L.ptr(out), L.ptr(ws), L.dtype_code(x.dtype), L.stream_ptr()), "cst_sumsq")
 
 
+def contrastive_fwd(a, t, temp):
+    """a, t [B, M, C] contiguous -> (loss fp32[1], sim, na, nt)."""
+    B, M, C = a.shape
+    loss = torch.zeros(1, dtype=torch.float32, device=a.device)
+    sim = torch.empty(B, M, M, dtype=torch.float32, device=a.device)
+    na = torch.empty(B, M, dtype=torch.float32, device=a.device)
+    nt = torch.empty_like(na)
+    L.check(L.load().cst_contrastive_fwd(L.ptr(a), L.ptr(t), L.ptr(loss), L.ptr(sim), L.ptr(na), L.ptr(nt), B, M, C, float(temp),
+                                         L.dtype_code(a.dtype), L.stream_ptr()), "cst_contrastive_fwd")
+    return loss, sim, na, nt
+
+
+def contrastive_bwd(a, t, sim, na, nt, gscale, temp):
+    B, M, C = a.shape
+    da, dt = torch.empty_like(a), torch.empty_like(t)
+    L.check(L.load().cst_contrastive_bwd(L.ptr(a), L.ptr(t), L.ptr(sim), L.ptr(na), L.ptr(nt), L.ptr(gscale), L.ptr(da), L.ptr(dt), B, M, C,
+                                         float(temp), L.dtype_code(a.dtype), L.stream_ptr()), "cst_contrastive_bwd")
+    return da, dt
+
+
 def adam_step(master, m, v, grad, param, lr, beta1, beta2, eps, wd, step, grad_scale):
     L.check(L.load().cst_adam_step(L.ptr(master), L.ptr(m), L.ptr(v), L.ptr(grad), L.ptr(param), master.numel(), lr, beta1, beta2,
                                    eps, wd, step, L.ptr(grad_scale), L.dtype_code(grad.dtype), L.dtype_code(param.dtype),

@@ -88,6 +88,8 @@ SYMBOLS = [
     ("cst_dropout", c_int, [c_p, c_p, c_i64, c_f, ctypes.c_uint32, c_int, c_p]),
     ("cst_ls_ce_fwd", c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_f, c_i64, c_int, c_p]),
     ("cst_ls_ce_bwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_f, c_i64, c_int, c_p]),
+    ("cst_contrastive_fwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_int, c_p]),
+    ("cst_contrastive_bwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_int, c_p]),
     ("cst_sumsq_workspace", c_i64, []),
     ("cst_sumsq", c_int, [c_p, c_i64, c_p, c_p, c_int, c_p]),
     ("cst_adam_step", c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_p, c_int, c_int, c_p]),

@@ -223,6 +223,19 @@ int cst_ls_ce_bwd(const void* logits, const int64_t* target, const float* lse, c
                   cst_stream stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Contrastive term of TripletSTMTContrastiveCriterion.compute_contrastive
+ * (criterions/triplet_st_mt_contrastive.py:154-169): a = audio memory, t = text memory, both [B, M, C] batch-major
+ * (M <= 64 slots); c[b,i,j] = cosine(a[b,i], t[b,j]) (fp32, eps 1e-8), logits = c / temp with the AUDIO slot as class
+ * dim and target(j) = j;  loss[0] += sum_b sum_j ( logsumexp_i - logits[j][j] )  (caller zeroes loss).
+ * sim fp32 [B,M,M], na/nt fp32 [B,M] (norms) are saved for backward;  bwd: da, dt = gscale[0] * d loss / d a, t.
+ * ------------------------------------------------------------------------------------------ */
+int cst_contrastive_fwd(const void* a, const void* t, float* loss, float* sim, float* na, float* nt,
+                        int64_t B, int64_t M, int64_t C, float temp, int dtype, cst_stream stream);
+int cst_contrastive_bwd(const void* a, const void* t, const float* sim, const float* na, const float* nt,
+                        const float* gscale, void* da, void* dt, int64_t B, int64_t M, int64_t C, float temp,
+                        int dtype, cst_stream stream);
+
+/* ------------------------------------------------------------------------------------------
  * Optimizer path — replaces FP16Optimizer's flat-copy / unscale / clip / Adam / copy-back chain
  * (optim/fp16_optimizer.py:16-300; utils.py:323-364; optim/adam.py:146-226).
  * ------------------------------------------------------------------------------------------ */

@@ -488,3 +488,24 @@ def test_attention_dropout(K, dt, Tq, Tk, causal):
     check(dq, qf.grad, dt, "attn dropout dq", scale=float(qf.grad.abs().max()) * sc)
     check(dk, kf.grad, dt, "attn dropout dk", scale=float(kf.grad.abs().max()) * sc)
     check(dv, vf.grad, dt, "attn dropout dv", scale=float(vf.grad.abs().max()) * sc)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,M,C", [(3, 64, 512), (2, 8, 64), (1, 33, 72)])
+def test_contrastive(K, dt, B, M, C):
+    """cst_contrastive_fwd/bwd against torch: cosine-similarity logits / temp, CE over the AUDIO slot dim, target(j) = j
+    (criterions/triplet_st_mt_contrastive.py:154-169)."""
+    k, L = K
+    temp = 0.1
+    a = rnd(B, M, C, dt=dt, seed=1)
+    t = (0.5 * a.float() + rnd(B, M, C, dt=torch.float32, seed=2)).to(dt)
+    loss, sim, na, nt = k.contrastive_fwd(a, t, temp)
+    ar, tr = a.float().requires_grad_(True), t.float().requires_grad_(True)
+    logits = F.cosine_similarity(ar.unsqueeze(2), tr.unsqueeze(1), dim=-1) / temp
+    ref = F.cross_entropy(logits, torch.arange(M, device="cuda")[None].repeat(B, 1), reduction="sum")
+    assert abs(float(loss) - float(ref)) <= 2e-4 * abs(float(ref)) + 1e-3, (float(loss), float(ref))
+    ref.backward()
+    g = torch.full((1,), 0.7, device="cuda")
+    da, dtt = k.contrastive_bwd(a, t, sim, na, nt, g, temp)
+    check(da, 0.7 * ar.grad, dt, "contrastive da", scale=float(ar.grad.abs().max()))
+    check(dtt, 0.7 * tr.grad, dt, "contrastive dt", scale=float(tr.grad.abs().max()))
