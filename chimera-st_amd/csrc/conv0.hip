@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* wav, const 
       for (int e = 0; e < 4; ++e) { acc[e] += w0[e] * xv; acc[4 + e] += w1[e] * xv; }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = gelu_f(acc[e]);
+    for (int e = 0; e < 8; ++e) acc[e] = gelu_t<T>(acc[e]);
     store8(y + (b * L + t0 + tl) * C + cv * 8, acc);
   }
 }
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(const T* dy, const float
         const int c = ccv * 8 + e;
         const float uh = (u[e] - sa[2 * C + c]) * sa[3 * C + c];
         const float z = uh * sa[c] + sa[C + c];
-        const float dz = d[e] * dgelu_f(z);
+        const float dz = d[e] * dgelu_t<T>(z);
         s1[e] += dz;
         s2[e] += dz * uh;
 #pragma unroll
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void conv0_fwd_reg_kernel(const float* wav, co
       for (int e = 0; e < 4; ++e) acc[e] = fmaf(wf[j][e], xv, acc[e]);
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] = gelu_f(acc[e]);
+    for (int e = 0; e < 4; ++e) acc[e] = gelu_t<T>(acc[e]);
     store4(y + (b * L + t0 + tl) * C + c0, acc);
   }
 }
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void conv0_bwd_reg_kernel(const T* dy, const f
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float uh = (u[e] - mu[e]) * rs[e];
-      const float dz = d[e] * dgelu_f(fmaf(uh, g[e], be[e]));
+      const float dz = d[e] * dgelu_t<T>(fmaf(uh, g[e], be[e]));
       s1[e] += dz;
       s2[e] = fmaf(dz, uh, s2[e]);
 #pragma unroll

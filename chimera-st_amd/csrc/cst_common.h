@@ -171,6 +171,39 @@ __device__ __forceinline__ float dgelu_f(float x) {
   const float cdf = x >= 0.0f ? 1.0f - q : q;
   return fmaf(x * 0.39894228040143268f, E, cdf);
 }
+// bf16 storage: odd minimax polynomials on the clamped argument (|x| <= 4), 11-13 VALU ops and no transcendental.
+//   gelu:  x * (0.5 + x P13(x^2))   max abs error 3.3e-4   |   gelu':  0.5 + x Q15(x^2)   max abs error 3.1e-4
+// (a bf16 result carries 2^-9 ~ 2e-3 relative rounding; fp32 storage keeps the 3e-7 erf forms above).  The activation
+// epilogues are VALU-bound — 4.9 G GELU and 4.9 G GELU' evaluations per B=32 update (conv0, conv 1-6, 12 x fc1).
+__device__ __forceinline__ float gelu_poly_f(float x) {
+  const float xc = fminf(fmaxf(x, -4.0f), 4.0f), t = xc * xc;
+  float p = fmaf(2.6867663649454698e-08f, t, -1.824730247790285e-06f);
+  p = fmaf(p, t, 5.28495256730821e-05f);
+  p = fmaf(p, t, -0.0008661365136504173f);
+  p = fmaf(p, t, 0.009053179994225502f);
+  p = fmaf(p, t, -0.06526926904916763f);
+  p = fmaf(p, t, 0.39845922589302063f);
+  return x * fmaf(p, xc, 0.5f);
+}
+__device__ __forceinline__ float dgelu_poly_f(float x) {
+  const float xc = fminf(fmaxf(x, -4.0f), 4.0f), t = xc * xc;
+  float p = fmaf(-1.5577683143419563e-08f, t, 1.1633505891950335e-06f);
+  p = fmaf(p, t, -3.7250658351695165e-05f);
+  p = fmaf(p, t, 0.0006728997686877847f);
+  p = fmaf(p, t, -0.0075911665335297585f);
+  p = fmaf(p, t, 0.0555923730134964f);
+  p = fmaf(p, t, -0.26155415177345276f);
+  p = fmaf(p, t, 0.7965189218521118f);
+  return fmaf(p, xc, 0.5f);
+}
+template <typename T> __device__ __forceinline__ float gelu_t(float x) { return sizeof(T) == 2 ? gelu_poly_f(x) : gelu_f(x); }
+template <typename T> __device__ __forceinline__ float dgelu_t(float x) { return sizeof(T) == 2 ? dgelu_poly_f(x) : dgelu_f(x); }
+template <typename T> __device__ __forceinline__ float act_t(float x, int act) {
+  return act == CST_ACT_RELU ? fmaxf(x, 0.0f) : (act == CST_ACT_GELU ? gelu_t<T>(x) : x);
+}
+template <typename T> __device__ __forceinline__ float dact_t(float z, int act) {
+  return act == CST_ACT_RELU ? (z > 0.0f ? 1.0f : 0.0f) : (act == CST_ACT_GELU ? dgelu_t<T>(z) : 1.0f);
+}
 __device__ __forceinline__ float act_f(float x, int act) {
   return act == CST_ACT_RELU ? fmaxf(x, 0.0f) : (act == CST_ACT_GELU ? gelu_f(x) : x);
 }

@@ -51,7 +51,7 @@ __global__ void act_bwd_kernel(const T* dy, const T* z, T* dx, int64_t n8, int a
     load8(dy + i * 8, d);
     load8(z + i * 8, zz);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) d[e] *= dact_f(zz[e], act);
+    for (int e = 0; e < 8; ++e) d[e] *= dact_t<T>(zz[e], act);
     store8(dx + i * 8, d);
   }
 }
@@ -62,7 +62,7 @@ __global__ void act_fwd_kernel(const T* x, T* y, int64_t n8, int act) {
     float v[8];
     load8(x + i * 8, v);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = act_f(v[e], act);
+    for (int e = 0; e < 8; ++e) v[e] = act_t<T>(v[e], act);
     store8(y + i * 8, v);
   }
 }
@@ -131,7 +131,7 @@ __global__ void col2im1d_kernel(const T* dcol, const T* z, T* dx, int64_t B, int
       float zz[8];
       load8(z + (b * Lin + l) * C + c, zz);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] *= dact_f(zz[e], dact);
+      for (int e = 0; e < 8; ++e) acc[e] *= dact_t<T>(zz[e], dact);
     }
     store8(dx + (b * Lin + l) * C + c, acc);
   }

@@ -682,6 +682,9 @@ extern "C" int cst_gemm(const cst_gemm_desc* d, cst_stream stream) {
   p.tiles_m = p.tiles_n = 0;  // set per configuration in launch()
   p.splits = choose_splits(d);
   p.ws = nullptr;
+#ifdef CST_TRACE
+  if (p.splits == 1 && d->workspace) p.ws = (float*)d->workspace;  // cycle-stamp buffer of tools/gemm8p_trace.py
+#endif
   const int64_t nbatch = d->batch0 * d->batch1;
   CST_REQUIRE(cst_ceil_div(d->M, 128) * cst_ceil_div(d->N, 128) < (1ll << 31) && nbatch * p.splits < 65536, "cst_gemm: grid too large");
   if (p.splits > 1) {

@@ -50,6 +50,25 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 template <int N>
 __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Epilogue LDS traffic goes through inline asm: hipcc orders every C++-visible LDS access behind pending LDS-DMA (the next
+// item's first K tile, in flight by design) with an s_waitcnt vmcnt, and inside the read-back loop that wait also drains the
+// previous iteration's global store — 17.7 k cycles per 256 x 256 tile for a plain store.  The image region never overlaps a
+// DMA target, so only the LDS counter has to be honoured (explicit lgkmcnt waits at the call sites).
+__device__ __forceinline__ unsigned lds_off(const void* p) {
+  return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ void lds_write_b64(unsigned addr, uint2 v) {
+  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_write_b128(unsigned addr, f32x4 v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ u32x4 lds_read_b128(unsigned addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, 0, 0, 0);
 }
@@ -264,6 +283,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
 
   // the epilogue image lives in the buffer-1 region (buffer 0 is receiving the next item's first K tile)
   char* const ebase = smem + BUFB;
+  const unsigned ebase_off = lds_off(ebase);
 
   int v = blockIdx.x;
   if (v >= total) return;
@@ -275,7 +295,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
     if (2 < S) stage(I2{}, I0{}, 0);
     if (3 < S) stage(I3{}, I0{}, 0);
   }
+#ifdef CST_TRACE
+  long long* trace = (p.splits == 1 && p.ws) ? reinterpret_cast<long long*>(p.ws) + (int64_t)blockIdx.x * 64 : nullptr;
+  int titem = 0;
+#define CST_STAMP(k) do { if (trace && tid == 0 && titem < 8) trace[titem * 8 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define CST_STAMP(k) do { } while (0)
+#endif
   while (true) {
+    CST_STAMP(0);
     // ---- the item being computed (its first K tile is in flight or landed) ----
     const int64_t e_m0 = m0, e_n0 = n0, e_cofs = cofs, e_bofs = bofs;
     const int e_z = zcur, e_nt = nt;
@@ -309,11 +337,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     }
     if (wm == 1) __builtin_amdgcn_s_barrier();  // stagger: the wm = 1 waves run one barrier behind
+    CST_STAMP(1);
     for (int t = 0; t < e_nt; t += 2) {
       tile_body(I0{}, t, S);
       if (t + 1 < e_nt) tile_body(I1{}, t + 1, S);
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();
+    CST_STAMP(2);
 
     // ---- start streaming the next item before this one's epilogue ----
     v += gridDim.x;
@@ -327,6 +357,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
       if (3 < Sn) stage(I3{}, I0{}, 0);
     }
 
+    CST_STAMP(3);
     asm volatile("" : "+s"(kp));
     GemmParams q;  // epilogue parameters, re-read after the K loop (only the fields used below are materialised)
     q.M = kp->M; q.N = kp->N; q.C = kp->C; q.ldc = kp->ldc; q.bias = kp->bias; q.bias_mode = kp->bias_mode; q.act = kp->act;
@@ -334,23 +365,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
     q.resid = kp->resid; q.ld_resid = kp->ld_resid; q.alpha = kp->alpha; q.splits = kp->splits; q.ws = kp->ws;
     q.c_f32 = kp->c_f32; q.vec_epi = kp->vec_epi; q.drop_thr = kp->drop_thr; q.drop_key = kp->drop_key; q.drop_scale = kp->drop_scale;
     if (fast_epi) {
-      // bf16 image [128 rows][256 cols], row stride 528 B; pass hm = rows [128 hm, 128 hm + 128) of the tile
+      // bf16 image [128 rows][256 cols], row stride 528 B; pass hm = rows [128 hm, 128 hm + 128) of the tile.
+      // Global LOADS and global STORES never share a loop: with stores pending, waiting for a load costs a full vmcnt(0)
+      // (loads and stores retire out of order with respect to each other), i.e. one store round trip per iteration.
+      //   loop A (only with an aux_in / residual operand): z, operand -> final value, written back into the image in place;
+      //   loop B: image -> [pre-activation output] -> [activation, dropout] -> C.
       constexpr int ERS = 528;
+      const T* exsrc = q.dact ? (const T*)q.aux_in : (const T*)q.resid;
+      const int64_t exld = q.dact ? q.ld_aux_in : q.ld_resid;
+      const bool both = q.dact && q.resid;
 #pragma unroll
       for (int hm = 0; hm < 2; ++hm) {
         if (hm) __builtin_amdgcn_s_barrier();  // previous pass fully read back
-        // the pass's extra operand (act'(aux_in), or the residual when there is no aux_in) is fetched first: 8 independent
-        // 16-byte loads per lane in flight under the LDS staging instead of one dependent load per output vector
-        const T* exsrc = q.dact ? (const T*)q.aux_in : (const T*)q.resid;
-        const int64_t exld = q.dact ? q.ld_aux_in : q.ld_resid;
-        auto ex_load = [&](int it) -> u32x4 {
-          const int vi = tid + NTHREADS * it;
-          const int64_t row = e_m0 + hm * 128 + (vi >> 5), col = e_n0 + (vi & 31) * 8;
-          u32x4 r = {0, 0, 0, 0};
-          if (exsrc && it < 8 && row < q.M && col < q.N) r = *reinterpret_cast<const u32x4*>(exsrc + e_cofs + row * exld + col);
-          return r;
-        };
-        u32x4 ex0 = ex_load(0), ex1 = ex_load(1), ex2 = ex_load(2), ex3 = ex_load(3);  // rotating 4-deep window
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -361,23 +387,76 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
               bf16x4_t pk;
 #pragma unroll
               for (int e = 0; e < 4; ++e) pk[e] = static_cast<__bf16>(acc[hm * 2 + i][hn][4 * g + e] * q.alpha);
-              *reinterpret_cast<bf16x4_t*>(ebase + (wm * 64 + i * 32 + lrow) * ERS + (hn * 128 + wn * 32 + 8 * g + 4 * hi) * 2) = pk;
+              lds_write_b64(ebase_off + (wm * 64 + i * 32 + lrow) * ERS + (hn * 128 + wn * 32 + 8 * g + 4 * hi) * 2, __builtin_bit_cast(uint2, pk));
             }
         wait_lgkm<0>();
         __builtin_amdgcn_s_barrier();
-#pragma unroll 1
+        if (exsrc) {
+#pragma unroll 2
+          for (int it = 0; it < 8; ++it) {
+            const int vi = tid + NTHREADS * it;
+            const int rl = vi >> 5, cl = (vi & 31) * 8;
+            const int64_t row = e_m0 + hm * 128 + rl, col = e_n0 + cl;
+            if (row >= q.M || col >= q.N) continue;
+            const u32x4 exv = *reinterpret_cast<const u32x4*>(exsrc + e_cofs + row * exld + col);
+            const u32x4 zraw = lds_read_b128(ebase_off + rl * ERS + cl * 2);
+            wait_lgkm<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            if (q.aux_out) *reinterpret_cast<u32x4*>((T*)q.aux_out + e_cofs + row * q.ld_aux_out + col) = zraw;  // (not on the hot path)
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              x[2 * e] = __uint_as_float(zraw[e] << 16);
+              x[2 * e + 1] = __uint_as_float(zraw[e] & 0xffff0000u);
+            }
+            if (q.act == CST_ACT_RELU) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.0f);
+            } else if (q.act == CST_ACT_GELU) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) x[e] = gelu_t<T>(x[e]);
+            }
+            if (q.drop_thr) cst_drop8(x, q.drop_key, (uint64_t)(row * q.N + col), q.drop_thr, q.drop_scale);
+            if (q.dact) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                x[2 * e] *= dact_t<T>(__uint_as_float(exv[e] << 16), q.dact);
+                x[2 * e + 1] *= dact_t<T>(__uint_as_float(exv[e] & 0xffff0000u), q.dact);
+              }
+              if (both) {
+                float rr[8];
+                load8((const T*)q.resid + e_cofs + row * q.ld_resid + col, rr);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] += rr[e];
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                x[2 * e] += __uint_as_float(exv[e] << 16);
+                x[2 * e + 1] += __uint_as_float(exv[e] & 0xffff0000u);
+              }
+            }
+            bf16x8 ob;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ob[e] = static_cast<__bf16>(x[e]);
+            lds_write_b128(ebase_off + rl * ERS + cl * 2, __builtin_bit_cast(f32x4, ob));
+          }
+          wait_lgkm<0>();  // loop B re-reads this thread's own slots
+        }
+        const bool post = !exsrc && (q.act != CST_ACT_NONE || q.drop_thr);
+#pragma unroll 2
         for (int it = 0; it < 8; ++it) {
-          const u32x4 exv = ex0;
-          ex0 = ex1; ex1 = ex2; ex2 = ex3; ex3 = ex_load(it + 4);
           const int vi = tid + NTHREADS * it;
           const int rl = vi >> 5, cl = (vi & 31) * 8;
           const int64_t row = e_m0 + hm * 128 + rl, col = e_n0 + cl;
           if (row >= q.M || col >= q.N) continue;
-          const u32x4 zraw = *reinterpret_cast<const u32x4*>(ebase + rl * ERS + cl * 2);
-          if (q.aux_out) *reinterpret_cast<u32x4*>((T*)q.aux_out + e_cofs + row * q.ld_aux_out + col) = zraw;
+          const u32x4 zraw = lds_read_b128(ebase_off + rl * ERS + cl * 2);
+          wait_lgkm<0>();
+          __builtin_amdgcn_sched_barrier(0);
           T* cdst = (T*)q.C + e_cofs + row * q.ldc + col;
-          if (q.act == CST_ACT_NONE && !exsrc && !q.drop_thr) {
-            *reinterpret_cast<u32x4*>(cdst) = zraw;
+          if (!exsrc && q.aux_out) __builtin_nontemporal_store(zraw, reinterpret_cast<u32x4*>((T*)q.aux_out + e_cofs + row * q.ld_aux_out + col));
+          if (!post) {
+            __builtin_nontemporal_store(zraw, reinterpret_cast<u32x4*>(cdst));
             continue;
           }
           float x[8];
@@ -391,29 +470,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
             for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.0f);
           } else if (q.act == CST_ACT_GELU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = gelu_f(x[e]);
+            for (int e = 0; e < 8; ++e) x[e] = gelu_t<T>(x[e]);
           }
           if (q.drop_thr) cst_drop8(x, q.drop_key, (uint64_t)(row * q.N + col), q.drop_thr, q.drop_scale);
-          if (q.dact) {
+          {
+            bf16x8 ob;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              x[2 * e] *= dact_f(__uint_as_float(exv[e] << 16), q.dact);
-              x[2 * e + 1] *= dact_f(__uint_as_float(exv[e] & 0xffff0000u), q.dact);
-            }
-            if (q.resid) {
-              float rr[8];
-              load8((const T*)q.resid + e_cofs + row * q.ld_resid + col, rr);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) x[e] += rr[e];
-            }
-          } else if (q.resid) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              x[2 * e] += __uint_as_float(exv[e] << 16);
-              x[2 * e + 1] += __uint_as_float(exv[e] & 0xffff0000u);
-            }
+            for (int e = 0; e < 8; ++e) ob[e] = static_cast<__bf16>(x[e]);
+            __builtin_nontemporal_store(__builtin_bit_cast(u32x4, ob), reinterpret_cast<u32x4*>(cdst));
           }
-          store8(cdst, x);
         }
       }
     } else {
@@ -421,7 +486,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
       constexpr int LDC = BN + 4;
       constexpr int VPR = BN / 8;
       constexpr int ITERS = 64 * VPR / NTHREADS;
-      float* stg = reinterpret_cast<float*>(ebase);
       float* wsp = q.splits > 1 ? q.ws + ((int64_t)e_z) * q.M * q.N : nullptr;
       const bool ws_vec = (q.N % 4) == 0;
 #pragma unroll
@@ -437,7 +501,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
                 f32x4 q;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) q[e] = acc[(ps >> 1) * 2 + i][hn][4 * g + e];
-                *reinterpret_cast<f32x4*>(stg + (i * 32 + lrow) * LDC + hn * 128 + wn * 32 + 8 * g + 4 * hi) = q;
+                lds_write_b128(ebase_off + ((i * 32 + lrow) * LDC + hn * 128 + wn * 32 + 8 * g + 4 * hi) * 4, q);
               }
         }
         wait_lgkm<0>();
@@ -450,8 +514,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
           if (row >= q.M || col >= q.N) continue;
           float x[8];
           {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(stg + rl * LDC + cl);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(stg + rl * LDC + cl + 4);
+            const u32x4 ua = lds_read_b128(ebase_off + (rl * LDC + cl) * 4), ub = lds_read_b128(ebase_off + (rl * LDC + cl + 4) * 4);
+            wait_lgkm<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 a = __builtin_bit_cast(f32x4, ua), b = __builtin_bit_cast(f32x4, ub);
             x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
           }
           const bool full = col + 8 <= q.N;
@@ -467,6 +533,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
         }
       }
     }
+    CST_STAMP(4);
+#ifdef CST_TRACE
+    ++titem;
+#endif
     if (!has_next) break;
     __builtin_amdgcn_s_barrier();  // the image is fully read back: buffer 1 may receive the next item's second K tile
   }

@@ -37,9 +37,9 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int64_t cofs
   if (p.bias_mode == CST_BIAS_COL) v += DT<T>::ld((const T*)p.bias + bofs + col);
   else if (p.bias_mode == CST_BIAS_ROW) v += DT<T>::ld((const T*)p.bias + bofs + row);
   if (p.aux_out) DT<T>::st((T*)p.aux_out + cofs + row * p.ld_aux_out + col, v);
-  v = act_f(v, p.act);
+  v = act_t<T>(v, p.act);
   if (p.drop_thr) v *= cst_drop1(p.drop_key, (uint64_t)(row * p.N + col), p.drop_thr, p.drop_scale);
-  if (p.dact) v *= dact_f(DT<T>::ld((const T*)p.aux_in + cofs + row * p.ld_aux_in + col), p.dact);
+  if (p.dact) v *= dact_t<T>(DT<T>::ld((const T*)p.aux_in + cofs + row * p.ld_aux_in + col), p.dact);
   if (p.resid) v += DT<T>::ld((const T*)p.resid + cofs + row * p.ld_resid + col);
   if (p.c_f32) ((float*)p.C)[cofs + row * p.ldc + col] = v;
   else DT<T>::st((T*)p.C + cofs + row * p.ldc + col, v);
@@ -66,14 +66,14 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int64_t cof
     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
   } else if (p.act == CST_ACT_GELU) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+    for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
   }
   if (p.drop_thr) cst_drop8(v, p.drop_key, (uint64_t)(row * p.N + col), p.drop_thr, p.drop_scale);
   if (p.dact) {
     float z[8];
     load8((const T*)p.aux_in + cofs + row * p.ld_aux_in + col, z);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] *= dact_f(z[e], p.dact);
+    for (int e = 0; e < 8; ++e) v[e] *= dact_t<T>(z[e], p.dact);
   }
   if (p.resid) {
     float r[8];

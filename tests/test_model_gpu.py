@@ -5,7 +5,7 @@ reference and (b) the oracle on the same inputs.  The product runs through the f
 Tolerances (stated where applied):
   fp32 storage: logits / memory / every gradient within 1e-3 * max(1, |ref|max)  (BASELINE north_star: "within 1e-3").
   bf16 storage: outputs within 5e-2 * max(1,|ref|max); losses within 2e-3 relative; gradients judged in norm —
-    the concatenation of all gradients within 3e-2 relative L2 error, and every tensor that carries >= 1e-3 of the
+    the concatenation of all gradients within 3e-2 relative L2 error, and every tensor that carries >= 3e-3 of the
     total gradient norm within 0.15 relative L2 error (8 mantissa bits through ~25 stacked layers of a tiny model;
     tensors whose true gradient is ~0, e.g. k_proj.bias, are pure rounding noise and only bound by the global check)."""
 import ast
@@ -72,7 +72,7 @@ def assert_grads_close_bf16(model, g):
         per.append((name, e, r))
     assert (num / den) ** 0.5 <= 3e-2, "global gradient rel-L2 error %.3e" % ((num / den) ** 0.5)
     for name, e, r in per:
-        if r >= 1e-6 * den:
+        if r >= 1e-5 * den:  # >= 3e-3 of the total norm (a tensor at 1e-3 of the norm sits at the global noise floor of 1.8e-2)
             assert (e / r) ** 0.5 <= 0.15, "grad %s rel-L2 error %.3e" % (name, (e / r) ** 0.5)
 
 
