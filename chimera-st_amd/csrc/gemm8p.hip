@@ -363,7 +363,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
     q.M = kp->M; q.N = kp->N; q.C = kp->C; q.ldc = kp->ldc; q.bias = kp->bias; q.bias_mode = kp->bias_mode; q.act = kp->act;
     q.aux_out = kp->aux_out; q.ld_aux_out = kp->ld_aux_out; q.dact = kp->dact; q.aux_in = kp->aux_in; q.ld_aux_in = kp->ld_aux_in;
     q.resid = kp->resid; q.ld_resid = kp->ld_resid; q.alpha = kp->alpha; q.splits = kp->splits; q.ws = kp->ws;
-    q.c_f32 = kp->c_f32; q.vec_epi = kp->vec_epi; q.drop_thr = kp->drop_thr; q.drop_key = kp->drop_key; q.drop_scale = kp->drop_scale;
+    q.c_f32 = kp->c_f32; q.vec_epi = kp->vec_epi; q.drop_thr = kp->drop_thr; q.drop_key = kp->drop_key; q.drop_scale = kp->drop_scale; q.drop_row0 = kp->drop_row0;
     if (fast_epi) {
       // bf16 image [128 rows][256 cols], row stride 528 B; pass hm = rows [128 hm, 128 hm + 128) of the tile.
       // Global LOADS and global STORES never share a loop: with stores pending, waiting for a load costs a full vmcnt(0)
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) x[e] = gelu_t<T>(x[e]);
             }
-            if (q.drop_thr) cst_drop8(x, q.drop_key, (uint64_t)(row * q.N + col), q.drop_thr, q.drop_scale);
+            if (q.drop_thr) cst_drop8(x, q.drop_key, (uint64_t)((row + q.drop_row0) * q.N + col), q.drop_thr, q.drop_scale);
             if (q.dact) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = gelu_t<T>(x[e]);
           }
-          if (q.drop_thr) cst_drop8(x, q.drop_key, (uint64_t)(row * q.N + col), q.drop_thr, q.drop_scale);
+          if (q.drop_thr) cst_drop8(x, q.drop_key, (uint64_t)((row + q.drop_row0) * q.N + col), q.drop_thr, q.drop_scale);
           {
             bf16x8 ob;
 #pragma unroll

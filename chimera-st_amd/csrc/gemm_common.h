@@ -16,7 +16,8 @@ struct GemmParams {
   const void* aux_in; int64_t ld_aux_in;
   const void* resid; int64_t ld_resid;
   float alpha;
-  uint32_t drop_thr, drop_key; float drop_scale;  // drop_thr == 0: no dropout; element index = row * N + col
+  uint32_t drop_thr, drop_key; float drop_scale;  // drop_thr == 0: no dropout; element index = (row + drop_row0) * N + col
+  int64_t drop_row0;                                // row offset of this launch inside the logical output (row-split launches)
   int64_t batch1;
   int64_t sa0, sa1, sb0, sb1, sc0, sc1;
   int splits;
@@ -38,7 +39,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int64_t cofs
   else if (p.bias_mode == CST_BIAS_ROW) v += DT<T>::ld((const T*)p.bias + bofs + row);
   if (p.aux_out) DT<T>::st((T*)p.aux_out + cofs + row * p.ld_aux_out + col, v);
   v = act_t<T>(v, p.act);
-  if (p.drop_thr) v *= cst_drop1(p.drop_key, (uint64_t)(row * p.N + col), p.drop_thr, p.drop_scale);
+  if (p.drop_thr) v *= cst_drop1(p.drop_key, (uint64_t)((row + p.drop_row0) * p.N + col), p.drop_thr, p.drop_scale);
   if (p.dact) v *= dact_t<T>(DT<T>::ld((const T*)p.aux_in + cofs + row * p.ld_aux_in + col), p.dact);
   if (p.resid) v += DT<T>::ld((const T*)p.resid + cofs + row * p.ld_resid + col);
   if (p.c_f32) ((float*)p.C)[cofs + row * p.ldc + col] = v;
@@ -68,7 +69,7 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int64_t cof
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
   }
-  if (p.drop_thr) cst_drop8(v, p.drop_key, (uint64_t)(row * p.N + col), p.drop_thr, p.drop_scale);
+  if (p.drop_thr) cst_drop8(v, p.drop_key, (uint64_t)((row + p.drop_row0) * p.N + col), p.drop_thr, p.drop_scale);
   if (p.dact) {
     float z[8];
     load8((const T*)p.aux_in + cofs + row * p.ld_aux_in + col, z);

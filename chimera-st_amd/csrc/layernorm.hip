@@ -140,14 +140,15 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(const T* dy, cons
   }
 }
 
-// partial [nblocks][2][cols] -> dgamma/dbeta: block = 64 columns x 16 row-groups, coalesced 256-B row reads
+// partial [nblocks][2][cols] -> dgamma/dbeta: block = 16 columns x 64 row-groups (48 blocks at 768 columns instead of 12: the
+// pass is latency-bound — 1024 partial rows, two loads each — so more, shorter chains win over wider coalescing)
 __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* part, float* dgamma, float* dbeta, int nblocks, int cols) {
-  __shared__ float ra[16][64], rb[16][64];
-  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  __shared__ float ra[64][17], rb[64][17];
+  const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   float a = 0.0f, b = 0.0f;
   if (c < cols)
-    for (int i = g; i < nblocks; i += 16) {
+    for (int i = g; i < nblocks; i += 64) {
       a += part[(int64_t)i * 2 * cols + c];
       b += part[(int64_t)i * 2 * cols + cols + c];
     }
@@ -155,8 +156,8 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* part, 
   rb[g][cl] = b;
   __syncthreads();
   if (g == 0 && c < cols) {
-#pragma unroll
-    for (int k = 1; k < 16; ++k) { a += ra[k][cl]; b += rb[k][cl]; }
+#pragma unroll 8
+    for (int k = 1; k < 64; ++k) { a += ra[k][cl]; b += rb[k][cl]; }
     dgamma[c] = a;
     dbeta[c] = b;
   }
@@ -206,6 +207,6 @@ extern "C" int cst_layernorm_bwd(const void* dy, const void* sx, const void* gam
   else CST_REQUIRE(false, "cst_layernorm_bwd: bad dtype %d", dtype);
   int rc = cst_check_launch("cst_layernorm_bwd");
   if (rc != CST_OK) return rc;
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)cst_ceil_div(cols, 64)), dim3(1024), 0, s, (const float*)workspace, dgamma, dbeta, nb, (int)cols);
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)cst_ceil_div(cols, 16)), dim3(1024), 0, s, (const float*)workspace, dgamma, dbeta, nb, (int)cols);
   return cst_check_launch("cst_layernorm_bwd reduce");
 }
