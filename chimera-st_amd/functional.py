@@ -437,8 +437,13 @@ class _Conv1dCLFn(torch.autograd.Function):
                 dx = K.col2im1d(dcol, pzc, B, Lin, Lout, Cin, k, stride, pad, L.ACT_GELU if prev_z is not None else 0)
         if ctx.needs_input_grad[1]:
             part = torch.empty(B, Cout, k * Cin, dtype=torch.float32, device=dy.device)
+            # one 256 x 256 workgroup per CU: B x tiles workgroups should fill whole rounds of 256 (B = 32, k = 3: 384 = 1.5
+            # rounds -> a 2-way split of the frame axis gives 768 = 3 rounds of half the length)
+            wgs = B * ((Cout + 255) // 256) * ((k * Cin + 255) // 256)
+            rem = wgs % 256
+            sk = 2 if (wgs >= 256 and 0 < rem < 192 and Lout >= 2048) else 1
             K.gemm(dz_rows, xp, part, Cout, k * Cin, Lout, a_kmajor=0, b_kmajor=0, lda=Cout, ldb=stride * Cin, ldc=k * Cin, batch0=B,
-                   sa=(dz_bs, 0), sb=(xp.stride(0), 0), sc=(Cout * k * Cin, 0), a_off=dz_off, split_k=1)
+                   sa=(dz_bs, 0), sb=(xp.stride(0), 0), sc=(Cout * k * Cin, 0), a_off=dz_off, split_k=sk)
             dw = part.sum(0).to(w_cl.dtype)
         if has_bias and ctx.needs_input_grad[2]:
             db = K.colsum(dz_rows.reshape(B * Lout, Cout) if dzp is None else dzp[:, 1:1 + Lout].reshape(B * Lout, Cout)).to(w_cl.dtype)
