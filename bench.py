@@ -202,10 +202,14 @@ def main():
     dt = float(t)
 
     roof = None
-    if not args.no_roofline and rank == 0:
-        lib.prof_enable(True)  # hipEvent pair around every launch of one extra (untimed) update, on the launch stream
+    if not args.no_roofline:
+        # one extra (untimed) update on EVERY rank (its gradient all-reduce is a collective); rank 0 wraps each of its launches
+        # in a hipEvent pair on the launch stream
+        if rank == 0:
+            lib.prof_enable(True)
         trainer.train_step([sample])
-        torch.cuda.synchronize()
+        barrier()
+    if not args.no_roofline and rank == 0:
         table = lib.prof_query()
         lib.prof_enable(False)
         dom = max(table.items(), key=lambda kv: kv[1]["ms"])
