@@ -1,0 +1,232 @@
+"""Device-resident beam search over the incremental decoder — the MI355X-native form of the decode loop of
+fairseq/sequence_generator.py:_generate (:179-541).
+
+The reference runs, per generated token, ~70 module calls, a K/V-cache `index_select` per layer
+(multihead_attention.py:419-437) and several host synchronisations (`.any()`, `masked_select`, Python lists of
+finalized hypotheses).  At batch x beam = 160 rows the arithmetic of a step is a few microseconds per kernel, so the
+loop is launch- and sync-bound.  Here one decode step is a FIXED sequence of C-ABI launches whose only step-dependent
+input is a device-side counter:
+
+    cst_dec_embed -> per layer [LN, packed QKV GEMM, cst_dec_self_attn (append-only caches + ancestry table), out-proj
+    GEMM (+residual), LN, q GEMM, cst_attn_fwd over the per-SENTENCE encoder K/V (beam rows are the query "time" axis, so
+    the encoder K/V are neither replicated nor reordered), out-proj GEMM (+residual), LN, fc1 GEMM (+bias+act), fc2 GEMM
+    (+bias+residual)] -> LN -> vocabulary GEMM -> cst_beam_step (log-softmax, masks, top-2*beam, finalisation, next rows)
+
+The sequence is captured once per (batch, encoder length) in a HIP graph and replayed; the host reads one int32
+(`num_remaining`) every `poll` steps.  Results are the reference's: same candidates, same finalisation order, same
+scores (tests/test_decode_engine_gpu.py checks token ids bit-exactly against the reference's SequenceGenerator fixtures
+and against the module-by-module mirror path)."""
+import ctypes
+import math
+
+import torch
+
+from . import kernels as K
+from . import lib as L
+
+
+class BeamDecodeEngine:
+    def __init__(self, decoder, tgt_dict, beam_size, max_len, min_len=1, normalize_scores=True, len_penalty=1.0,
+                 unk_penalty=0.0, temperature=1.0, use_graph=True, poll=8):
+        self.dec = decoder
+        self.pad, self.unk, self.eos = tgt_dict.pad(), tgt_dict.unk(), tgt_dict.eos()
+        self.vocab = len(tgt_dict)
+        self.beam, self.max_len, self.min_len = int(beam_size), int(max_len), int(min_len)
+        self.normalize_scores, self.len_penalty = bool(normalize_scores), float(len_penalty)
+        self.unk_penalty, self.temperature = float(unk_penalty), float(temperature)
+        self.use_graph, self.poll = use_graph, max(1, int(poll))
+        self._packed = None
+        self._state = {}
+
+    # ------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def supported(decoder):
+        """The fused loop covers the configuration every Chimera / s2t_transformer arch uses: pre-norm layers, sinusoidal
+        positions, encoder attention in every layer, no layernorm_embedding / project_in / adaptive softmax."""
+        try:
+            ok = (decoder.embed_positions is not None and decoder.layernorm_embedding is None and decoder.project_in_dim is None
+                  and decoder.project_out_dim is None and decoder.adaptive_softmax is None and len(decoder.layers) > 0)
+            for l in decoder.layers:
+                ok = ok and l.normalize_before and l.encoder_attn is not None and l.self_attn.head_dim in (32, 64)
+                ok = ok and l.self_attn.q_proj.bias is not None and l.encoder_attn.head_dim == l.self_attn.head_dim
+            return bool(ok)
+        except AttributeError:
+            return False
+
+    def _pack(self, dtype, device):
+        """Per-layer packed [3C, C] self-attention projection (weights are constants in eval mode)."""
+        # weights may have been updated since the last call (training between validations): re-pack and drop the graphs
+        key = (dtype, device, tuple((p.data_ptr(), p._version) for p in self.dec.parameters()))
+        if self._packed is not None and self._packed[0] == key:
+            return self._packed[1]
+        self._state.clear()
+        layers = []
+        for l in self.dec.layers:
+            sa = l.self_attn
+            layers.append(dict(
+                wqkv=torch.cat((sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight), 0).detach().contiguous(),
+                bqkv=torch.cat((sa.q_proj.bias, sa.k_proj.bias, sa.v_proj.bias), 0).detach().contiguous()))
+        pos = self.dec.embed_positions
+        need = self.dec.padding_idx + 2 + self.max_len + 1
+        table = pos.get_embedding(need, pos.embedding_dim, pos.padding_idx).to(device=device, dtype=torch.float32).contiguous()
+        # the module path adds positions converted to the storage dtype (models/transformer.py:756 on a .half()/bf16 model)
+        if dtype != torch.float32:
+            table = table.to(dtype).float()
+        self._packed = (key, dict(layers=layers, pos=table))
+        return self._packed[1]
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _alloc(self, bsz, S, dtype, device, has_mask):
+        key = (bsz, S, dtype, device, has_mask)
+        st = self._state.get(key)
+        if st is not None:
+            return st
+        self._state.clear()  # one resident configuration (caches are the large buffers)
+        beam, L1, LT = self.beam, self.max_len + 1, self.max_len + 2
+        bbsz, C, nl = bsz * beam, self.dec.embed_dim, len(self.dec.layers)
+        F = self.dec.layers[0].fc1.out_features
+        z = lambda *shape, dt=dtype: torch.zeros(*shape, dtype=dt, device=device)
+        st = dict(
+            step=z(1, dt=torch.int32), num_remaining=z(1, dt=torch.int32),
+            tokens=z(2, bbsz, LT, dt=torch.int64), scores=z(2, bbsz, L1, dt=torch.float32), anc=z(2, bbsz, L1, dt=torch.int32),
+            ignore=z(bsz, beam, dt=torch.uint8), finished=z(bsz, dt=torch.uint8), nfinal=z(bsz, dt=torch.int32),
+            fin_tokens=z(bsz, beam, L1, dt=torch.int64), fin_pos=z(bsz, beam, L1, dt=torch.float32),
+            fin_score=z(bsz, beam, dt=torch.float32), fin_len=z(bsz, beam, dt=torch.int32),
+            x=z(bbsz, C), x2=z(bbsz, C), h=z(bbsz, C), qkv=z(bbsz, 3 * C), q=z(bbsz, C), attn=z(bbsz, C), f=z(bbsz, F),
+            logits=z(bbsz, (self.vocab + 7) // 8 * 8),
+            mean=z(bbsz, dt=torch.float32), rstd=z(bbsz, dt=torch.float32), lse=z(bsz * 64 * beam, dt=torch.float32),
+            kc=[z(bbsz, L1, C) for _ in range(nl)], vc=[z(bbsz, L1, C) for _ in range(nl)],
+            kx=[z(bsz, S, C) for _ in range(nl)], vx=[z(bsz, S, C) for _ in range(nl)],
+            kpm=z(bsz, S, dt=torch.uint8) if has_mask else None, graph=None)
+        d = L.BeamDesc()
+        d.dtype = L.dtype_code(dtype)
+        d.bsz, d.beam, d.vocab, d.max_len = bsz, beam, self.vocab, self.max_len
+        d.pad, d.unk, d.eos, d.min_len = self.pad, self.unk, self.eos, self.min_len
+        d.unk_penalty, d.len_penalty, d.temperature = self.unk_penalty, self.len_penalty, self.temperature
+        d.normalize_scores = int(self.normalize_scores)
+        d.logits, d.ld_logits = st["logits"].data_ptr(), st["logits"].stride(0)
+        d.step, d.tokens, d.scores, d.anc = (st[k].data_ptr() for k in ("step", "tokens", "scores", "anc"))
+        d.cands_to_ignore, d.finished, d.nfinal = st["ignore"].data_ptr(), st["finished"].data_ptr(), st["nfinal"].data_ptr()
+        d.num_remaining = st["num_remaining"].data_ptr()
+        d.fin_tokens, d.fin_pos, d.fin_score, d.fin_len = (st[k].data_ptr() for k in ("fin_tokens", "fin_pos", "fin_score", "fin_len"))
+        st["desc"] = d
+        self._state[key] = st
+        return st
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _linear(self, x, w, b, out, act=L.ACT_NONE, resid=None):
+        M, Kd = x.shape
+        N = w.shape[0]
+        K.gemm(x, w, out, M, N, Kd, a_kmajor=1, b_kmajor=1, lda=Kd, ldb=Kd, ldc=out.stride(0), bias=b, act=act,
+               resid=resid, ld_resid=0 if resid is None else resid.stride(0), split_k=-1)
+
+    def _ln(self, x, ln, out, st):
+        lib = L.load()
+        L.check(lib.cst_layernorm_fwd(L.ptr(x), None, L.ptr(ln.weight), L.ptr(ln.bias), L.ptr(out), None, L.ptr(st["mean"]),
+                                      L.ptr(st["rstd"]), x.shape[0], x.shape[1], ln.eps, L.dtype_code(x.dtype), L.stream_ptr()),
+                "cst_layernorm_fwd")
+
+    def _step(self, st, pk, bsz):
+        """One decode step: every launch reads the step counter from device memory."""
+        lib, dec = L.load(), self.dec
+        bbsz, C = st["x"].shape
+        dt = L.dtype_code(st["x"].dtype)
+        H = dec.layers[0].self_attn.num_heads
+        D = C // H
+        L.check(lib.cst_dec_embed(L.ptr(st["tokens"]), L.ptr(st["step"]), L.ptr(dec.embed_tokens.weight), L.ptr(pk["pos"]),
+                                  float(dec.embed_scale), dec.padding_idx, L.ptr(st["x"]), bbsz, C, self.max_len,
+                                  pk["pos"].shape[0], dt, L.stream_ptr()), "cst_dec_embed")
+        x, x2 = st["x"], st["x2"]
+        for li, layer in enumerate(dec.layers):
+            sa, ca, p = layer.self_attn, layer.encoder_attn, pk["layers"][li]
+            self._ln(x, layer.self_attn_layer_norm, st["h"], st)
+            self._linear(st["h"], p["wqkv"], p["bqkv"], st["qkv"])
+            L.check(lib.cst_dec_self_attn(L.ptr(st["qkv"]), L.ptr(st["kc"][li]), L.ptr(st["vc"][li]), L.ptr(st["anc"]),
+                                          L.ptr(st["step"]), L.ptr(st["attn"]), bbsz, H, D, self.max_len, float(sa.scaling), dt,
+                                          L.stream_ptr()), "cst_dec_self_attn")
+            self._linear(st["attn"], sa.out_proj.weight, sa.out_proj.bias, x2, resid=x)
+            x, x2 = x2, x
+            self._ln(x, layer.encoder_attn_layer_norm, st["h"], st)
+            self._linear(st["h"], ca.q_proj.weight, ca.q_proj.bias, st["q"])
+            # cross attention: batch = sentence, query "time" axis = the beam rows of that sentence
+            q3, o3 = st["q"].view(bsz, self.beam, C), st["attn"].view(bsz, self.beam, C)
+            d = K.attn_desc(q3, st["kx"][li], st["vx"][li], o3, st["lse"], H, D, st["kpm"], False, float(ca.scaling))
+            K.attn_fwd_desc(d)
+            self._linear(st["attn"], ca.out_proj.weight, ca.out_proj.bias, x2, resid=x)
+            x, x2 = x2, x
+            self._ln(x, layer.final_layer_norm, st["h"], st)
+            act = L.ACT_GELU if layer.activation_fn == "gelu" else L.ACT_RELU
+            self._linear(st["h"], layer.fc1.weight, layer.fc1.bias, st["f"], act=act)
+            self._linear(st["f"], layer.fc2.weight, layer.fc2.bias, x2, resid=x)
+            x, x2 = x2, x
+        if dec.layer_norm is not None:
+            self._ln(x, dec.layer_norm, st["h"], st)
+            feat = st["h"]
+        else:
+            feat = x
+        w = dec.output_projection.weight
+        K.gemm(feat, w, st["logits"], bbsz, w.shape[0], C, a_kmajor=1, b_kmajor=1, lda=C, ldb=C, ldc=st["logits"].stride(0), split_k=-1)
+        L.check(lib.cst_beam_step(ctypes.byref(st["desc"]), L.stream_ptr()), "cst_beam_step")
+        # an even number of x/x2 swaps per layer (3) x layers may leave the residual stream in x2: the NEXT step's embed always
+        # writes st["x"], and every step performs the same swaps, so the captured sequence is step-invariant.
+
+    # ------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate(self, encoder_out, bsz):
+        """encoder_out: EncoderOut with encoder_out [S, B, C] (T x B x C view) and encoder_padding_mask [B, S] or None.
+        Returns the reference's `finalized` structure (list over sentences of hypothesis dicts, best first)."""
+        enc = encoder_out.encoder_out
+        S, B, Ce = enc.shape
+        assert B == bsz
+        dtype, device = enc.dtype, enc.device
+        mask = encoder_out.encoder_padding_mask
+        has_mask = mask is not None and mask.dim() == 2
+        pk = self._pack(dtype, device)
+        st = self._alloc(bsz, S, dtype, device, has_mask)
+        encb = enc.transpose(0, 1)
+        encb = encb if encb.is_contiguous() else encb.contiguous()
+        flat = encb.reshape(bsz * S, Ce)
+        for li, layer in enumerate(self.dec.layers):  # static cross-attention K/V, once per sentence (not per beam)
+            ca = layer.encoder_attn
+            self._linear(flat, ca.k_proj.weight, ca.k_proj.bias, st["kx"][li].view(bsz * S, -1))
+            self._linear(flat, ca.v_proj.weight, ca.v_proj.bias, st["vx"][li].view(bsz * S, -1))
+        if has_mask:
+            st["kpm"].copy_(mask.to(torch.uint8))
+        lib = L.load()
+        L.check(lib.cst_beam_init(ctypes.byref(st["desc"]), L.stream_ptr()), "cst_beam_init")
+
+        steps_done = 0
+        if self.use_graph and st["graph"] is None:
+            self._step(st, pk, bsz)  # eager warm-up step 0 (loads code objects, sizes the GEMM workspace)
+            steps_done = 1
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step(st, pk, bsz)
+            st["graph"] = g
+        total = self.max_len + 1
+        remaining = bsz
+        while steps_done < total and remaining > 0:
+            n = min(self.poll, total - steps_done)
+            for _ in range(n):
+                if self.use_graph:
+                    st["graph"].replay()
+                else:
+                    self._step(st, pk, bsz)
+            steps_done += n
+            remaining = int(st["num_remaining"].item())  # the only host sync of the loop
+        assert remaining == 0, "beam search did not terminate within max_len + 1 steps"
+
+        # hypotheses are views of ONE device-side copy of the result buffers (the engine state is reused by the next call)
+        d_tokens, d_pos, d_score = st["fin_tokens"].clone(), st["fin_pos"].clone(), st["fin_score"].clone()
+        fin_score, fin_len, nfinal = d_score.cpu(), st["fin_len"].cpu(), st["nfinal"].cpu()
+        finalized = []
+        for b in range(bsz):
+            hyps = []
+            for r in range(int(nfinal[b])):
+                n = int(fin_len[b, r])
+                hyps.append({"tokens": d_tokens[b, r, :n], "score": d_score[b, r], "attention": None, "alignment": None,
+                             "positional_scores": d_pos[b, r, :n]})
+            _, order = torch.sort(fin_score[b, :len(hyps)], descending=True)  # sequence_generator.py:529-540
+            finalized.append([hyps[i] for i in order.tolist()])
+        return finalized

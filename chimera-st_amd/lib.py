@@ -61,6 +61,21 @@ class AttnDesc(ctypes.Structure):
     ]
 
 
+class BeamDesc(ctypes.Structure):
+    _fields_ = [
+        ("dtype", c_int),
+        ("bsz", c_i64), ("beam", c_i64), ("vocab", c_i64), ("max_len", c_i64),
+        ("pad", c_i64), ("unk", c_i64), ("eos", c_i64), ("min_len", c_i64),
+        ("unk_penalty", c_f), ("len_penalty", c_f), ("temperature", c_f),
+        ("normalize_scores", c_int),
+        ("logits", c_p), ("ld_logits", c_i64),
+        ("step", c_p),
+        ("tokens", c_p), ("scores", c_p), ("anc", c_p),
+        ("cands_to_ignore", c_p), ("finished", c_p), ("nfinal", c_p), ("num_remaining", c_p),
+        ("fin_tokens", c_p), ("fin_pos", c_p), ("fin_score", c_p), ("fin_len", c_p),
+    ]
+
+
 # every symbol include/cst.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("cst_last_error", ctypes.c_char_p, []),
@@ -93,6 +108,10 @@ SYMBOLS = [
     ("cst_sumsq_workspace", c_i64, []),
     ("cst_sumsq", c_int, [c_p, c_i64, c_p, c_p, c_int, c_p]),
     ("cst_adam_step", c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_p, c_int, c_int, c_p]),
+    ("cst_beam_init", c_int, [ctypes.POINTER(BeamDesc), c_p]),
+    ("cst_beam_step", c_int, [ctypes.POINTER(BeamDesc), c_p]),
+    ("cst_dec_embed", c_int, [c_p, c_p, c_p, c_p, c_f, c_i64, c_p, c_i64, c_i64, c_i64, c_i64, c_int, c_p]),
+    ("cst_dec_self_attn", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_f, c_int, c_p]),
 ]
 
 _lib = None

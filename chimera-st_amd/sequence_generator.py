@@ -35,7 +35,7 @@ class BeamSearch:
 class SequenceGenerator:
     def __init__(self, models, tgt_dict, beam_size=1, max_len_a=0, max_len_b=200, min_len=1, normalize_scores=True,
                  len_penalty=1.0, unk_penalty=0.0, temperature=1.0, match_source_len=False, no_repeat_ngram_size=0,
-                 search_strategy=None, eos=None):
+                 search_strategy=None, eos=None, fused=True, use_graph=True):
         self.model = models[0] if isinstance(models, (list, tuple)) else models
         self.tgt_dict = tgt_dict
         self.pad, self.unk = tgt_dict.pad(), tgt_dict.unk()
@@ -47,6 +47,12 @@ class SequenceGenerator:
         self.temperature = temperature
         assert temperature > 0 and not match_source_len and no_repeat_ngram_size == 0
         self.search = BeamSearch(tgt_dict) if search_strategy is None else search_strategy
+        # fused=True (default): the device-resident loop of decode_engine.py (one captured HIP graph per step, no per-step host
+        # sync); fused=False: the module-by-module mirror of the reference loop below (same kernels, host-driven) — kept as the
+        # readable restatement and as the cross-check of the engine.  A custom search strategy needs the host loop.
+        self.fused = bool(fused) and search_strategy is None and (eos is None or eos == tgt_dict.eos())
+        self._engine = None
+        self.use_graph = use_graph
         self.model.eval()
 
     @torch.no_grad()
@@ -71,6 +77,14 @@ class SequenceGenerator:
         max_len = min(int(self.max_len_a * src_len + self.max_len_b), self.model.max_decoder_positions() - 1)
         assert self.min_len <= max_len
         encoder_out = self.model.encoder.forward_torchscript(net_input)
+        if self.fused:
+            from .decode_engine import BeamDecodeEngine
+            if BeamDecodeEngine.supported(self.model.decoder):
+                if self._engine is None or self._engine.max_len != max_len:
+                    self._engine = BeamDecodeEngine(self.model.decoder, self.tgt_dict, beam_size, max_len, self.min_len,
+                                                    self.normalize_scores, self.len_penalty, self.unk_penalty, self.temperature,
+                                                    use_graph=self.use_graph)
+                return self._engine.generate(encoder_out, bsz)
         new_order = torch.arange(bsz, device=device).view(-1, 1).repeat(1, beam_size).view(-1)
         encoder_out = self.model.encoder.reorder_encoder_out(encoder_out, new_order)
         incremental_state: Dict[str, Dict[str, Optional[Tensor]]] = {}

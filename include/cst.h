@@ -251,6 +251,48 @@ int cst_adam_step(float* master, float* exp_avg, float* exp_avg_sq, const void* 
                   int64_t step, const float* grad_scale, int grad_dtype, int param_dtype,
                   cst_stream stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Device-resident incremental decoding — replaces the per-step host loop of
+ * fairseq/sequence_generator.py:_generate (:286-541), search.py BeamSearch.step (:109-144), finalize_hypos
+ * (:575-696), the incremental self-attention branch of modules/multihead_attention.py:189-293 and
+ * reorder_incremental_state (:419-437).  Every kernel reads the step counter from DEVICE memory, so one decode step is
+ * a fixed launch sequence (capturable in a hipGraph); the host polls *num_remaining instead of synchronising per step.
+ *
+ * State (all caller-owned device buffers; bbsz = bsz*beam, L1 = max_len+1, LT = max_len+2):
+ *   step int32[1]; tokens int64[2][bbsz][LT], scores f32[2][bbsz][L1], anc int32[2][bbsz][L1]: ping-pong halves, step s
+ *   reads half (s & 1) and writes half ((s+1) & 1).  anc[h][j] = cache row holding position j of hypothesis h (the K/V
+ *   caches are append-only: row h writes slot [h][s]; a beam reorder moves ancestry entries, not cache contents).
+ *   cands_to_ignore u8[bsz][beam], finished u8[bsz], nfinal int32[bsz], num_remaining int32[1];
+ *   finalized hypotheses in emission order: fin_tokens int64[bsz][beam][L1], fin_pos f32[bsz][beam][L1] (positional
+ *   scores), fin_score f32[bsz][beam] (length-normalised when normalize_scores), fin_len int32[bsz][beam].
+ * cst_beam_step: fp32 log-softmax of logits [bbsz, vocab] (/temperature), NaN/pad/unk/min-len/max-len masks, + cumulative
+ *   score, top-(2*beam) per sentence, eos finalisation, next active hypotheses, then *step += 1.  beam <= 20.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int dtype;                         /* storage type of logits */
+  int64_t bsz, beam, vocab, max_len;
+  int64_t pad, unk, eos, min_len;
+  float unk_penalty, len_penalty, temperature;
+  int normalize_scores;
+  const void* logits; int64_t ld_logits;
+  int32_t* step;
+  int64_t* tokens; float* scores; int32_t* anc;
+  uint8_t* cands_to_ignore; uint8_t* finished; int32_t* nfinal; int32_t* num_remaining;
+  int64_t* fin_tokens; float* fin_pos; float* fin_score; int32_t* fin_len;
+} cst_beam_desc;
+int cst_beam_init(const cst_beam_desc* d, cst_stream stream);
+int cst_beam_step(const cst_beam_desc* d, cst_stream stream);
+/* out[h] = scale * embed[tokens[s&1][h][s]] + pos_table[pad_idx + 1 + s], s = *step (models/transformer.py:744-760,
+ * sinusoidal_positional_embedding.py:88-95).  embed/out in `dtype`, pos_table fp32 [pos_rows, C]. */
+int cst_dec_embed(const int64_t* tokens, const int32_t* step, const void* embed, const float* pos_table, float scale,
+                  int64_t pad_idx, void* out, int64_t rows, int64_t C, int64_t max_len, int64_t pos_rows, int dtype,
+                  cst_stream stream);
+/* Single-query self-attention at position s = *step: qkv [rows, 3*H*D] (q | k | v of the newest token), caches
+ * [rows, L1, H*D]; appends k/v at slot s, attends over positions 0..s through anc (half s & 1), out [rows, H*D].
+ * `scale` multiplies QK^T in fp32.  D in {32, 64}. */
+int cst_dec_self_attn(const void* qkv, void* kcache, void* vcache, const int32_t* anc, const int32_t* step, void* out,
+                      int64_t rows, int64_t H, int64_t D, int64_t max_len, float scale, int dtype, cst_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -476,21 +476,27 @@ def beam_search(p: P, enc, enc_pm, cfg, beam: int, max_len: int, min_len: int = 
     """SequenceGenerator._generate + BeamSearch.step (sequence_generator.py:179-541; search.py:109-144),
     restated per sentence (no batch shrinking).  enc [Tk,B,C].  Returns per sentence a list of
     finalized hypotheses sorted by score: dict(tokens, score, positional_scores)."""
-    B = enc.size(1)
-    results = []
-    for b in range(B):
+    def lp(b, tokens):
         e = enc[:, b:b + 1].repeat(1, beam, 1)
         epm = enc_pm[b:b + 1].repeat(beam, 1) if enc_pm is not None else None
+        return decoder_step_logprobs(p, tokens, e, epm, cfg)
+
+    return beam_search_with(lp, enc.size(1), beam, max_len, min_len, pad, eos, unk, bos, len_penalty, unk_penalty, normalize_scores)
+
+
+def beam_search_with(logprob_fn, B: int, beam: int, max_len: int, min_len: int = 1, pad=1, eos=2, unk=3, bos=2,
+                     len_penalty=1.0, unk_penalty=0.0, normalize_scores=True):
+    """The search loop itself, over any `logprob_fn(sentence, tokens[beam, step+1]) -> lprobs[beam, V]` (fp32
+    log-probabilities of the next token).  Lets the search bookkeeping be checked apart from the decoder."""
+    results = []
+    for b in range(B):
         tokens = torch.full((beam, max_len + 2), pad, dtype=torch.long)
         tokens[:, 0] = bos  # eos is the bos of generation (sequence_generator.py:248-249)
         scores = torch.zeros(beam, max_len + 1)
         finalized = []
         cand_size = 2 * beam
-        active = torch.arange(beam)
-        n_active = beam
-        done = False
         for step in range(max_len + 1):
-            lprobs = decoder_step_logprobs(p, tokens[:, :step + 1], e, epm, cfg)
+            lprobs = logprob_fn(b, tokens[:, :step + 1]).clone()
             lprobs[lprobs != lprobs] = -math.inf
             lprobs[:, pad] = -math.inf
             lprobs[:, unk] -= unk_penalty
@@ -520,7 +526,6 @@ def beam_search(p: P, enc, enc_pm, cfg, beam: int, max_len: int, min_len: int = 
                         sc = sc / ((step + 1) ** len_penalty)
                     finalized.append(dict(tokens=toks, score=sc, positional_scores=pos))
             if len(finalized) >= beam or step >= max_len:
-                done = True
                 break
             # pick the first `beam` non-eos candidates as the new active set (:471-499)
             keep = [j for j in range(top_s.numel()) if not eos_mask[j]][:beam]

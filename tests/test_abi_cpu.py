@@ -50,7 +50,7 @@ def test_library_exports_every_declared_symbol(built):
 def test_descriptor_structs_match_header_field_order(built):
     src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
     bodies = {name: body for body, name in re.findall(r"typedef struct \{([^{}]*)\} (\w+);", src)}
-    for struct, cls in (("cst_gemm_desc", built.GemmDesc), ("cst_attn_desc", built.AttnDesc)):
+    for struct, cls in (("cst_gemm_desc", built.GemmDesc), ("cst_attn_desc", built.AttnDesc), ("cst_beam_desc", built.BeamDesc)):
         body = bodies[struct]
         names = []
         for decl in body.split(";"):
