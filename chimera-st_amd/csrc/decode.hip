@@ -25,7 +25,7 @@ struct BeamP {
   int64_t* fin_tokens; float* fin_pos; float* fin_score; int32_t* fin_len;
 };
 
-__global__ void beam_init_kernel(BeamP p) {
+__global__ void beam_init_kernel(BeamP p, int32_t* ticket) {
   const int h = blockIdx.x, bbsz = p.bsz * p.beam, L1 = p.max_len + 1, LT = p.max_len + 2;
   for (int buf = 0; buf < 2; ++buf) {
     int64_t* tk = p.tokens + ((int64_t)buf * bbsz + h) * LT;
@@ -49,26 +49,244 @@ __global__ void beam_init_kernel(BeamP p) {
     if (h == 0) {
       *p.step = 0;
       *p.num_remaining = p.bsz;
+      *ticket = 0;
     }
   }
 }
 
-__global__ void beam_advance_kernel(int32_t* step) { *step += 1; }
-
 __device__ __forceinline__ bool cand_better(float x, int i, float y, int j) { return x > y || (x == y && i < j); }
+constexpr int BEAM_MAX = 20, KMAX_ALL = 2 * BEAM_MAX;
 
-// One workgroup per sentence.  (a) fp32 log-softmax statistics of the `rows` live hypothesis rows (utils.py:469-473 via
-// models/fairseq_decoder.py:58-79), (b) the masks of sequence_generator.py:311-331 and the cumulative-score add of search.py:121-126,
-// (c) top-(2*beam) over rows*V candidates (search.py:127-135): per-thread sorted lists merged by 2*beam block-wide arg-max
-// rounds, (d) the eos / finalize / active-hypothesis bookkeeping of sequence_generator.py:340-499 and finalize_hypos :575-696,
-// (e) the token / score / ancestry rows of the next step written into the other half of the ping-pong buffers.
-template <typename T, int KMAX>
-__global__ __launch_bounds__(1024) void beam_step_kernel(BeamP p) {
-  constexpr int KB = KMAX / 2 > 0 ? KMAX / 2 : 1;  // max beam for this instantiation
+// ---- beam search step, kernel 1 of 2: one workgroup per hypothesis ROW -------------------------------------------------------
+// (a) fp32 log-softmax statistics of the row (utils.py:469-473 via models/fairseq_decoder.py:58-79), (b) the masks of
+// sequence_generator.py:311-331 and the cumulative-score add of search.py:121-126, (c) the row's top-(2*beam) candidates in
+// descending (value, then ascending token) order -> cand_val / cand_tok [row][2*beam].
+// The row's logits stay in registers (NV 16-byte vectors per thread) between the statistics pass and the selection; the
+// selection is 2*beam block-wide arg-max rounds in which only the winning thread rescans its registers (an earlier version kept
+// a sorted top-K list per thread for a whole sentence per workgroup: the divergent insertion chains made it 105 us per step).
+template <typename T, int NV>
+__global__ __launch_bounds__(512) void beam_row_topk_kernel(BeamP p, float* cand_val, int32_t* cand_tok) {
+  constexpr int VEC = DT<T>::VEC, NTH = 512, NW = NTH / 64;
   const int s = *p.step;
   if (s > p.max_len) return;
-  const int sent = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
-  const int beam = p.beam, V = p.vocab, K = 2 * beam, bbsz = p.bsz * beam;
+  const int h = blockIdx.x, r = h % p.beam;
+  if (s == 0 && r != 0) return;  // all hypotheses are equal at step 0: only the first beam competes (search.py:121-124)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int V = p.vocab, K = 2 * p.beam, L1 = p.max_len + 1;
+  const int nvec = (V + VEC - 1) / VEC;
+  const T* lg = reinterpret_cast<const T*>(p.logits) + (int64_t)h * p.ld_logits;
+  const float NEG = -INFINITY;
+  __shared__ float red_m[NW], red_s[NW], wv[NW];
+  __shared__ int wi[NW];
+  __shared__ float sh_lse;
+  __shared__ float o_val[KMAX_ALL];
+  __shared__ int o_tok[KMAX_ALL];
+
+  float x[NV][VEC];
+  float mx = NEG;
+  bool nan = false;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int vi = tid + i * NTH;
+    if (vi < nvec) {
+      if constexpr (VEC == 8) { float t8[8]; load8(lg + (int64_t)vi * 8, t8); for (int e = 0; e < 8; ++e) x[i][e] = t8[e]; }
+      else { const f32x4 a4 = *reinterpret_cast<const f32x4*>(lg + (int64_t)vi * 4); for (int e = 0; e < 4; ++e) x[i][e] = a4[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      x[i][e] = (vi < nvec && vi * VEC + e < V) ? x[i][e] * p.inv_temperature : NEG;
+      nan = nan || x[i][e] != x[i][e];
+      mx = fmaxf(mx, x[i][e]);
+    }
+  }
+  float sum = 0.0f;
+  if (mx != NEG) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) sum += expf(x[i][e] - mx);
+  }
+  if (nan) sum = NAN;  // NaN logits: lse NaN -> every candidate of the row becomes -inf (sequence_generator.py:311)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m2 = __shfl_xor(mx, o, 64), s2 = __shfl_xor(sum, o, 64);
+    const float M = fmaxf(mx, m2);
+    sum = (mx == NEG ? 0.0f : sum * expf(mx - M)) + (m2 == NEG ? 0.0f : s2 * expf(m2 - M));
+    mx = M;
+  }
+  if (lane == 0) { red_m[wave] = mx; red_s[wave] = sum; }
+  __syncthreads();
+  if (tid == 0) {
+    float mm = NEG, ss = 0.0f;
+    for (int w = 0; w < NW; ++w) {
+      const float m2 = red_m[w], s2 = red_s[w];
+      const float M = fmaxf(mm, m2);
+      ss = (mm == NEG ? 0.0f : ss * expf(mm - M)) + (m2 == NEG ? 0.0f : s2 * expf(m2 - M));
+      mm = M;
+    }
+    sh_lse = mm + logf(ss);
+  }
+  __syncthreads();
+  const float lse = sh_lse;
+  const float prev = s > 0 ? (p.scores + (int64_t)(s & 1) * p.bsz * p.beam * L1)[(int64_t)h * L1 + s - 1] : 0.0f;
+  // candidate values replace the logits in the registers
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int vi = tid + i * NTH;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int v = vi * VEC + e;
+      float val = x[i][e] - lse;
+      if (val != val) val = NEG;                       // lprobs[lprobs != lprobs] = -inf        (:311)
+      if (v == p.pad) val = NEG;                       // never select pad                        (:313)
+      if (v == p.unk) val -= p.unk_penalty;            //                                         (:314)
+      if (s >= p.max_len && v != p.eos) val = NEG;     // force eos at max length                 (:317-319)
+      if (s < p.min_len && v == p.eos) val = NEG;      // minimum length constraint               (:329-331)
+      if (s > 0) val += prev;                          // search.py:125
+      x[i][e] = (vi < nvec && v < V) ? val : NAN;      // NaN = not a candidate (never compares better)
+    }
+  }
+  // local best that is strictly worse than (tv, ti) — the thread's previously taken candidate
+  float tv = INFINITY, bv;
+  int ti = -1, bi;
+  auto rescan = [&]() {
+    bv = NEG; bi = INT_MAX;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int vi = tid + i * NTH;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float val = x[i][e];
+        const int v = vi * VEC + e;
+        const bool open = val < tv || (val == tv && v > ti);
+        if (open && val == val && cand_better(val, v, bv, bi)) { bv = val; bi = v; }
+      }
+    }
+  };
+  rescan();
+  for (int k = 0; k < K; ++k) {
+    float cv = bv;
+    int ci = bi;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float v2 = __shfl_xor(cv, o, 64);
+      const int i2 = __shfl_xor(ci, o, 64);
+      if (cand_better(v2, i2, cv, ci)) { cv = v2; ci = i2; }
+    }
+    if (lane == 0) { wv[wave] = cv; wi[wave] = ci; }
+    __syncthreads();
+    cv = wv[0]; ci = wi[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w)
+      if (cand_better(wv[w], wi[w], cv, ci)) { cv = wv[w]; ci = wi[w]; }
+    if (bi == ci && ci != INT_MAX) {  // this thread owns the winner: take it, find its next best
+      tv = bv; ti = bi;
+      rescan();
+    }
+    if (tid == 0) { o_val[k] = cv; o_tok[k] = ci == INT_MAX ? p.pad : ci; }  // (a global store here would be waited for at every barrier)
+    __syncthreads();
+  }
+  if (tid < K) {
+    cand_val[(int64_t)h * K + tid] = o_val[tid];
+    cand_tok[(int64_t)h * K + tid] = o_tok[tid];
+  }
+}
+
+// generic-width variant: rows too long for registers are re-read from memory (L2-resident) on every scan
+template <typename T>
+__global__ __launch_bounds__(512) void beam_row_topk_wide_kernel(BeamP p, float* cand_val, int32_t* cand_tok) {
+  constexpr int NTH = 512, NW = NTH / 64;
+  const int s = *p.step;
+  if (s > p.max_len) return;
+  const int h = blockIdx.x, r = h % p.beam;
+  if (s == 0 && r != 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int V = p.vocab, K = 2 * p.beam, L1 = p.max_len + 1;
+  const T* lg = reinterpret_cast<const T*>(p.logits) + (int64_t)h * p.ld_logits;
+  const float NEG = -INFINITY;
+  __shared__ float red_m[NW], red_s[NW], wv[NW];
+  __shared__ int wi[NW];
+  __shared__ float sh_lse;
+  __shared__ float o_val[KMAX_ALL];
+  __shared__ int o_tok[KMAX_ALL];
+  float mx = NEG, sum = 0.0f;
+  for (int v = tid; v < V; v += NTH) {
+    const float xv = DT<T>::ld(lg + v) * p.inv_temperature;
+    if (xv > mx) { sum = (mx == NEG ? 0.0f : sum * expf(mx - xv)) + 1.0f; mx = xv; }
+    else sum += expf(xv - mx);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m2 = __shfl_xor(mx, o, 64), s2 = __shfl_xor(sum, o, 64);
+    const float M = fmaxf(mx, m2);
+    sum = (mx == NEG ? 0.0f : sum * expf(mx - M)) + (m2 == NEG ? 0.0f : s2 * expf(m2 - M));
+    mx = M;
+  }
+  if (lane == 0) { red_m[wave] = mx; red_s[wave] = sum; }
+  __syncthreads();
+  if (tid == 0) {
+    float mm = NEG, ss = 0.0f;
+    for (int w = 0; w < NW; ++w) {
+      const float m2 = red_m[w], s2 = red_s[w];
+      const float M = fmaxf(mm, m2);
+      ss = (mm == NEG ? 0.0f : ss * expf(mm - M)) + (m2 == NEG ? 0.0f : s2 * expf(m2 - M));
+      mm = M;
+    }
+    sh_lse = mm + logf(ss);
+  }
+  __syncthreads();
+  const float lse = sh_lse;
+  const float prev = s > 0 ? (p.scores + (int64_t)(s & 1) * p.bsz * p.beam * L1)[(int64_t)h * L1 + s - 1] : 0.0f;
+  float tv = INFINITY, bv;
+  int ti = -1, bi;
+  auto rescan = [&]() {
+    bv = NEG; bi = INT_MAX;
+    for (int v = tid; v < V; v += NTH) {
+      float val = DT<T>::ld(lg + v) * p.inv_temperature - lse;
+      if (val != val) val = NEG;
+      if (v == p.pad) val = NEG;
+      if (v == p.unk) val -= p.unk_penalty;
+      if (s >= p.max_len && v != p.eos) val = NEG;
+      if (s < p.min_len && v == p.eos) val = NEG;
+      if (s > 0) val += prev;
+      const bool open = val < tv || (val == tv && v > ti);
+      if (open && cand_better(val, v, bv, bi)) { bv = val; bi = v; }
+    }
+  };
+  rescan();
+  for (int k = 0; k < K; ++k) {
+    float cv = bv;
+    int ci = bi;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float v2 = __shfl_xor(cv, o, 64);
+      const int i2 = __shfl_xor(ci, o, 64);
+      if (cand_better(v2, i2, cv, ci)) { cv = v2; ci = i2; }
+    }
+    if (lane == 0) { wv[wave] = cv; wi[wave] = ci; }
+    __syncthreads();
+    cv = wv[0]; ci = wi[0];
+    for (int w = 1; w < NW; ++w)
+      if (cand_better(wv[w], wi[w], cv, ci)) { cv = wv[w]; ci = wi[w]; }
+    if (bi == ci && ci != INT_MAX) { tv = bv; ti = bi; rescan(); }
+    if (tid == 0) { o_val[k] = cv; o_tok[k] = ci == INT_MAX ? p.pad : ci; }
+    __syncthreads();
+  }
+  if (tid < K) {
+    cand_val[(int64_t)h * K + tid] = o_val[tid];
+    cand_tok[(int64_t)h * K + tid] = o_tok[tid];
+  }
+}
+
+// ---- beam search step, kernel 2 of 2: one workgroup per SENTENCE -------------------------------------------------------------
+// merges the rows' sorted candidate lists into the sentence's top-(2*beam) over beam*V (search.py:127-135: flat index =
+// beam*V + token, ties to the smaller flat index), then (d) the eos / finalize / active-hypothesis bookkeeping of
+// sequence_generator.py:340-499 and finalize_hypos :575-696, (e) the token / score / ancestry rows of the next step written
+// into the other half of the ping-pong buffers; the last workgroup to finish advances the step counter.
+__global__ __launch_bounds__(256) void beam_merge_kernel(BeamP p, const float* cand_val, const int32_t* cand_tok, int32_t* ticket) {
+  const int s = *p.step;
+  const int sent = blockIdx.x, tid = threadIdx.x;
+  const int beam = p.beam, K = 2 * beam, bbsz = p.bsz * beam;
   const int L1 = p.max_len + 1, LT = p.max_len + 2;
   const int rows = s == 0 ? 1 : beam;
   const int cur = s & 1, nxt = cur ^ 1;
@@ -78,184 +296,112 @@ __global__ __launch_bounds__(1024) void beam_step_kernel(BeamP p) {
   float* sc_new = p.scores + (int64_t)nxt * bbsz * L1;
   const int32_t* anc_old = p.anc + (int64_t)cur * bbsz * L1;
   int32_t* anc_new = p.anc + (int64_t)nxt * bbsz * L1;
-  const T* logits = reinterpret_cast<const T*>(p.logits) + (int64_t)sent * beam * p.ld_logits;
   const float NEG = -INFINITY;
-
-  __shared__ float red_m[16][KB], red_s[16][KB];
-  __shared__ float row_lse[KB], row_prev[KB];
-  __shared__ float wv[16];
-  __shared__ int wi[16];
-  __shared__ float c_score[KMAX];
-  __shared__ int c_tok[KMAX], c_beam[KMAX], c_em[KMAX];
-  __shared__ int act[KB], rec_k[KB], rec_r[KB], n_rec;
-
-  // ---- (a) online max / sum-exp per row ----
-  float m[KB], sum[KB];
-#pragma unroll
-  for (int r = 0; r < KB; ++r) { m[r] = NEG; sum[r] = 0.0f; }
-  for (int v = tid; v < V; v += blockDim.x) {
-#pragma unroll
-    for (int r = 0; r < KB; ++r) {
-      if (r < rows) {
-        const float x = DT<T>::ld(logits + (int64_t)r * p.ld_logits + v) * p.inv_temperature;
-        if (x > m[r]) { sum[r] = sum[r] * expf(m[r] - x) + 1.0f; m[r] = x; }
-        else sum[r] += expf(x - m[r]);  // NaN logits propagate into the sum -> lse NaN -> row masked to -inf below
+  __shared__ float l_val[BEAM_MAX * KMAX_ALL];
+  __shared__ int l_tok[BEAM_MAX * KMAX_ALL];
+  __shared__ float c_score[KMAX_ALL];
+  __shared__ int c_tok[KMAX_ALL], c_beam[KMAX_ALL], c_em[KMAX_ALL];
+  __shared__ int act[BEAM_MAX], rec_k[BEAM_MAX], rec_r[BEAM_MAX], n_rec;
+  __shared__ int ign[BEAM_MAX], ign_new[BEAM_MAX];
+  if (s <= p.max_len) {
+    for (int i = tid; i < rows * K; i += blockDim.x) {
+      l_val[i] = cand_val[(int64_t)sent * beam * K + i];
+      l_tok[i] = cand_tok[(int64_t)sent * beam * K + i];
+    }
+    if (tid < beam) ign[tid] = p.cands_to_ignore[sent * beam + tid];
+    __syncthreads();
+    // rank of every row candidate among the sentence's rows*K candidates (ordered by value desc, then row asc = flat index asc,
+    // then position in the row's list): rank < K -> it is the sentence's candidate number `rank`.  One thread per candidate; a
+    // serial K-round head merge by one thread cost ~8 us of dependent LDS round trips.
+    for (int i = tid; i < rows * K; i += blockDim.x) {
+      const float v = l_val[i];
+      const int r = i / K;
+      int rank = 0;
+      for (int o = 0; o < rows * K; ++o) {
+        const float vo = l_val[o];
+        rank += (vo > v || (vo == v && o < i)) ? 1 : 0;   // lists are sorted within a row, so o < i orders equal values by (row, position)
+      }
+      if (rank < K) { c_score[rank] = v; c_tok[rank] = l_tok[i]; c_beam[rank] = r; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      // ---- (d) bookkeeping (LDS / registers only: a global access inside these serial loops costs a memory round trip each) ----
+      bool any_top_eos = false;
+      int nr = 0;
+      int nf = p.nfinal[sent];
+      const bool was_finished = p.finished[sent] != 0;
+      for (int k = 0; k < K; ++k) {
+        bool e = c_tok[k] == p.eos && c_score[k] != NEG;                       // :341
+        if (k < beam && ign[k]) e = false;                                     // :346
+        c_em[k] = e ? 1 : 0;
+        if (k < beam && e) {
+          any_top_eos = true;
+          if (!was_finished && nf < beam) { rec_k[nr] = k; rec_r[nr] = nf; ++nr; ++nf; }   // finalize_hypos :575-696
+        }
+      }
+      n_rec = nr;
+      p.nfinal[sent] = nf;
+      if (any_top_eos && !was_finished && (nf == beam || s == p.max_len)) {     // is_finished :698-713
+        p.finished[sent] = 1;
+        atomicSub(p.num_remaining, 1);
+      }
+      // active hypotheses: the first `beam` candidates that are not eos / ignored, in candidate order (:465-499)
+      int na = 0;
+      for (int k = 0; k < K && na < beam; ++k) {
+        const bool e = c_em[k] || (k < beam && ign[k]);
+        if (!e) act[na++] = k;
+      }
+      const int n_live = na;
+      for (int k = 0; k < K && na < beam; ++k) {
+        const bool e = c_em[k] || (k < beam && ign[k]);
+        if (e) act[na++] = k;
+      }
+      for (int i = 0; i < beam; ++i) ign_new[i] = i >= n_live ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid < beam) p.cands_to_ignore[sent * beam + tid] = (uint8_t)ign_new[tid];
+    // ---- finalized hypotheses (tokens[bi, 1:step+2] with eos at [step]; positional scores = differences) ----
+    for (int q = 0; q < n_rec; ++q) {
+      const int k = rec_k[q], r = rec_r[q];
+      const int64_t bi = sent * beam + c_beam[k], slot = (int64_t)sent * beam + r;
+      const float sc = c_score[k];
+      for (int j = tid; j <= s; j += blockDim.x) {
+        p.fin_tokens[slot * L1 + j] = j == s ? (int64_t)p.eos : tok_old[bi * LT + j + 1];
+        const float cum = j == s ? sc : sc_old[bi * L1 + j];
+        const float before = j > 0 ? sc_old[bi * L1 + j - 1] : 0.0f;
+        p.fin_pos[slot * L1 + j] = j > 0 ? cum - before : cum;
+      }
+      if (tid == 0) {
+        p.fin_len[slot] = s + 1;
+        p.fin_score[slot] = p.normalize_scores ? sc / (float)pow((double)(s + 1), (double)p.len_penalty) : sc;
       }
     }
-  }
-#pragma unroll
-  for (int r = 0; r < KB; ++r) {
-    if (r < rows) {
-      float mm = m[r], ss = sum[r];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const float m2 = __shfl_xor(mm, o, 64), s2 = __shfl_xor(ss, o, 64);
-        const float M = fmaxf(mm, m2);
-        ss = (mm == NEG ? 0.0f : ss * expf(mm - M)) + (m2 == NEG ? 0.0f : s2 * expf(m2 - M));
-        mm = M;
-      }
-      if (lane == 0) { red_m[wave][r] = mm; red_s[wave][r] = ss; }
-    }
-  }
-  __syncthreads();
-  if (tid < rows) {
-    float mm = NEG, ss = 0.0f;
-    for (int w = 0; w < NW; ++w) {
-      const float m2 = red_m[w][tid], s2 = red_s[w][tid];
-      const float M = fmaxf(mm, m2);
-      ss = (mm == NEG ? 0.0f : ss * expf(mm - M)) + (m2 == NEG ? 0.0f : s2 * expf(m2 - M));
-      mm = M;
-    }
-    row_lse[tid] = mm + logf(ss);
-    row_prev[tid] = s > 0 ? sc_old[(int64_t)(sent * beam + tid) * L1 + s - 1] : 0.0f;
-  }
-  __syncthreads();
-
-  // ---- (b)+(c) masked candidate values, per-thread sorted top-KMAX ----
-  float lv[KMAX];
-  int li[KMAX];
-#pragma unroll
-  for (int t = 0; t < KMAX; ++t) { lv[t] = NEG; li[t] = INT_MAX; }
-  for (int r = 0; r < rows; ++r) {
-    const float lse = row_lse[r], prev = row_prev[r];
-    const T* lg = logits + (int64_t)r * p.ld_logits;
-    for (int v = tid; v < V; v += blockDim.x) {
-      float val = DT<T>::ld(lg + v) * p.inv_temperature - lse;
-      if (val != val) val = NEG;                       // lprobs[lprobs != lprobs] = -inf        (:311)
-      if (v == p.pad) val = NEG;                       // never select pad                        (:313)
-      if (v == p.unk) val -= p.unk_penalty;            //                                         (:314)
-      if (s >= p.max_len && v != p.eos) val = NEG;     // force eos at max length                 (:317-319)
-      if (s < p.min_len && v == p.eos) val = NEG;      // minimum length constraint               (:329-331)
-      if (s > 0) val += prev;                          // search.py:125
-      const int idx = r * V + v;
-      if (cand_better(val, idx, lv[KMAX - 1], li[KMAX - 1])) {
-        lv[KMAX - 1] = val; li[KMAX - 1] = idx;
-#pragma unroll
-        for (int t = KMAX - 1; t > 0; --t) {
-          if (cand_better(lv[t], li[t], lv[t - 1], li[t - 1])) {
-            const float tv = lv[t]; lv[t] = lv[t - 1]; lv[t - 1] = tv;
-            const int ti = li[t]; li[t] = li[t - 1]; li[t - 1] = ti;
-          }
+    // ---- (e) rows of the next step ----
+    if (s < p.max_len) {
+      for (int i = 0; i < beam; ++i) {
+        const int k = act[i];
+        const int64_t src = sent * beam + c_beam[k], dst = (int64_t)sent * beam + i;
+        for (int j = tid; j <= s; j += blockDim.x) {
+          tok_new[dst * LT + j] = tok_old[src * LT + j];
+          anc_new[dst * L1 + j] = anc_old[src * L1 + j];
+          if (j < s) sc_new[dst * L1 + j] = sc_old[src * L1 + j];
+        }
+        if (tid == 0) {
+          tok_new[dst * LT + s + 1] = c_tok[k];
+          sc_new[dst * L1 + s] = c_score[k];
+          anc_new[dst * L1 + s + 1] = (int32_t)dst;
         }
       }
     }
   }
-  // ---- merge: K block-wide arg-max rounds over the list heads ----
-  for (int k = 0; k < K; ++k) {
-    float bv = lv[0];
-    int bi = li[0];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float v2 = __shfl_xor(bv, o, 64);
-      const int i2 = __shfl_xor(bi, o, 64);
-      if (cand_better(v2, i2, bv, bi)) { bv = v2; bi = i2; }
-    }
-    if (lane == 0) { wv[wave] = bv; wi[wave] = bi; }
-    __syncthreads();
-    bv = wv[0]; bi = wi[0];
-    for (int w = 1; w < NW; ++w)
-      if (cand_better(wv[w], wi[w], bv, bi)) { bv = wv[w]; bi = wi[w]; }
-    if (li[0] == bi && bi != INT_MAX) {  // this thread owns the winner: pop it
-#pragma unroll
-      for (int t = 0; t < KMAX - 1; ++t) { lv[t] = lv[t + 1]; li[t] = li[t + 1]; }
-      lv[KMAX - 1] = NEG; li[KMAX - 1] = INT_MAX;
-    }
-    if (tid == 0) {
-      c_score[k] = bv;
-      c_tok[k] = bi == INT_MAX ? p.pad : bi % V;
-      c_beam[k] = bi == INT_MAX ? 0 : bi / V;
-    }
-    __syncthreads();
-  }
-
-  // ---- (d) bookkeeping (one thread; K <= 40 entries) ----
-  if (tid == 0) {
-    uint8_t* ign = p.cands_to_ignore + sent * beam;
-    bool any_top_eos = false;
-    int nr = 0;
-    int nf = p.nfinal[sent];
-    const bool was_finished = p.finished[sent] != 0;
-    for (int k = 0; k < K; ++k) {
-      bool e = c_tok[k] == p.eos && c_score[k] != NEG;                       // :341
-      if (k < beam && ign[k]) e = false;                                     // :346
-      c_em[k] = e ? 1 : 0;
-      if (k < beam && e) {
-        any_top_eos = true;
-        if (!was_finished && nf < beam) { rec_k[nr] = k; rec_r[nr] = nf; ++nr; ++nf; }   // finalize_hypos :575-696
-      }
-    }
-    n_rec = nr;
-    p.nfinal[sent] = nf;
-    if (any_top_eos && !was_finished && (nf == beam || s == p.max_len)) {     // is_finished :698-713
-      p.finished[sent] = 1;
-      atomicSub(p.num_remaining, 1);
-    }
-    // active hypotheses: the first `beam` candidates that are not eos / ignored, in candidate order (:465-499)
-    int na = 0;
-    for (int k = 0; k < K && na < beam; ++k) {
-      const bool e = c_em[k] || (k < beam && ign[k]);
-      if (!e) act[na++] = k;
-    }
-    const int n_live = na;
-    for (int k = 0; k < K && na < beam; ++k) {
-      const bool e = c_em[k] || (k < beam && ign[k]);
-      if (e) act[na++] = k;
-    }
-    for (int i = 0; i < beam; ++i) ign[i] = i >= n_live ? 1 : 0;
-  }
+  // the last workgroup to get here advances the step (every workgroup has read *p.step by now)
   __syncthreads();
-
-  // ---- finalized hypotheses (tokens[bi, 1:step+2] with eos at [step]; positional scores = differences) ----
-  for (int q = 0; q < n_rec; ++q) {
-    const int k = rec_k[q], r = rec_r[q];
-    const int64_t bi = sent * beam + c_beam[k], slot = (int64_t)sent * beam + r;
-    const float sc = c_score[k];
-    for (int j = tid; j <= s; j += blockDim.x) {
-      p.fin_tokens[slot * L1 + j] = j == s ? (int64_t)p.eos : tok_old[bi * LT + j + 1];
-      const float cum = j == s ? sc : sc_old[bi * L1 + j];
-      const float before = j > 0 ? sc_old[bi * L1 + j - 1] : 0.0f;
-      p.fin_pos[slot * L1 + j] = j > 0 ? cum - before : cum;
-    }
-    if (tid == 0) {
-      p.fin_len[slot] = s + 1;
-      p.fin_score[slot] = p.normalize_scores ? sc / (float)pow((double)(s + 1), (double)p.len_penalty) : sc;
-    }
-  }
-  // ---- (e) rows of the next step ----
-  if (s < p.max_len) {
-    for (int i = 0; i < beam; ++i) {
-      const int k = act[i];
-      const int64_t src = sent * beam + c_beam[k], dst = (int64_t)sent * beam + i;
-      for (int j = tid; j <= s; j += blockDim.x) {
-        tok_new[dst * LT + j] = tok_old[src * LT + j];
-        anc_new[dst * L1 + j] = anc_old[src * L1 + j];
-        if (j < s) sc_new[dst * L1 + j] = sc_old[src * L1 + j];
-      }
-      if (tid == 0) {
-        tok_new[dst * LT + s + 1] = c_tok[k];
-        sc_new[dst * L1 + s] = c_score[k];
-        anc_new[dst * L1 + s + 1] = (int32_t)dst;
-      }
+  if (tid == 0) {
+    __threadfence();
+    if (atomicAdd(ticket, 1) == (int)gridDim.x - 1) {
+      *ticket = 0;
+      if (s <= p.max_len) *p.step = s + 1;
+      __threadfence();
     }
   }
 }
@@ -278,71 +424,259 @@ __global__ void dec_embed_kernel(const int64_t* tokens, const int32_t* stepp, co
   }
 }
 
-// Single-query self-attention over the append-only caches; one wave per (hypothesis, head).
+// 16-byte vector of T -> floats
+template <typename T>
+__device__ __forceinline__ void ld_vec(const T* p, float (&v)[DT<T>::VEC]) {
+  if constexpr (DT<T>::VEC == 8) { float v8[8]; load8(p, v8); for (int e = 0; e < 8; ++e) v[e] = v8[e]; }
+  else { const f32x4 a = *reinterpret_cast<const f32x4*>(p); for (int e = 0; e < 4; ++e) v[e] = a[e]; }
+}
+// packed 16-byte vector -> floats (keeps in-flight loads at 4 VGPRs each instead of 8 for bf16)
+template <typename T>
+__device__ __forceinline__ void cvt_vec(const u32x4& r, float (&v)[DT<T>::VEC]) {
+  if constexpr (DT<T>::VEC == 8) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(r[i] << 16); v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = __uint_as_float(r[i]);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void st_vec(T* p, const float (&v)[DT<T>::VEC]) {
+  if constexpr (DT<T>::VEC == 8) { float v8[8]; for (int e = 0; e < 8; ++e) v8[e] = v[e]; store8(p, v8); }
+  else { f32x4 a = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(p) = a; }
+}
+
+// Single-query self-attention over the append-only caches; one wave per (hypothesis, head), no LDS.
+// A key / value row of one head is D*sizeof(T) contiguous bytes: LPK = that / 16 lanes cover it with one 16-byte load each, so a
+// 64-lane load instruction fetches KPI = 64 / LPK whole rows (full 128-byte lines, not 64 scattered 16-byte pieces).  One pass
+// with an online softmax: the K and V loads of UNR * KPI positions are issued together (the loop is a chain of memory round
+// trips, so bytes in flight per wave is what sets its speed); scores = per-lane partial dots reduced over the LPK lanes of a key;
+// the output = per-slot partial sums reduced over the KPI slots at the end.
 template <typename T, int D>
 __global__ __launch_bounds__(256) void dec_self_attn_kernel(const T* qkv, T* kc, T* vc, const int32_t* anc2, const int32_t* stepp,
                                                             T* out, int rows, int H, int max_len, float scale) {
-  extern __shared__ float smem[];
+  constexpr int VEC = DT<T>::VEC;          // elements per 16-byte vector
+  constexpr int LPK = D / VEC;             // lanes per key row
+  constexpr int KPI = 64 / LPK;            // key rows per load instruction
+  constexpr int UNR = 8;
   const int s = *stepp;
   if (s > max_len) return;
   const int L1 = max_len + 1, C = H * D;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int item = blockIdx.x * (blockDim.x >> 6) + wave;
-  const bool valid = item < rows * H;
-  const int h = valid ? item / H : 0, head = valid ? item % H : 0;
-  float* pr = smem + wave * L1;
+  if (item >= rows * H) return;            // waves are independent: no block-level barrier below
+  const int h = item / H, head = item % H;
   const int32_t* anc = anc2 + ((int64_t)(s & 1) * rows + h) * L1;
-  const T* qp = qkv + (int64_t)h * 3 * C + head * D;
+  const int slot = lane / LPK, c0 = (lane % LPK) * VEC;
+  const T* qp = qkv + (int64_t)h * 3 * C + head * D + c0;
   const T* kn = qp + C;
   const T* vn = qp + 2 * C;
-  float q[D];
+  const int64_t hoff = (int64_t)head * D + c0;
+  float q[VEC];
+  ld_vec<T>(qp, q);
 #pragma unroll
-  for (int d = 0; d < D; d += 8) {
-    float t[8];
-    load8(qp + d, t);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) q[d + e] = t[e];
+  for (int e = 0; e < VEC; ++e) q[e] *= scale;
+  // caches are head-major [rows][H][L1][D]: the positions of one head are contiguous (128-byte rows back to back), so the KPI
+  // rows of a load instruction are one contiguous KPI*128-byte run wherever the ancestry does not switch rows
+  if (slot == 0) {  // append this step's key / value (slot 0's lanes hold one full row between them)
+    *reinterpret_cast<u32x4*>(kc + (((int64_t)h * H + head) * L1 + s) * D + c0) = *reinterpret_cast<const u32x4*>(kn);
+    *reinterpret_cast<u32x4*>(vc + (((int64_t)h * H + head) * L1 + s) * D + c0) = *reinterpret_cast<const u32x4*>(vn);
   }
-  if (valid && lane < D) {  // append this step's key / value (read back from the projection registers below, not from the cache)
-    kc[((int64_t)h * L1 + s) * C + head * D + lane] = kn[lane];
-    vc[((int64_t)h * L1 + s) * C + head * D + lane] = vn[lane];
-  }
-  float mx = -INFINITY;
-  if (valid) {
-    for (int j = lane; j <= s; j += 64) {
-      const T* kr = j == s ? kn : kc + ((int64_t)anc[j] * L1 + j) * C + head * D;
-      float acc = 0.0f;
+  float m = -INFINITY, l = 0.0f, acc[VEC];
 #pragma unroll
-      for (int d = 0; d < D; d += 8) {
-        float t[8];
-        load8(kr + d, t);
+  for (int e = 0; e < VEC; ++e) acc[e] = 0.0f;
+  for (int j0 = 0; j0 <= s; j0 += KPI * UNR) {
+    u32x4 tk[UNR], tv[UNR];
+    float part[UNR];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc = fmaf(q[d + e], t[e], acc);
+    for (int u = 0; u < UNR; ++u) {
+      const int j = j0 + u * KPI + slot;
+      if (j <= s) {  // position s comes from the projection buffer, not from the cache (written above by other lanes)
+        const int64_t off = j == s ? 0 : (((int64_t)anc[j] * H + head) * L1 + j) * D + c0;
+        tk[u] = *reinterpret_cast<const u32x4*>(j == s ? kn : kc + off);
+        tv[u] = *reinterpret_cast<const u32x4*>(j == s ? vn : vc + off);
       }
-      acc *= scale;
-      pr[j] = acc;
-      mx = fmaxf(mx, acc);
     }
+    float bm = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int j = j0 + u * KPI + slot;
+      float d = 0.0f;
+      if (j <= s) {
+        float kf[VEC];
+        cvt_vec<T>(tk[u], kf);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) d = fmaf(q[e], kf[e], d);
+      }
+#pragma unroll
+      for (int o = LPK >> 1; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+      part[u] = j <= s ? d : -INFINITY;
+      bm = fmaxf(bm, part[u]);
+    }
+    bm = wave_max(bm);
+    const float mn = fmaxf(m, bm);
+    const float corr = m == -INFINITY ? 0.0f : expf(m - mn);
+    l *= corr;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] *= corr;
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int j = j0 + u * KPI + slot;
+      if (j <= s) {
+        const float pe = expf(part[u] - mn);
+        l += pe;
+        float vf[VEC];
+        cvt_vec<T>(tv[u], vf);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = fmaf(pe, vf[e], acc[e]);
+      }
+    }
+    m = mn;
   }
-  mx = wave_max(mx);
-  float sum = 0.0f;
-  if (valid) {
-    for (int j = lane; j <= s; j += 64) {
-      const float e = expf(pr[j] - mx);
-      pr[j] = e;
-      sum += e;
-    }
+#pragma unroll
+  for (int o = LPK; o < 64; o <<= 1) {
+    l += __shfl_xor(l, o, 64);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
   }
-  sum = wave_sum(sum);
-  __syncthreads();
-  if (valid && lane < D) {
-    float acc = 0.0f;
-    for (int j = 0; j < s; ++j) {
-      const float pj = pr[j];
-      acc = fmaf(pj, DT<T>::ld(vc + ((int64_t)anc[j] * L1 + j) * C + head * D + lane), acc);
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] /= l;
+  if (slot == 0) st_vec<T>(out + (int64_t)h * C + hoff, acc);
+}
+
+// Cross attention of the decode step: one workgroup per (sentence, head).  The encoder keys / values of a sentence are shared
+// by its `beam` hypotheses (they are never replicated or reordered: the reference's reorder_encoder_out + static_kv caches hold
+// beam copies), so every K / V row is read once per step and used for BQ queries.  4 waves split the source positions; rows are
+// fetched as whole 128-byte lines (LPK lanes per row, as in the self-attention kernel).  Three passes over LDS-resident scores:
+// scores + per-query max, exp + per-query sum, P V.
+template <typename T, int D, int BQ>
+__global__ __launch_bounds__(256, 2) void dec_cross_attn_kernel(const T* q, const T* kx, const T* vx, const uint8_t* kpm, T* out,
+                                                             const int32_t* stepp, int max_len, int beam, int H, int S, float scale) {
+  constexpr int VEC = DT<T>::VEC, LPK = D / VEC, KPI = 64 / LPK, UNR = 4, NW = 4;
+  extern __shared__ float smem[];
+  if (*stepp > max_len) return;
+  float* pr = smem;                          // [BQ][S]
+  float* red = smem + (size_t)BQ * S;        // [NW][BQ] max, [NW][BQ] sum, then [NW][BQ][D] partial outputs
+  const int b = blockIdx.x / H, head = blockIdx.x % H, C = H * D;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int slot = lane / LPK, c0 = (lane % LPK) * VEC;
+  const T* kb = kx + ((int64_t)b * H + head) * S * D + c0;  // head-major [bsz][H][S][D]: a head's rows are one contiguous stream
+  const T* vb = vx + ((int64_t)b * H + head) * S * D + c0;
+  const uint8_t* mk = kpm ? kpm + (int64_t)b * S : nullptr;
+  for (int q0 = 0; q0 < beam; q0 += BQ) {
+    const int nq = beam - q0 < BQ ? beam - q0 : BQ;
+    float qv[BQ][VEC];
+#pragma unroll
+    for (int qi = 0; qi < BQ; ++qi) {
+      const int qq = qi < nq ? qi : 0;
+      ld_vec<T>(q + ((int64_t)(b * beam + q0 + qq)) * C + head * D + c0, qv[qi]);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) qv[qi][e] *= scale;
     }
-    acc = fmaf(pr[s], DT<T>::ld(vn + lane), acc);
-    DT<T>::st(out + (int64_t)h * C + head * D + lane, acc / sum);
+    // ---- scores ----
+    float mq[BQ];
+#pragma unroll
+    for (int qi = 0; qi < BQ; ++qi) mq[qi] = -INFINITY;
+    for (int j0 = wave * KPI * UNR; j0 < S; j0 += NW * KPI * UNR) {
+      u32x4 tk[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int j = j0 + u * KPI + slot;
+        if (j < S) tk[u] = *reinterpret_cast<const u32x4*>(kb + (int64_t)j * D);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int j = j0 + u * KPI + slot;
+        const bool ok = j < S && !(mk && mk[j < S ? j : 0]);
+        float kf[VEC];
+        cvt_vec<T>(tk[u], kf);
+#pragma unroll
+        for (int qi = 0; qi < BQ; ++qi) {
+          float d = 0.0f;
+          if (j < S) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) d = fmaf(qv[qi][e], kf[e], d);
+          }
+#pragma unroll
+          for (int o = LPK >> 1; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+          d = ok ? d : -INFINITY;
+          mq[qi] = fmaxf(mq[qi], d);
+          if (j < S && (lane % LPK) == 0) pr[qi * S + j] = d;
+        }
+      }
+    }
+#pragma unroll
+    for (int qi = 0; qi < BQ; ++qi) {
+      mq[qi] = wave_max(mq[qi]);
+      if (lane == 0) red[wave * BQ + qi] = mq[qi];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int qi = 0; qi < BQ; ++qi) mq[qi] = fmaxf(fmaxf(red[qi], red[BQ + qi]), fmaxf(red[2 * BQ + qi], red[3 * BQ + qi]));
+    // ---- exp + sums (each thread owns a strided set of positions for every query) ----
+    float lq[BQ];
+#pragma unroll
+    for (int qi = 0; qi < BQ; ++qi) {
+      float acc = 0.0f;
+      for (int j = tid; j < S; j += 256) {
+        const float e = expf(pr[qi * S + j] - mq[qi]);
+        pr[qi * S + j] = e;
+        acc += e;
+      }
+      lq[qi] = wave_sum(acc);
+      if (lane == 0) red[NW * BQ + wave * BQ + qi] = lq[qi];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int qi = 0; qi < BQ; ++qi) lq[qi] = red[NW * BQ + qi] + red[NW * BQ + BQ + qi] + red[NW * BQ + 2 * BQ + qi] + red[NW * BQ + 3 * BQ + qi];
+    // ---- P V ----
+    float acc[BQ][VEC];
+#pragma unroll
+    for (int qi = 0; qi < BQ; ++qi)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[qi][e] = 0.0f;
+    for (int j0 = wave * KPI * UNR; j0 < S; j0 += NW * KPI * UNR) {
+      u32x4 tv[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int j = j0 + u * KPI + slot;
+        if (j < S) tv[u] = *reinterpret_cast<const u32x4*>(vb + (int64_t)j * D);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int j = j0 + u * KPI + slot;
+        if (j < S) {
+          float vf[VEC];
+          cvt_vec<T>(tv[u], vf);
+#pragma unroll
+          for (int qi = 0; qi < BQ; ++qi) {
+            const float pj = pr[qi * S + j];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[qi][e] = fmaf(pj, vf[e], acc[qi][e]);
+          }
+        }
+      }
+    }
+    float* ro = red + 2 * NW * BQ;  // [NW][BQ][D]
+#pragma unroll
+    for (int qi = 0; qi < BQ; ++qi) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+#pragma unroll
+        for (int o = LPK; o < 64; o <<= 1) acc[qi][e] += __shfl_xor(acc[qi][e], o, 64);
+        if (slot == 0) ro[(wave * BQ + qi) * D + c0 + e] = acc[qi][e];
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < nq * D; i += 256) {
+      const int qi = i / D, dd = i % D;
+      const float v = ro[(0 * BQ + qi) * D + dd] + ro[(1 * BQ + qi) * D + dd] + ro[(2 * BQ + qi) * D + dd] + ro[(3 * BQ + qi) * D + dd];
+      float lsum = red[NW * BQ + qi] + red[NW * BQ + BQ + qi] + red[NW * BQ + 2 * BQ + qi] + red[NW * BQ + 3 * BQ + qi];
+      DT<T>::st(out + ((int64_t)(b * beam + q0 + qi)) * C + head * D + dd, v / lsum);
+    }
+    __syncthreads();  // pr / red are reused by the next query group
+    (void)lq;
   }
 }
 
@@ -376,8 +710,14 @@ int cst_beam_init(const cst_beam_desc* d, cst_stream stream) {
   const int rc = to_params(d, p);
   if (rc != CST_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(beam_init_kernel, dim3(p.bsz * p.beam), dim3(256), 0, s, p);
+  CST_REQUIRE(d->workspace != nullptr, "cst_beam_init: workspace of cst_beam_workspace() bytes required");
+  hipLaunchKernelGGL(beam_init_kernel, dim3(p.bsz * p.beam), dim3(256), 0, s, p, reinterpret_cast<int32_t*>(d->workspace));
   return cst_check_launch("cst_beam_init");
+}
+
+int64_t cst_beam_workspace(int64_t bsz, int64_t beam) {
+  // per row 2*beam (value, token) candidates + the step ticket
+  return bsz * beam * 2 * beam * (int64_t)(sizeof(float) + sizeof(int32_t)) + 64;
 }
 
 int cst_beam_step(const cst_beam_desc* d, cst_stream stream) {
@@ -385,16 +725,25 @@ int cst_beam_step(const cst_beam_desc* d, cst_stream stream) {
   const int rc = to_params(d, p);
   if (rc != CST_OK) return rc;
   CST_REQUIRE(d->logits != nullptr && d->ld_logits >= d->vocab, "cst_beam_step: null logits / ld_logits < vocab");
+  const int64_t vec = d->dtype == CST_BF16 ? 8 : 4;
+  CST_REQUIRE(d->ld_logits % vec == 0 && d->ld_logits >= cst_ceil_div(d->vocab, vec) * vec && ((uintptr_t)d->logits % 16) == 0,
+              "cst_beam_step: logits rows must be 16-byte aligned and padded to a multiple of %lld elements", (long long)vec);
+  CST_REQUIRE(d->workspace != nullptr && ((uintptr_t)d->workspace % 16) == 0, "cst_beam_step: workspace of cst_beam_workspace() bytes required");
   hipStream_t s = (hipStream_t)stream;
-  const int K = 2 * p.beam;
+  const int64_t rows = (int64_t)p.bsz * p.beam, K = 2 * p.beam;
+  int32_t* ticket = reinterpret_cast<int32_t*>(d->workspace);
+  float* cand_val = reinterpret_cast<float*>(reinterpret_cast<char*>(d->workspace) + 64);
+  int32_t* cand_tok = reinterpret_cast<int32_t*>(cand_val + rows * K);
   {
-    CstProfScope prof(CST_K_ELEMENTWISE, s, 0.0, (double)p.bsz * p.beam * p.vocab * cst_dtype_size(d->dtype) * 2.0);
-#define CST_BEAM(T, KM) hipLaunchKernelGGL((beam_step_kernel<T, KM>), dim3(p.bsz), dim3(1024), 0, s, p)
-#define CST_BEAM_K(T) do { if (K <= 2) CST_BEAM(T, 2); else if (K <= 10) CST_BEAM(T, 10); else if (K <= 20) CST_BEAM(T, 20); else CST_BEAM(T, 40); } while (0)
-    if (d->dtype == CST_BF16) CST_BEAM_K(bf16_t); else CST_BEAM_K(float);
-#undef CST_BEAM_K
-#undef CST_BEAM
-    hipLaunchKernelGGL(beam_advance_kernel, dim3(1), dim3(1), 0, s, p.step);
+    CstProfScope prof(CST_K_ELEMENTWISE, s, 0.0, (double)rows * p.vocab * cst_dtype_size(d->dtype));
+    const int64_t nvec = cst_ceil_div(d->vocab, vec), per_thread = cst_ceil_div(nvec, 512);
+#define CST_TOPK(T, NV) hipLaunchKernelGGL((beam_row_topk_kernel<T, NV>), dim3((unsigned)rows), dim3(512), 0, s, p, cand_val, cand_tok)
+#define CST_TOPK_T(T) do { if (per_thread <= 1) CST_TOPK(T, 1); else if (per_thread <= 3) CST_TOPK(T, 3); else if (per_thread <= 5) CST_TOPK(T, 5); \
+                            else hipLaunchKernelGGL((beam_row_topk_wide_kernel<T>), dim3((unsigned)rows), dim3(512), 0, s, p, cand_val, cand_tok); } while (0)
+    if (d->dtype == CST_BF16) CST_TOPK_T(bf16_t); else CST_TOPK_T(float);
+#undef CST_TOPK_T
+#undef CST_TOPK
+    hipLaunchKernelGGL(beam_merge_kernel, dim3(p.bsz), dim3(256), 0, s, p, (const float*)cand_val, (const int32_t*)cand_tok, ticket);
   }
   return cst_check_launch("cst_beam_step");
 }
@@ -425,7 +774,7 @@ int cst_dec_self_attn(const void* qkv, void* kcache, void* vcache, const int32_t
   hipStream_t s = (hipStream_t)stream;
   const int WPB = 4;
   const unsigned blocks = (unsigned)cst_ceil_div(rows * H, WPB);
-  const size_t lds = (size_t)WPB * (max_len + 1) * sizeof(float);
+  const size_t lds = 0;
   CstProfScope prof(CST_K_ATTN_FWD, s, 4.0 * rows * H * D * (max_len + 1) * 0.5, 0.0);
 #define CST_DSA(T, DD) hipLaunchKernelGGL((dec_self_attn_kernel<T, DD>), dim3(blocks), dim3(64 * WPB), lds, s, (const T*)qkv, (T*)kcache, (T*)vcache, \
                                           anc, step, (T*)out, (int)rows, (int)H, (int)max_len, scale)
@@ -433,6 +782,33 @@ int cst_dec_self_attn(const void* qkv, void* kcache, void* vcache, const int32_t
   else { if (D == 64) CST_DSA(float, 64); else CST_DSA(float, 32); }
 #undef CST_DSA
   return cst_check_launch("cst_dec_self_attn");
+}
+
+int cst_dec_cross_attn(const void* q, const void* kx, const void* vx, const uint8_t* key_padding_mask, void* out,
+                       const int32_t* step, int64_t max_len, int64_t bsz, int64_t beam, int64_t H, int64_t D, int64_t S, float scale,
+                       int dtype, cst_stream stream) {
+  CST_REQUIRE(q && kx && vx && out && step, "cst_dec_cross_attn: null operand");
+  CST_REQUIRE(dtype == CST_F32 || dtype == CST_BF16, "cst_dec_cross_attn: bad dtype %d", dtype);
+  CST_REQUIRE(D == 32 || D == 64, "cst_dec_cross_attn: head dim %lld not in {32,64}", (long long)D);
+  CST_REQUIRE(bsz > 0 && beam > 0 && H > 0 && S > 0, "cst_dec_cross_attn: bad shape");
+  const int BQ = beam == 1 ? 1 : (beam <= 5 ? 5 : 8);
+  const size_t lds = ((size_t)BQ * S + 2 * 4 * BQ + (size_t)4 * BQ * D) * sizeof(float);
+  CST_REQUIRE(lds <= 150 * 1024, "cst_dec_cross_attn: %lld source positions need %zu bytes of LDS (max 150 KiB); use cst_attn_fwd", (long long)S, lds);
+  hipStream_t s = (hipStream_t)stream;
+  CstProfScope prof(CST_K_ATTN_FWD, s, 4.0 * bsz * beam * H * D * S, 2.0 * bsz * S * H * D * cst_dtype_size(dtype));
+#define CST_DCA(T, DD, QQ)                                                                                                      \
+  do {                                                                                                                          \
+    static bool attr = false;                                                                                                   \
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_cross_attn_kernel<T, DD, QQ>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; } \
+    hipLaunchKernelGGL((dec_cross_attn_kernel<T, DD, QQ>), dim3((unsigned)(bsz * H)), dim3(256), lds, s, (const T*)q, (const T*)kx, (const T*)vx, \
+                       key_padding_mask, (T*)out, step, (int)max_len, (int)beam, (int)H, (int)S, scale);                       \
+  } while (0)
+#define CST_DCA_Q(T, DD) do { if (BQ == 1) CST_DCA(T, DD, 1); else if (BQ == 5) CST_DCA(T, DD, 5); else CST_DCA(T, DD, 8); } while (0)
+  if (dtype == CST_BF16) { if (D == 64) CST_DCA_Q(bf16_t, 64); else CST_DCA_Q(bf16_t, 32); }
+  else { if (D == 64) CST_DCA_Q(float, 64); else CST_DCA_Q(float, 32); }
+#undef CST_DCA_Q
+#undef CST_DCA
+  return cst_check_launch("cst_dec_cross_attn");
 }
 
 }  // extern "C"

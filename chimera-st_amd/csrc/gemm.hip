@@ -31,6 +31,11 @@ using CfgSmall = Cfg<128, 128, 2, 2>;   // 4 waves, 2 blocks/CU: small / skinny 
 // 16 waves (wave tile 64 x 64), 1 block/CU, 4 waves/SIMD: half the L2->LDS bytes per FLOP of CfgSmall.  Measured
 // alternatives on MI355X at M=48k, K/N in {768, 3072} (tools/bench_kernels.py): 8 waves x (128 x 64) 660-690 TF/s (VGPR-capped,
 // 2 waves/SIMD); 256 x 128 x 64 8 waves with a 3-stage DMA ring 590; 256 x 128 x 32 4 waves 2 blocks/CU 590-660; this one 670-760.
+// decode-time problems (M = batch x beam <= 256 rows, k-major operands): 64 x 64 tiles, 4 waves of one 32 x 32 MFMA tile each, on a
+// 4-stage DMA ring (3 K tiles = 48 KiB in flight per workgroup, 2 workgroups per CU).  The step of an incremental decoder is
+// bound by how many bytes each CU keeps in flight, not by MFMA: with 128 x 128 tiles a 160 x 1024 x 1024 projection is 16
+// workgroups behind a 2-stage ring (13 us + a 5 us split-K reduce, or 33 us unsplit); this configuration runs it as 48.
+using CfgSkinny = Cfg<64, 64, 2, 2>;
 using CfgLarge = Cfg<256, 256, 4, 4>;   // 8 waves (wave tile 128 x 64), 1 block/CU: half the L2->LDS bytes per FLOP
 
 template <typename T, bool A_KMAJOR, bool B_KMAJOR, bool SEG, typename C>
@@ -727,7 +732,11 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
   // (A k-major only: with an mn-major A the register-staged 16-wave kernel measured 20-30 % faster on the dW shapes; and not
   //  with an act'(aux_in) epilogue, whose 128 KiB-per-tile operand read is exposed at one workgroup per CU: 0.49 vs 0.42 ms)
   static const bool all_8p = getenv("CST_GEMM_8P_ALL") != nullptr;
-  if (d->dtype == CST_BF16 && !seg && !no_8p && (ak || all_8p || force_8p) && (!d->dact || all_8p || force_8p) && (large || force_8p) && cst_gemm8p_supported(p, ak, bk, nbatch))
+  static const bool no_skinny = getenv("CST_GEMM_NO_SKINNY") != nullptr;
+  if (!no_skinny && ak && bk && !seg && d->M <= 256 && nbatch == 1 && p.splits == 1) {
+    rc = d->dtype == CST_BF16 ? launch_glds<bf16_t, true, true, CfgSkinny, 4>(p, d->M, d->N, nbatch, s)
+                              : launch_glds<float, true, true, CfgSkinny, 4>(p, d->M, d->N, nbatch, s);
+  } else if (d->dtype == CST_BF16 && !seg && !no_8p && (ak || all_8p || force_8p) && (!d->dact || all_8p || force_8p) && (large || force_8p) && cst_gemm8p_supported(p, ak, bk, nbatch))
     rc = cst_gemm8p_launch(p, ak, bk, nbatch, s);
   else if (d->dtype == CST_BF16) rc = CST_GEMM_DISPATCH(bf16_t);
   else rc = CST_GEMM_DISPATCH(float);

@@ -27,7 +27,7 @@ from . import lib as L
 
 class BeamDecodeEngine:
     def __init__(self, decoder, tgt_dict, beam_size, max_len, min_len=1, normalize_scores=True, len_penalty=1.0,
-                 unk_penalty=0.0, temperature=1.0, use_graph=True, poll=8):
+                 unk_penalty=0.0, temperature=1.0, use_graph=True, poll=8, cross_kernel="flash"):
         self.dec = decoder
         self.pad, self.unk, self.eos = tgt_dict.pad(), tgt_dict.unk(), tgt_dict.eos()
         self.vocab = len(tgt_dict)
@@ -35,6 +35,11 @@ class BeamDecodeEngine:
         self.normalize_scores, self.len_penalty = bool(normalize_scores), float(len_penalty)
         self.unk_penalty, self.temperature = float(unk_penalty), float(temperature)
         self.use_graph, self.poll = use_graph, max(1, int(poll))
+        # cross attention per step: "flash" = cst_attn_fwd with batch = sentence and the beam rows as the query axis (37 us per
+        # layer at 32 x beam 5 x 750 source positions, bf16); "shared" = cst_dec_cross_attn (dedicated kernel, head-major K/V;
+        # measured 51 us on the same shape: three dependent passes per wave — kept selectable, covered by the same tests)
+        assert cross_kernel in ("flash", "shared")
+        self.cross_kernel = cross_kernel
         self._packed = None
         self._state = {}
 
@@ -97,7 +102,7 @@ class BeamDecodeEngine:
             mean=z(bbsz, dt=torch.float32), rstd=z(bbsz, dt=torch.float32), lse=z(bsz * 64 * beam, dt=torch.float32),
             kc=[z(bbsz, L1, C) for _ in range(nl)], vc=[z(bbsz, L1, C) for _ in range(nl)],
             kx=[z(bsz, S, C) for _ in range(nl)], vx=[z(bsz, S, C) for _ in range(nl)],
-            kpm=z(bsz, S, dt=torch.uint8) if has_mask else None, graph=None)
+            proj=z(bsz * S, C), kpm=z(bsz, S, dt=torch.uint8) if has_mask else None, graph=None)
         d = L.BeamDesc()
         d.dtype = L.dtype_code(dtype)
         d.bsz, d.beam, d.vocab, d.max_len = bsz, beam, self.vocab, self.max_len
@@ -109,6 +114,8 @@ class BeamDecodeEngine:
         d.cands_to_ignore, d.finished, d.nfinal = st["ignore"].data_ptr(), st["finished"].data_ptr(), st["nfinal"].data_ptr()
         d.num_remaining = st["num_remaining"].data_ptr()
         d.fin_tokens, d.fin_pos, d.fin_score, d.fin_len = (st[k].data_ptr() for k in ("fin_tokens", "fin_pos", "fin_score", "fin_len"))
+        st["beam_ws"] = torch.zeros(L.load().cst_beam_workspace(bsz, beam), dtype=torch.uint8, device=device)
+        d.workspace = st["beam_ws"].data_ptr()
         st["desc"] = d
         self._state[key] = st
         return st
@@ -118,7 +125,13 @@ class BeamDecodeEngine:
         M, Kd = x.shape
         N = w.shape[0]
         K.gemm(x, w, out, M, N, Kd, a_kmajor=1, b_kmajor=1, lda=Kd, ldb=Kd, ldc=out.stride(0), bias=b, act=act,
-               resid=resid, ld_resid=0 if resid is None else resid.stride(0), split_k=-1)
+               resid=resid, ld_resid=0 if resid is None else resid.stride(0), split_k=1)
+
+    def _cross_fits(self, S, D):
+        if self.cross_kernel != "shared":
+            return False
+        bq = 1 if self.beam == 1 else (5 if self.beam <= 5 else 8)
+        return (bq * S + 8 * bq + 4 * bq * D) * 4 <= 150 * 1024
 
     def _ln(self, x, ln, out, st):
         lib = L.load()
@@ -148,10 +161,16 @@ class BeamDecodeEngine:
             x, x2 = x2, x
             self._ln(x, layer.encoder_attn_layer_norm, st["h"], st)
             self._linear(st["h"], ca.q_proj.weight, ca.q_proj.bias, st["q"])
-            # cross attention: batch = sentence, query "time" axis = the beam rows of that sentence
-            q3, o3 = st["q"].view(bsz, self.beam, C), st["attn"].view(bsz, self.beam, C)
-            d = K.attn_desc(q3, st["kx"][li], st["vx"][li], o3, st["lse"], H, D, st["kpm"], False, float(ca.scaling))
-            K.attn_fwd_desc(d)
+            # cross attention: one workgroup per (sentence, head); the sentence's K/V rows serve all of its beam rows
+            S = st["kx"][li].shape[1]
+            if self._cross_fits(S, D):
+                L.check(lib.cst_dec_cross_attn(L.ptr(st["q"]), L.ptr(st["kx"][li]), L.ptr(st["vx"][li]), L.ptr(st["kpm"]), L.ptr(st["attn"]),
+                                               L.ptr(st["step"]), self.max_len, bsz, self.beam, H, D, S, float(ca.scaling), dt,
+                                               L.stream_ptr()), "cst_dec_cross_attn")
+            else:  # very long sources: the flash kernel with batch = sentence, query "time" axis = the beam rows
+                q3, o3 = st["q"].view(bsz, self.beam, C), st["attn"].view(bsz, self.beam, C)
+                d = K.attn_desc(q3, st["kx"][li], st["vx"][li], o3, st["lse"], H, D, st["kpm"], False, float(ca.scaling))
+                K.attn_fwd_desc(d)
             self._linear(st["attn"], ca.out_proj.weight, ca.out_proj.bias, x2, resid=x)
             x, x2 = x2, x
             self._ln(x, layer.final_layer_norm, st["h"], st)
@@ -165,7 +184,7 @@ class BeamDecodeEngine:
         else:
             feat = x
         w = dec.output_projection.weight
-        K.gemm(feat, w, st["logits"], bbsz, w.shape[0], C, a_kmajor=1, b_kmajor=1, lda=C, ldb=C, ldc=st["logits"].stride(0), split_k=-1)
+        K.gemm(feat, w, st["logits"], bbsz, w.shape[0], C, a_kmajor=1, b_kmajor=1, lda=C, ldb=C, ldc=st["logits"].stride(0), split_k=1)
         L.check(lib.cst_beam_step(ctypes.byref(st["desc"]), L.stream_ptr()), "cst_beam_step")
         # an even number of x/x2 swaps per layer (3) x layers may leave the residual stream in x2: the NEXT step's embed always
         # writes st["x"], and every step performs the same swaps, so the captured sequence is step-invariant.
@@ -188,8 +207,14 @@ class BeamDecodeEngine:
         flat = encb.reshape(bsz * S, Ce)
         for li, layer in enumerate(self.dec.layers):  # static cross-attention K/V, once per sentence (not per beam)
             ca = layer.encoder_attn
-            self._linear(flat, ca.k_proj.weight, ca.k_proj.bias, st["kx"][li].view(bsz * S, -1))
-            self._linear(flat, ca.v_proj.weight, ca.v_proj.bias, st["vx"][li].view(bsz * S, -1))
+            if self._cross_fits(S, ca.head_dim):  # head-major [bsz, H, S, D] for cst_dec_cross_attn (one transposing copy per call)
+                for name, proj in (("kx", ca.k_proj), ("vx", ca.v_proj)):
+                    self._linear(flat, proj.weight, proj.bias, st["proj"])
+                    st[name][li].view(bsz, ca.num_heads, S, ca.head_dim).copy_(
+                        st["proj"].view(bsz, S, ca.num_heads, ca.head_dim).transpose(1, 2))
+            else:
+                self._linear(flat, ca.k_proj.weight, ca.k_proj.bias, st["kx"][li].view(bsz * S, -1))
+                self._linear(flat, ca.v_proj.weight, ca.v_proj.bias, st["vx"][li].view(bsz * S, -1))
         if has_mask:
             st["kpm"].copy_(mask.to(torch.uint8))
         lib = L.load()

@@ -73,6 +73,7 @@ class BeamDesc(ctypes.Structure):
         ("tokens", c_p), ("scores", c_p), ("anc", c_p),
         ("cands_to_ignore", c_p), ("finished", c_p), ("nfinal", c_p), ("num_remaining", c_p),
         ("fin_tokens", c_p), ("fin_pos", c_p), ("fin_score", c_p), ("fin_len", c_p),
+        ("workspace", c_p),
     ]
 
 
@@ -108,10 +109,12 @@ SYMBOLS = [
     ("cst_sumsq_workspace", c_i64, []),
     ("cst_sumsq", c_int, [c_p, c_i64, c_p, c_p, c_int, c_p]),
     ("cst_adam_step", c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_p, c_int, c_int, c_p]),
+    ("cst_beam_workspace", c_i64, [c_i64, c_i64]),
     ("cst_beam_init", c_int, [ctypes.POINTER(BeamDesc), c_p]),
     ("cst_beam_step", c_int, [ctypes.POINTER(BeamDesc), c_p]),
     ("cst_dec_embed", c_int, [c_p, c_p, c_p, c_p, c_f, c_i64, c_p, c_i64, c_i64, c_i64, c_i64, c_int, c_p]),
     ("cst_dec_self_attn", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_f, c_int, c_p]),
+    ("cst_dec_cross_attn", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f, c_int, c_p]),
 ]
 
 _lib = None

@@ -35,7 +35,7 @@ class BeamSearch:
 class SequenceGenerator:
     def __init__(self, models, tgt_dict, beam_size=1, max_len_a=0, max_len_b=200, min_len=1, normalize_scores=True,
                  len_penalty=1.0, unk_penalty=0.0, temperature=1.0, match_source_len=False, no_repeat_ngram_size=0,
-                 search_strategy=None, eos=None, fused=True, use_graph=True):
+                 search_strategy=None, eos=None, fused=True, use_graph=True, cross_kernel="flash"):
         self.model = models[0] if isinstance(models, (list, tuple)) else models
         self.tgt_dict = tgt_dict
         self.pad, self.unk = tgt_dict.pad(), tgt_dict.unk()
@@ -52,7 +52,7 @@ class SequenceGenerator:
         # readable restatement and as the cross-check of the engine.  A custom search strategy needs the host loop.
         self.fused = bool(fused) and search_strategy is None and (eos is None or eos == tgt_dict.eos())
         self._engine = None
-        self.use_graph = use_graph
+        self.use_graph, self.cross_kernel = use_graph, cross_kernel
         self.model.eval()
 
     @torch.no_grad()
@@ -83,7 +83,7 @@ class SequenceGenerator:
                 if self._engine is None or self._engine.max_len != max_len:
                     self._engine = BeamDecodeEngine(self.model.decoder, self.tgt_dict, beam_size, max_len, self.min_len,
                                                     self.normalize_scores, self.len_penalty, self.unk_penalty, self.temperature,
-                                                    use_graph=self.use_graph)
+                                                    use_graph=self.use_graph, cross_kernel=self.cross_kernel)
                 return self._engine.generate(encoder_out, bsz)
         new_order = torch.arange(bsz, device=device).view(-1, 1).repeat(1, beam_size).view(-1)
         encoder_out = self.model.encoder.reorder_encoder_out(encoder_out, new_order)

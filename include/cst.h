@@ -267,6 +267,7 @@ int cst_adam_step(float* master, float* exp_avg, float* exp_avg_sq, const void* 
  *   scores), fin_score f32[bsz][beam] (length-normalised when normalize_scores), fin_len int32[bsz][beam].
  * cst_beam_step: fp32 log-softmax of logits [bbsz, vocab] (/temperature), NaN/pad/unk/min-len/max-len masks, + cumulative
  *   score, top-(2*beam) per sentence, eos finalisation, next active hypotheses, then *step += 1.  beam <= 20.
+ *   logits: 16-byte aligned, ld_logits a multiple of 16 bytes and >= vocab rounded up to it (rows are read as vectors).
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
   int dtype;                         /* storage type of logits */
@@ -279,7 +280,9 @@ typedef struct {
   int64_t* tokens; float* scores; int32_t* anc;
   uint8_t* cands_to_ignore; uint8_t* finished; int32_t* nfinal; int32_t* num_remaining;
   int64_t* fin_tokens; float* fin_pos; float* fin_score; int32_t* fin_len;
+  void* workspace;                   /* cst_beam_workspace(bsz, beam) bytes, 16-byte aligned: per-row candidates + step ticket */
 } cst_beam_desc;
+int64_t cst_beam_workspace(int64_t bsz, int64_t beam);
 int cst_beam_init(const cst_beam_desc* d, cst_stream stream);
 int cst_beam_step(const cst_beam_desc* d, cst_stream stream);
 /* out[h] = scale * embed[tokens[s&1][h][s]] + pos_table[pad_idx + 1 + s], s = *step (models/transformer.py:744-760,
@@ -292,6 +295,12 @@ int cst_dec_embed(const int64_t* tokens, const int32_t* step, const void* embed,
  * `scale` multiplies QK^T in fp32.  D in {32, 64}. */
 int cst_dec_self_attn(const void* qkv, void* kcache, void* vcache, const int32_t* anc, const int32_t* step, void* out,
                       int64_t rows, int64_t H, int64_t D, int64_t max_len, float scale, int dtype, cst_stream stream);
+/* Cross attention of one decode step (modules/multihead_attention.py:189-293 with static_kv): q, out [bsz*beam, H*D];
+ * kx, vx HEAD-MAJOR [bsz, H, S, D] — the encoder keys / values of a SENTENCE, shared by its beam hypotheses (not replicated);
+ * key_padding_mask uint8 [bsz, S] or NULL.  No-op when *step > max_len.  beam * S * 4 bytes of LDS: S <= ~7000 at beam 5. */
+int cst_dec_cross_attn(const void* q, const void* kx, const void* vx, const uint8_t* key_padding_mask, void* out,
+                       const int32_t* step, int64_t max_len, int64_t bsz, int64_t beam, int64_t H, int64_t D, int64_t S, float scale,
+                       int dtype, cst_stream stream);
 
 #ifdef __cplusplus
 }

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--mirror", action="store_true", help="also time the host-driven loop (fused=False)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--cross-kernel", default="flash", choices=["flash", "shared"])
     ap.add_argument("--profile", action="store_true", help="per-class GPU time of one eager decode loop (hipEvent pairs)")
     args = ap.parse_args()
 
@@ -75,7 +76,8 @@ def main():
         torch.cuda.synchronize()
         enc_s = (time.perf_counter() - t0) / args.reps
 
-    fused = SG([model], task.target_dictionary, beam_size=args.beam, max_len_a=0, max_len_b=args.max_len, use_graph=not args.no_graph)
+    fused = SG([model], task.target_dictionary, beam_size=args.beam, max_len_a=0, max_len_b=args.max_len, use_graph=not args.no_graph,
+               cross_kernel=args.cross_kernel)
     t_f, ntok = timed(fused)
     steps = args.max_len + 1
     out = {"metric": "decode utterances/sec, s2t_transformer_l beam 5, 1 MI355X", "config": {"arch": args.arch, "batch": args.batch,
