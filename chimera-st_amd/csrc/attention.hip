@@ -37,6 +37,7 @@ struct AttnParams {
   int64_t dq_sb, dq_sh, dq_st, dk_sb, dk_sh, dk_st, dv_sb, dv_sh, dv_st;
   float* delta;
   uint32_t drop_thr, drop_key; float drop_scale;  // attention-probability dropout (drop_thr == 0: none)
+  const int32_t* kv_len;  // optional [B]: keys >= kv_len[b] are all padding -> their tiles are skipped (they contribute exact zeros)
 };
 
 // the row (within a 32-row MFMA tile) that k-slot j of half-wave `hi` holds for the 16-row step t
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_fwd_ke
   float m_run = -1.0e30f, l_run = 0.0f;
 
   int64_t kend = p.Tk;
+  if (p.kv_len && p.kv_len[b] < kend) kend = p.kv_len[b] > 0 ? p.kv_len[b] : 0;  // trailing padding: P = exp2(-inf) = 0, alpha = 1 — skipping is exact
   if (p.causal) {
     const int64_t last = (int64_t)q_blk0 + NW * QB - 1 + cshift + 1;
     if (last < kend) kend = last;
@@ -319,6 +321,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_bwd_dq
     for (int r = 0; r < 16; ++r) dq[dt][r] = 0.0f;
 
   int64_t kend = p.Tk;
+  if (p.kv_len && p.kv_len[b] < kend) kend = p.kv_len[b] > 0 ? p.kv_len[b] : 0;
   if (p.causal) {
     const int64_t last = (int64_t)q_blk0 + NW * QB + cshift;
     if (last < kend) kend = last;
@@ -434,6 +437,21 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnParams p) 
   const uint32_t dsh = (uint32_t)(key & 1) * 16;
   const uint32_t rowpair0 = (uint32_t)((b * p.H + h) * p.Tq) * hp + (uint32_t)(key >> 1) + (uint32_t)(4 * hi) * hp;
 
+  if (p.kv_len && k_blk0 >= p.kv_len[b]) {  // every key of this block is padding: dK = dV = 0 (workgroup-uniform exit)
+    if (key < p.Tk) {
+      T* gk = (T*)p.dK + b * p.dk_sb + h * p.dk_sh + (int64_t)key * p.dk_st;
+      T* gv = (T*)p.dV + b * p.dv_sb + h * p.dv_sh + (int64_t)key * p.dv_st;
+      f32x16 z;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+#pragma unroll
+      for (int dt = 0; dt < D / 32; ++dt) {
+        store_dcol<T>(gk, z, dt * 32, lane, 1.0f);
+        store_dcol<T>(gv, z, dt * 32, lane, 1.0f);
+      }
+    }
+    return;
+  }
   Frag<T> fk[D / 16], fv[D / 16];
   load_row_frags<T, D>(fk, Kg, p.k_st, key, (int)p.Tk, lane);
   load_row_frags<T, D>(fv, Vg, p.v_st, key, (int)p.Tk, lane);
@@ -596,6 +614,7 @@ int fill_params(const cst_attn_desc* d, AttnParams& p, bool bwd) {
   p.dk_sb = d->dk_sb; p.dk_sh = d->dk_sh; p.dk_st = d->dk_st;
   p.dv_sb = d->dv_sb; p.dv_sh = d->dv_sh; p.dv_st = d->dv_st;
   p.delta = d->delta;
+  p.kv_len = d->kv_len;
   if (bwd) {
     CST_REQUIRE(d->dO && d->dQ && d->dK && d->dV && d->delta, "cst_attn_bwd: null gradient tensor");
     CST_REQUIRE(d->do_sb % vec == 0 && d->do_sh % vec == 0 && d->do_st % vec == 0 && d->o_st % vec == 0 && d->o_sb % vec == 0 && d->o_sh % vec == 0,

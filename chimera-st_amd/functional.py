@@ -221,25 +221,46 @@ def layer_norm_residual(x, gamma, beta, eps=1e-5):
 # ------------------------------------------------------------------------------------------------
 # fused attention
 # ------------------------------------------------------------------------------------------------
+_MASK_CACHE = []  # [(source mask (kept alive), version, uint8 mask, kv_len)] — one padding mask serves every layer of a pass
+
+
+def _mask_and_len(key_padding_mask):
+    """(uint8 [B,Tk] mask, int32 [B] kv_len) of a key padding mask; kv_len[b] = 1 + index of the last real key, so that the
+    kernels skip the all-padding key tiles at the end of every utterance of a length-sorted batch (cst_attn_desc.kv_len)."""
+    if key_padding_mask is None:
+        return None, None
+    for src, ver, u8, kvl in _MASK_CACHE:
+        if src is key_padding_mask and ver == key_padding_mask._version:
+            return u8, kvl
+    u8 = key_padding_mask.to(torch.uint8).contiguous()
+    Tk = u8.shape[1]
+    pos = torch.arange(1, Tk + 1, device=u8.device, dtype=torch.int32)
+    kvl = (pos * (u8 == 0)).amax(dim=1).to(torch.int32).contiguous()
+    _MASK_CACHE.append((key_padding_mask, key_padding_mask._version, u8, kvl))
+    if len(_MASK_CACHE) > 8:
+        _MASK_CACHE.pop(0)
+    return u8, kvl
+
+
 class _AttnFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, kpm, H, causal, scale, layout_q, layout_kv, drop_p, drop_key):
+    def forward(ctx, q, k, v, kpm, kvl, H, causal, scale, layout_q, layout_kv, drop_p, drop_key):
         D = q.shape[-1] // H
-        o, lse = K.attn_fwd(q, k, v, H, D, kpm, causal, scale, layout_q, layout_kv, drop_p, drop_key)
-        ctx.save_for_backward(q, k, v, o, lse, kpm)
+        o, lse = K.attn_fwd(q, k, v, H, D, kpm, causal, scale, layout_q, layout_kv, drop_p, drop_key, kvl)
+        ctx.save_for_backward(q, k, v, o, lse, kpm, kvl)
         ctx.cfg = (H, D, causal, scale, layout_q, layout_kv, drop_p, drop_key)
         return o
 
     @staticmethod
     def backward(ctx, do):
-        q, k, v, o, lse, kpm = ctx.saved_tensors
+        q, k, v, o, lse, kpm, kvl = ctx.saved_tensors
         H, D, causal, scale, lq, lkv, drop_p, drop_key = ctx.cfg
         if do.stride() != o.stride():
             tmp = torch.empty_like(o)
             tmp.copy_(do)
             do = tmp
-        dq, dk, dv = K.attn_bwd(do, q, k, v, o, lse, H, D, kpm, causal, scale, lq, lkv, drop_p, drop_key)
-        return dq, dk, dv, None, None, None, None, None, None, None, None
+        dq, dk, dv = K.attn_bwd(do, q, k, v, o, lse, H, D, kpm, causal, scale, lq, lkv, drop_p, drop_key, kvl)
+        return dq, dk, dv, None, None, None, None, None, None, None, None, None
 
 
 def _drop_args(dropout_p):
@@ -255,10 +276,10 @@ def attention(q, k, v, num_heads, key_padding_mask=None, causal=False, scale=Non
     key_padding_mask: bool/uint8 [B,Tk], True = pad.  dropout_p > 0: attention-probability dropout inside the kernels."""
     if scale is None:
         scale = (q.shape[-1] // num_heads) ** -0.5
-    if key_padding_mask is not None:
-        key_padding_mask = key_padding_mask.to(torch.uint8).contiguous()
+    key_padding_mask, kv_len = _mask_and_len(key_padding_mask)
     assert q.stride(-1) == 1 and k.stride(-1) == 1 and v.stride(-1) == 1
-    return _AttnFn.apply(q, k, v, key_padding_mask, num_heads, bool(causal), float(scale), layout_q, layout_kv, *_drop_args(dropout_p))
+    return _AttnFn.apply(q, k, v, key_padding_mask, kv_len, num_heads, bool(causal), float(scale), layout_q, layout_kv,
+                         *_drop_args(dropout_p))
 
 
 class _AttnPackedFn(torch.autograd.Function):
@@ -266,22 +287,22 @@ class _AttnPackedFn(torch.autograd.Function):
     into ONE [B, T, 3C] buffer, so the projection's dX / dW are single GEMMs and x receives a single gradient."""
 
     @staticmethod
-    def forward(ctx, qkv, kpm, H, causal, scale, drop_p, drop_key):
+    def forward(ctx, qkv, kpm, kvl, H, causal, scale, drop_p, drop_key):
         C = qkv.shape[-1] // 3
         D = C // H
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
         B, T = qkv.shape[0], qkv.shape[1]
         o = torch.empty(B, T, C, dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
-        d = K.attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, "bt", "bt", drop_p, drop_key)
+        d = K.attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, "bt", "bt", drop_p, drop_key, kvl)
         K.attn_fwd_desc(d)
-        ctx.save_for_backward(qkv, o, lse, kpm)
+        ctx.save_for_backward(qkv, o, lse, kpm, kvl)
         ctx.cfg = (H, D, C, causal, scale, drop_p, drop_key)
         return o
 
     @staticmethod
     def backward(ctx, do):
-        qkv, o, lse, kpm = ctx.saved_tensors
+        qkv, o, lse, kpm, kvl = ctx.saved_tensors
         H, D, C, causal, scale, drop_p, drop_key = ctx.cfg
         if not do.is_contiguous():
             do = do.contiguous()
@@ -289,10 +310,10 @@ class _AttnPackedFn(torch.autograd.Function):
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
         dq, dk, dv = dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:]
         delta = torch.empty_like(lse)
-        d = K.attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, "bt", "bt", drop_p, drop_key)
+        d = K.attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, "bt", "bt", drop_p, drop_key, kvl)
         K.attn_bwd_fill(d, do, dq, dk, dv, delta, D, "bt", "bt")
         K.attn_bwd_desc(d)
-        return dqkv, None, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None, None
 
 
 def attention_packed(qkv, num_heads, key_padding_mask=None, causal=False, scale=None, dropout_p=0.0):
@@ -300,10 +321,9 @@ def attention_packed(qkv, num_heads, key_padding_mask=None, causal=False, scale=
     C = qkv.shape[-1] // 3
     if scale is None:
         scale = (C // num_heads) ** -0.5
-    if key_padding_mask is not None:
-        key_padding_mask = key_padding_mask.to(torch.uint8).contiguous()
+    key_padding_mask, kv_len = _mask_and_len(key_padding_mask)
     assert qkv.is_contiguous()
-    return _AttnPackedFn.apply(qkv, key_padding_mask, num_heads, bool(causal), float(scale), *_drop_args(dropout_p))
+    return _AttnPackedFn.apply(qkv, key_padding_mask, kv_len, num_heads, bool(causal), float(scale), *_drop_args(dropout_p))
 
 
 # ------------------------------------------------------------------------------------------------

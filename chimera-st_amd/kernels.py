@@ -108,7 +108,7 @@ def _bhtd_strides(t, layout):
     return t.stride(1), None, t.stride(0)  # [T, B, C]
 
 
-def attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, layout_q="bt", layout_kv="bt", drop_p=0.0, drop_key=0):
+def attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, layout_q="bt", layout_kv="bt", drop_p=0.0, drop_key=0, kv_len=None):
     """q,o: [B,Tq,H*D] (layout "bt") or [Tq,B,H*D] ("tb"); k,v likewise with Tk.  Head h at channel offset h*D."""
     d = L.AttnDesc()
     d.dtype = L.dtype_code(q.dtype)
@@ -135,17 +135,22 @@ def attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, layout_q="bt", layout_k
         d.key_padding_mask, d.kpm_stride = None, 0
     d.causal, d.scale = int(causal), scale
     d.drop_p, d.drop_key = float(drop_p), int(drop_key) & 0xFFFFFFFF
+    if kv_len is not None:
+        assert kpm is not None and kv_len.dtype == torch.int32 and kv_len.numel() == B and kv_len.is_contiguous()
+        d.kv_len = kv_len.data_ptr()
+    else:
+        d.kv_len = None
     return d
 
 
-def attn_fwd(q, k, v, H, D, kpm, causal, scale, layout_q="bt", layout_kv="bt", drop_p=0.0, drop_key=0):
+def attn_fwd(q, k, v, H, D, kpm, causal, scale, layout_q="bt", layout_kv="bt", drop_p=0.0, drop_key=0, kv_len=None):
     o = torch.empty_like(q)
     if layout_q == "bt":
         B, Tq = q.shape[0], q.shape[1]
     else:
         Tq, B = q.shape[0], q.shape[1]
     lse = torch.empty(B, H, Tq, dtype=torch.float32, device=q.device)
-    d = attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, layout_q, layout_kv, drop_p, drop_key)
+    d = attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, layout_q, layout_kv, drop_p, drop_key, kv_len)
     L.check(L.load().cst_attn_fwd(ctypes.byref(d), L.stream_ptr()), "cst_attn_fwd")
     return o, lse
 
@@ -171,10 +176,10 @@ def attn_bwd_fill(d, do, dq, dk, dv, delta, D, layout_q="bt", layout_kv="bt"):
     d.delta = delta.data_ptr()
 
 
-def attn_bwd(do, q, k, v, o, lse, H, D, kpm, causal, scale, layout_q="bt", layout_kv="bt", drop_p=0.0, drop_key=0):
+def attn_bwd(do, q, k, v, o, lse, H, D, kpm, causal, scale, layout_q="bt", layout_kv="bt", drop_p=0.0, drop_key=0, kv_len=None):
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     delta = torch.empty_like(lse)
-    d = attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, layout_q, layout_kv, drop_p, drop_key)
+    d = attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, layout_q, layout_kv, drop_p, drop_key, kv_len)
     attn_bwd_fill(d, do, dq, dk, dv, delta, D, layout_q, layout_kv)
     L.check(L.load().cst_attn_bwd(ctypes.byref(d), L.stream_ptr()), "cst_attn_bwd")
     return dq, dk, dv

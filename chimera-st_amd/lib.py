@@ -58,6 +58,7 @@ class AttnDesc(ctypes.Structure):
         ("dK", c_p), ("dk_sb", c_i64), ("dk_sh", c_i64), ("dk_st", c_i64),
         ("dV", c_p), ("dv_sb", c_i64), ("dv_sh", c_i64), ("dv_st", c_i64),
         ("delta", c_p),
+        ("kv_len", c_p),
     ]
 
 

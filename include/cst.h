@@ -156,6 +156,10 @@ typedef struct {
   void* dK; int64_t dk_sb, dk_sh, dk_st;
   void* dV; int64_t dv_sb, dv_sh, dv_st;
   float* delta;  /* fp32 [B,H,Tq] workspace: rowsum(dO * O) */
+  /* optional int32 [B] (NULL = none): the caller's promise that every key >= kv_len[b] is padding in key_padding_mask
+   * (trailing padding of a length-sorted batch).  Those key tiles are skipped in all three kernels — they contribute
+   * exact zeros, so results are bit-identical to the unskipped run; key_padding_mask still governs keys < kv_len[b]. */
+  const int32_t* kv_len;
 } cst_attn_desc;
 
 int cst_attn_fwd(const cst_attn_desc* d, cst_stream stream);

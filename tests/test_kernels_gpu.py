@@ -241,6 +241,34 @@ def test_attention_fwd_bwd(K, dt, B, H, D, Tq, Tk, causal, pad, layout):
     check(dv, vr.grad, dt, "attn dv")
 
 
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("Tq,Tk,drop", [(300, 300, 0.0), (130, 517, 0.0), (257, 257, 0.1)])
+def test_attention_kv_len_skip_is_bit_identical(K, dt, Tq, Tk, drop):
+    """cst_attn_desc.kv_len (skip the all-padding key tiles at the end of each utterance): outputs and all three gradients are
+    bit-identical to the run that walks every tile (the skipped tiles contribute exact zeros), incl. an all-padding row."""
+    k, L = K
+    B, H, D = 4, 2, 64
+    C = H * D
+    q, kk, v, do = (rnd(B, T, C, dt=dt, seed=50 + i) for i, T in enumerate((Tq, Tk, Tk, Tq)))
+    lens = torch.tensor([Tk, Tk // 2 + 3, 65, 1])
+    kpm = (torch.arange(Tk)[None] >= lens[:, None]).to(torch.uint8).cuda()
+    kpm[1, 5] = 1  # a masked key INSIDE the valid range stays governed by the mask
+    kvl = lens.to(torch.int32).cuda()
+    scale = D ** -0.5
+    outs = []
+    for kv in (None, kvl):
+        o, lse = k.attn_fwd(q, kk, v, H, D, kpm, False, scale, "bt", "bt", drop, 1234, kv_len=kv)
+        dq, dk, dv = k.attn_bwd(do, q, kk, v, o, lse, H, D, kpm, False, scale, "bt", "bt", drop, 1234, kv_len=kv)
+        outs.append((o, lse, dq, dk, dv))
+    for a, b, name in zip(outs[0], outs[1], ("o", "lse", "dq", "dk", "dv")):
+        assert torch.equal(a, b), name
+    assert float(outs[1][3][2, 65:].abs().max()) == 0.0 and float(outs[1][4][3, 1:].abs().max()) == 0.0
+    # the host helper derives kv_len from the mask
+    CF = __import__("importlib").import_module("chimera-st_amd.functional")
+    u8, got = CF._mask_and_len(kpm.bool())
+    assert got.tolist() == lens.tolist() and torch.equal(u8, kpm)
+
+
 # --------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("B,S,C", [(2, 4000, 32), (2, 16000, 512)])
