@@ -48,6 +48,21 @@ class Dictionary:
         toks = [self[int(i)] for i in tensor if int(i) not in (self.eos_index, self.pad_index)]
         return " ".join(toks)
 
+    def encode_line(self, line, add_if_not_exist=True, append_eos=True, reverse_order=False):
+        """data/dictionary.py:292-317 with tokenizer.tokenize_line (:12-15): whitespace split -> IntTensor of indices (+ eos)."""
+        import re
+
+        import torch
+        words = re.sub(r"\s+", " ", line).strip().split()
+        if reverse_order:
+            words = list(reversed(words))
+        ids = torch.IntTensor(len(words) + 1 if append_eos else len(words))
+        for i, w in enumerate(words):
+            ids[i] = self.add_symbol(w) if add_if_not_exist else self.index(w)
+        if append_eos:
+            ids[len(words)] = self.eos_index
+        return ids
+
     @classmethod
     def load(cls, f):
         d = cls()

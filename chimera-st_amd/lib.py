@@ -115,6 +115,9 @@ SYMBOLS = [
     ("cst_beam_step", c_int, [ctypes.POINTER(BeamDesc), c_p]),
     ("cst_dec_embed", c_int, [c_p, c_p, c_p, c_p, c_f, c_i64, c_p, c_i64, c_i64, c_i64, c_i64, c_int, c_p]),
     ("cst_dec_self_attn", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_f, c_int, c_p]),
+    ("cst_batch_by_size", c_i64, [c_p, c_i64, c_i64, c_i64, ctypes.c_int32, c_p]),
+    ("cst_wav_info", c_int, [ctypes.c_char_p, c_p, c_p, c_p, c_p]),
+    ("cst_wav_read_f32", c_i64, [ctypes.c_char_p, c_i64, c_i64, c_p, c_i64]),
     ("cst_dec_cross_attn", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f, c_int, c_p]),
 ]
 

@@ -78,6 +78,21 @@ class FairseqTask:
         with torch.no_grad():
             return generator.generate(models, sample, prefix_tokens=prefix_tokens)
 
+    # ---- datasets (data.py; tasks/fairseq_task.py:162-275) --------------------------------------------------------
+    def dataset(self, split):
+        if split not in getattr(self, "datasets", {}):
+            raise KeyError("Dataset not loaded: " + split)
+        return self.datasets[split]
+
+    def max_positions(self):
+        return getattr(self.args, "max_source_positions", 6000), getattr(self.args, "max_target_positions", 1024)
+
+    def get_batch_iterator(self, dataset, max_tokens=None, max_sentences=None, max_positions=None, ignore_invalid_inputs=False,
+                           required_batch_size_multiple=1, seed=1, num_shards=1, shard_id=0, num_workers=0, epoch=1, **unused):
+        from . import data as D
+        return D.get_batch_iterator(dataset, max_tokens, max_sentences, max_positions, ignore_invalid_inputs,
+                                    required_batch_size_multiple, seed, num_shards, shard_id, epoch)
+
     def build_generator(self, models, args, seq_gen_cls=None, extra_gen_cls_kwargs=None):
         """fairseq_task.py:309-412, beam-search branch."""
         from .sequence_generator import SequenceGenerator
@@ -105,13 +120,47 @@ class SpeechToTextTask(FairseqTask):
     @staticmethod
     def add_args(parser):
         parser.add_argument("--config-yaml", type=str, default="config.yaml")
+        parser.add_argument("--normalize", action="store_true")
         parser.add_argument("--max-source-positions", default=6000, type=int, metavar="N")
         parser.add_argument("--max-target-positions", default=1024, type=int, metavar="N")
         parser.add_argument("--synthetic-vocab-size", default=10000, type=int)
 
-    def __init__(self, args, tgt_dict=None):
+    TRIPLET = False
+
+    def __init__(self, args, tgt_dict=None, data_cfg=None):
         super().__init__(args)
+        self.data_cfg = data_cfg if data_cfg is not None else self._load_data_cfg(args)
+        if tgt_dict is None and self.data_cfg is not None and getattr(args, "data", None) and \
+                os.path.isfile(os.path.join(args.data, self.data_cfg.vocab_filename)):
+            tgt_dict = Dictionary.load(os.path.join(args.data, self.data_cfg.vocab_filename))  # speech_to_text.py:60-70
         self.tgt_dict = tgt_dict if tgt_dict is not None else _load_dict(args, 10000)
+        self.datasets = {}
+
+    @staticmethod
+    def _load_data_cfg(args):
+        data, name = getattr(args, "data", None), getattr(args, "config_yaml", "config.yaml")
+        if data and os.path.isfile(os.path.join(data, name)):
+            from . import data as D
+            return D.TripletDataConfig(os.path.join(data, name))
+        return None
+
+    def load_dataset(self, split, epoch=1, combine=False, **kwargs):
+        """tasks/speech_to_text.py:95-111 / tasks/triplet.py:112-132: <data>/<split>.tsv through the data config YAML."""
+        from . import data as D
+        assert self.data_cfg is not None, "load_dataset needs --data <manifest root> with the --config-yaml file in it"
+        self.datasets[split] = D.TripletDatasetCreator.from_tsv(
+            self.args.data, self.data_cfg, split, self.tgt_dict, self.source_dictionary if self.TRIPLET else None,
+            D.build_tokenizer(self.data_cfg.pre_tokenizer), D.build_bpe(self.data_cfg.bpe_tokenizer),
+            D.build_bpe(self.data_cfg.src_bpe_tokenizer) if self.TRIPLET else None, is_train_split=split.startswith("train"),
+            epoch=epoch, seed=getattr(self.args, "seed", 1), normalize=getattr(self.args, "normalize", False),
+            sample_rate=getattr(self.args, "sample_rate", 16000), triplet=self.TRIPLET)
+        return self.datasets[split]
+
+    def build_model(self, args):
+        if self.data_cfg is not None:  # speech_to_text.py:119-122
+            args.input_feat_per_channel = self.data_cfg.input_feat_per_channel
+            args.input_channels = self.data_cfg.input_channels
+        return super().build_model(args)
 
     @property
     def target_dictionary(self):
@@ -132,8 +181,13 @@ class TripletTask(SpeechToTextTask):
         parser.add_argument("--dump-feature-to-file", type=str, default=None)
         parser.add_argument("--sample-rate", type=int, default=16000)
 
-    def __init__(self, args, tgt_dict=None, src_dict=None):
-        super().__init__(args, tgt_dict)
+    TRIPLET = True
+
+    def __init__(self, args, tgt_dict=None, src_dict=None, data_cfg=None):
+        super().__init__(args, tgt_dict, data_cfg)
+        if src_dict is None and self.data_cfg is not None and getattr(args, "data", None) and \
+                os.path.isfile(os.path.join(args.data, self.data_cfg.src_vocab_filename)):
+            src_dict = Dictionary.load(os.path.join(args.data, self.data_cfg.src_vocab_filename))  # triplet.py:80-95
         self.src_dict = src_dict if src_dict is not None else self.tgt_dict
 
     @property

@@ -306,6 +306,21 @@ int cst_dec_cross_attn(const void* q, const void* kx, const void* vx, const uint
                        const int32_t* step, int64_t max_len, int64_t bsz, int64_t beam, int64_t H, int64_t D, int64_t S, float scale,
                        int dtype, cst_stream stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Host-side (CPU) natives of the input pipeline — no device work, no stream.
+ * cst_batch_by_size replaces the Cython batch_by_size_fast (fairseq/data/data_utils_fast.pyx:17-67): num_tokens[i] is
+ *   the size of the i-th sample IN BATCHING ORDER; batches are consecutive runs of that order; batch_sizes (capacity n)
+ *   receives their lengths; returns the number of batches, or a negative cst_status (a sample above max_tokens).
+ *   max_tokens / max_sentences <= 0 mean "no limit"; bsz_mult = required_batch_size_multiple.
+ * cst_wav_info / cst_wav_read_f32 replace soundfile.read(path, dtype="float32", start=, frames=) for 16-bit PCM WAV
+ *   (fairseq/data/audio/audio_utils.py:7-55): samples / 32768 as float32, interleaved if multi-channel; nframes < 0 =
+ *   to the end; returns frames read or a negative cst_status.  cst_wav_info returns CST_ERR_UNSUPPORTED for non-PCM16.
+ * ------------------------------------------------------------------------------------------ */
+int64_t cst_batch_by_size(const int64_t* num_tokens, int64_t n, int64_t max_tokens, int64_t max_sentences, int32_t bsz_mult,
+                          int64_t* batch_sizes);
+int cst_wav_info(const char* path, int32_t* sample_rate, int32_t* channels, int64_t* frames, int32_t* bits);
+int64_t cst_wav_read_f32(const char* path, int64_t start_frame, int64_t nframes, float* out, int64_t capacity_samples);
+
 #ifdef __cplusplus
 }
 #endif
