@@ -129,6 +129,45 @@ class FusedAdam:
         self.lr = inverse_sqrt_lr(self.num_updates, self.base_lr, self.warmup_updates, self.warmup_init_lr)
         return gnorm
 
+    # ---- the reference's on-disk optimizer state (torch.optim state dict of optim/adam.py, or FP16Optimizer's single flat fp32
+    #      parameter, optim/fp16_optimizer.py:33-60, :71-76) <-> the flat master / moment buffers ----
+    def fairseq_state_dict(self):
+        state = {}
+        for i, (p, o) in enumerate(zip(self.buf.params, self.buf.offsets)):
+            n = p.numel()
+            state[i] = {"step": self.num_updates, "exp_avg": self.exp_avg[o:o + n].view(p.shape).cpu().clone(),
+                        "exp_avg_sq": self.exp_avg_sq[o:o + n].view(p.shape).cpu().clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
+                 "params": list(range(len(self.buf.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_fairseq_state_dict(self, sd, num_updates=None):
+        """Moments from a reference checkpoint; the fp32 master is re-derived from the (just loaded) model parameters, as
+        FP16Optimizer does on construction.  `num_updates` (optimizer_history[-1]) drives the lr schedule."""
+        st = {int(k): v for k, v in sd["state"].items()}  # keys = parameter indices; parameters that never had a gradient have none
+        entries = [st[k] for k in sorted(st)]
+        params, offs = self.buf.params, self.buf.offsets
+        total = sum(p.numel() for p in params)
+        self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+        if len(st) == 1 and len(params) > 1 and entries[0]["exp_avg"].numel() == total:  # FP16Optimizer: one flat fp32 parameter
+            m, v, at = entries[0]["exp_avg"].reshape(-1).float(), entries[0]["exp_avg_sq"].reshape(-1).float(), 0
+            for p, o in zip(params, offs):
+                self.exp_avg[o:o + p.numel()].copy_(m[at:at + p.numel()])
+                self.exp_avg_sq[o:o + p.numel()].copy_(v[at:at + p.numel()])
+                at += p.numel()
+        else:
+            for i, e in st.items():
+                if not (0 <= i < len(params)) or e["exp_avg"].numel() != params[i].numel():
+                    raise ValueError("optimizer state entry %d does not match the model's parameter list (the index space of a "
+                                     "fairseq optimizer state is model.parameters() order)" % i)
+                n, o = params[i].numel(), offs[i]
+                self.exp_avg[o:o + n].copy_(e["exp_avg"].reshape(-1).float())
+                self.exp_avg_sq[o:o + n].copy_(e["exp_avg_sq"].reshape(-1).float())
+        step = int(entries[0]["step"]) if entries else 0
+        self.num_updates = int(num_updates) if num_updates is not None else step
+        self.master.copy_(self.buf.flat_param.float())
+        self.lr = inverse_sqrt_lr(self.num_updates, self.base_lr, self.warmup_updates, self.warmup_init_lr)
+
     def state_dict(self):
         return {"master": self.master, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
                 "num_updates": self.num_updates, "lr": self.lr}

@@ -88,3 +88,33 @@ class Trainer:
         out["gnorm"] = float(gnorm)
         out["lr"] = self.optimizer.get_lr()
         return out
+
+    # ---- checkpoints in the reference's format (fairseq/trainer.py:270-395; checkpoint_utils.py) -------------------------
+    def save_checkpoint(self, filename, extra_state=None):
+        from . import checkpoint_utils
+        if self.rank != 0:
+            return None
+        extra = {"train_iterator": {"epoch": 1, "iterations_in_epoch": 0}, "val_loss": None}
+        extra.update(extra_state or {})
+        return checkpoint_utils.save_state(filename, self.args, self._model.state_dict(), self.criterion, self.optimizer,
+                                           self.num_updates, extra_state=extra)
+
+    def load_checkpoint(self, filename, reset_optimizer=False):
+        """Model + optimizer moments + update counter (lr schedule, per-update seeds) from a checkpoint written by this build or
+        by the reference.  Returns extra_state (train_iterator position, val_loss) or None if the file does not exist."""
+        from . import checkpoint_utils
+        import os
+        if not os.path.exists(filename):
+            return None
+        state = checkpoint_utils.load_checkpoint_to_cpu(filename)
+        sd = state["model"]
+        self._model.upgrade_state_dict(sd)
+        self._model.load_state_dict(sd, strict=True)  # copies into the flat parameter buffer (parameters are views of it)
+        last = state["optimizer_history"][-1]
+        if not reset_optimizer and state.get("last_optimizer_state") is not None:
+            self.optimizer.load_fairseq_state_dict(state["last_optimizer_state"], num_updates=last["num_updates"])
+            self.num_updates = int(last["num_updates"])
+        else:
+            self.optimizer.load_fairseq_state_dict({"state": {}}, num_updates=0)
+            self.num_updates = 0
+        return state["extra_state"]

@@ -190,11 +190,13 @@ class Wav2Vec2Model(nn.Module):
         self.feature_grad_mult = args.feature_grad_mult
         self.dropout_input_p = getattr(args, "dropout_input", 0)
         final_dim = args.final_dim if args.final_dim > 0 else args.encoder_embed_dim
+        # registration ORDER follows wav2vec2.py:306-420 (post_extract_proj, project_q, encoder, layer_norm, final_proj):
+        # model.parameters() order is the index space of the reference's optimizer state (checkpoint interop)
+        # pre-training heads (project_q, final_proj): never on the ST path, kept for checkpoint compatibility
+        self.project_q = Linear(self.embed, final_dim) if not getattr(args, "quantize_targets", False) else None
         self.mask_emb = nn.Parameter(torch.FloatTensor(args.encoder_embed_dim).uniform_())
         self.encoder = TransformerEncoder(args)
         self.layer_norm = LayerNorm(self.embed)
-        # pre-training heads: never on the ST path, kept for checkpoint compatibility
-        self.project_q = Linear(self.embed, final_dim) if not getattr(args, "quantize_targets", False) else None
         self.final_proj = Linear(args.encoder_embed_dim, final_dim)
         self._passthrough_state = {}
 

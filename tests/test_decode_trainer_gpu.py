@@ -88,3 +88,45 @@ def test_bf16_trainer_runs_and_decreases_loss():
     sample = golden_sample(g0)
     losses = [tr.train_step([sample])["loss"] for _ in range(12)]
     assert all(np.isfinite(losses)) and losses[-1] < 0.8 * losses[0]
+
+
+def _resume_trainer(path):
+    CU = import_module("chimera-st_amd.checkpoint_utils")
+    (model,), args, task = CU.load_model_ensemble_and_task([path])
+    crit = import_module("chimera-st_amd.criterions").TripletSTMTContrastiveCriterion(task, False, 0.1, [1.0, 1.0, 1.0], 0.1)
+    Trainer = import_module("chimera-st_amd.trainer").Trainer
+    args.bf16 = False
+    tr = Trainer(args, task, model, crit, device="cuda")
+    extra = tr.load_checkpoint(path)
+    return tr, extra
+
+
+def test_resume_from_reference_checkpoint_reproduces_its_next_update(tmp_path):
+    """tests/golden/ref_checkpoint_tiny.pt was written by the REFERENCE's checkpoint_utils.save_state after two updates; loading it
+    (model + Adam moments + update counter -> lr schedule) and running update 3 must give the reference's update 3."""
+    import os
+    from conftest import GOLDEN
+    g0 = load_golden("chimera_tiny.npz")
+    g = load_golden("ref_checkpoint_tiny_next.npz")
+    tr, extra = _resume_trainer(os.path.join(GOLDEN, "ref_checkpoint_tiny.pt"))
+    assert extra["train_iterator"] == {"epoch": 1, "iterations_in_epoch": 2} and tr.num_updates == 2
+    sample = golden_sample(g0)
+    out = tr.train_step([sample])
+    assert out["loss"] == pytest.approx(float(g["loss/2"]), rel=1e-4)
+    assert out["gnorm"] == pytest.approx(float(g["gnorm/2"]), rel=1e-3)
+    assert out["lr"] == pytest.approx(float(g["lr/3"]), rel=1e-9)
+    for name, p in tr.get_model().named_parameters():
+        assert_close(p, g["param_after3/" + name], 1e-4, "param " + name)
+    # a checkpoint written by THIS build has the reference's structure and resumes to the same next update
+    path = str(tmp_path / "checkpoint_last.pt")
+    tr.save_checkpoint(path, {"train_iterator": {"epoch": 1, "iterations_in_epoch": 3}})
+    state = torch.load(path, weights_only=False)
+    assert list(state.keys()) == ["cfg", "args", "model", "optimizer_history", "extra_state", "last_optimizer_state"]
+    assert state["optimizer_history"][-1]["num_updates"] == 3 and list(state["model"].keys()) == list(tr.get_model().state_dict().keys())
+    nxt = tr.train_step([sample])
+    tr2, extra2 = _resume_trainer(path)
+    assert extra2["train_iterator"]["iterations_in_epoch"] == 3 and tr2.num_updates == 3
+    nxt2 = tr2.train_step([sample])
+    assert nxt2["loss"] == pytest.approx(nxt["loss"], rel=1e-6) and nxt2["gnorm"] == pytest.approx(nxt["gnorm"], rel=1e-5)
+    for (n, a), (_, b) in zip(tr.get_model().named_parameters(), tr2.get_model().named_parameters()):
+        assert float((a - b).abs().max()) < 1e-6, n
