@@ -32,6 +32,7 @@ class Trainer:
         self._model = model
         self.num_updates = 0
         self.dtype = dtype
+        self._dummy_batch = None
 
     def get_model(self):
         return self._model
@@ -64,11 +65,22 @@ class Trainer:
         self.optimizer.zero_grad()
         logs, sample_size = [], 0
         for i, sample in enumerate(samples):
+            # an empty batch (this rank's shard ran out: ShardedIterator pads with []) runs the dummy batch with its loss zeroed
+            # so that every rank issues the same collectives (trainer.py:469-477, 552-556)
+            ignore = sample is None or len(sample) == 0
+            if ignore:
+                assert self._dummy_batch is not None, "an empty batch before any real batch was seen"
+                sample = self._dummy_batch
+            elif self._dummy_batch is None:
+                self._dummy_batch = sample
             sample = self._prepare_sample(sample)
             last = i == len(samples) - 1
             ctx = self.model.no_sync() if (self.world > 1 and not last) else contextlib.nullcontext()
             with ctx:
-                loss, ss, log = self.task.train_step(sample, self.model, self.criterion, self.optimizer, self.num_updates)
+                loss, ss, log = self.task.train_step(sample, self.model, self.criterion, self.optimizer, self.num_updates,
+                                                     ignore_grad=ignore)
+            if ignore:
+                log, ss = {k: v * 0 for k, v in log.items()}, 0
             logs.append(log)
             sample_size += ss
         if self.world > 1:
@@ -88,6 +100,14 @@ class Trainer:
         out["gnorm"] = float(gnorm)
         out["lr"] = self.optimizer.get_lr()
         return out
+
+    @torch.no_grad()
+    def valid_step(self, sample):
+        """trainer.py:702-760: criterion outputs of one validation batch (device scalars)."""
+        if sample is None or len(sample) == 0:
+            return None
+        loss, ss, log = self.task.valid_step(self._prepare_sample(sample), self._model, self.criterion)
+        return log
 
     # ---- checkpoints in the reference's format (fairseq/trainer.py:270-395; checkpoint_utils.py) -------------------------
     def save_checkpoint(self, filename, extra_state=None):
