@@ -756,5 +756,8 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
 }
 
 // (A row-split dispatch — whole rounds of 256 x 256 tiles to the persistent kernel, the remaining row slab to the 128 x 128
-// configurations — was measured for the N = 768 family (564 tiles = 2.2 rounds): 0.241 vs 0.244 ms, no gain; not kept.)
+// configurations — was measured for the N = 768 family (564 tiles = 2.2 rounds): 0.241 vs 0.244 ms, no gain; not kept.
+// Second attempt, the slab kept on the persistent kernel as a split-K (x3-4) launch + reduce epilogue: fc2 fwd 0.275 vs 0.278 ms,
+// out_proj 0.105 vs 0.093, qkv dX 0.215 vs 0.189 — the 20 %-occupied last round is not a full round's cost (the 52 busy CUs run
+// with the whole chip's bandwidth and clock budget), and the slabs + reduce launch cost more than it saves; not kept.)
 extern "C" int cst_gemm(const cst_gemm_desc* d, cst_stream stream) { return gemm_one(d, stream, 0); }
