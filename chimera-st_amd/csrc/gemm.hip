@@ -62,26 +62,39 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmParams p) {
 
   // ---- XCD-aware tile id (bijective) ----
   const int ntiles = p.tiles_m * p.tiles_n;
-  int id = blockIdx.x;
-  {
-    const int q = ntiles / 8, r = ntiles % 8, xcd = id % 8, loc = id / 8;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
-  // grouped order inside each XCD's contiguous id range: GROUP_M row-tiles x all column-tiles, walked column-major, so the
-  // ~64 tiles an XCD runs concurrently form a compact 8 x 8 patch (8 A panels + 8 B panels ~ 3 MB at K=768: fits the 4 MB L2)
-  constexpr int GROUP_M = 8;
-  int tm, tn;
-  {
+  int tm, tn, z;
+  if (p.split_order) {
+    // split-K, unbatched (the dW GEMMs: 12 x 3 tiles x 7 splits = 252 workgroups, one round): the work items (split, m tile,
+    // n tile) are laid out split-major / n-fastest and each XCD takes one CONTIGUOUS run of them, so the ~32 workgroups that share
+    // an XCD's 4 MiB L2 work on one or two K slices and neighbouring tiles: an A slice is fetched once for its 3 n tiles and a B
+    // slice once for the ~11 m tiles of the run.  With the plain (x, z) grid order the tiles of one split were dealt round-robin
+    // over all 8 XCDs and every operand slice was fetched by several L2s: 924 MB at the fabric for 370 MB of operands, at 5.9 TB/s.
+    const int total = ntiles * p.splits, L = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.z;
+    const int q = total / 8, r = total % 8, xcd = L % 8, loc = L / 8;
+    const int item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    z = item / ntiles;
+    const int t = item % ntiles;
+    tm = t / p.tiles_n;
+    tn = t % p.tiles_n;
+  } else {
+    int id = blockIdx.x;
+    {
+      const int q = ntiles / 8, r = ntiles % 8, xcd = id % 8, loc = id / 8;
+      id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    // grouped order inside each XCD's contiguous id range: GROUP_M row-tiles x all column-tiles, walked column-major, so the
+    // ~64 tiles an XCD runs concurrently form a compact 8 x 8 patch (8 A panels + 8 B panels ~ 3 MB at K=768: fits the 4 MB L2)
+    constexpr int GROUP_M = 8;
     const int per_group = GROUP_M * p.tiles_n;
     const int grp = id / per_group, rem = id % per_group;
     const int gm0 = grp * GROUP_M;
     const int gsz = (p.tiles_m - gm0 < GROUP_M) ? (p.tiles_m - gm0) : GROUP_M;
     tm = gm0 + rem % gsz;
     tn = rem / gsz;
+    z = blockIdx.z;
   }
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
 
-  const int z = blockIdx.z;
   const int split = z % p.splits;
   const int64_t bidx = z / p.splits;
   const int64_t b0 = bidx / p.batch1, b1 = bidx % p.batch1;
@@ -567,6 +580,8 @@ int launch(GemmParams p, int64_t M, int64_t N, int64_t nbatch, hipStream_t s) {
   }
   p.tiles_m = (int)cst_ceil_div(M, C::BM);
   p.tiles_n = (int)cst_ceil_div(N, C::BN);
+  static const bool no_split_order = getenv("CST_GEMM_NO_SPLIT_ORDER") != nullptr;
+  p.split_order = (p.splits > 1 && nbatch == 1 && !no_split_order) ? 1 : 0;
   dim3 grid(p.tiles_m * p.tiles_n, 1, (unsigned)(nbatch * p.splits));
   hipLaunchKernelGGL((gemm_kernel<T, AK, BK_, SEG, C>), grid, dim3(C::NT), lds, s, p);
   return cst_check_launch("cst_gemm");
@@ -686,6 +701,7 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
     p.vec_epi = ok ? 1 : 0;
   }
   p.tiles_m = p.tiles_n = 0;  // set per configuration in launch()
+  p.split_order = 0;
   p.splits = choose_splits(d);
   p.ws = nullptr;
 #ifdef CST_TRACE

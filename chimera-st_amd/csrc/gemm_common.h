@@ -26,6 +26,7 @@ struct GemmParams {
   int vec_epi;  // all epilogue operands 16-byte aligned -> staged, vectorised epilogue
   int tiles_m, tiles_n;
   int nz;  // persistent kernels: number of (batch, split) slices
+  int split_order;  // gemm_kernel, split-K unbatched: XCD-contiguous (split, tile) item order (see the kernel)
 };
 
 __device__ __forceinline__ int64_t segaddr(int64_t c, int64_t seg, int64_t seg_stride) {
