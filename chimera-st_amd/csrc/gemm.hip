@@ -36,6 +36,10 @@ using CfgSmall = Cfg<128, 128, 2, 2>;   // 4 waves, 2 blocks/CU: small / skinny 
 // bound by how many bytes each CU keeps in flight, not by MFMA: with 128 x 128 tiles a 160 x 1024 x 1024 projection is 16
 // workgroups behind a 2-stage ring (13 us + a 5 us split-K reduce, or 33 us unsplit); this configuration runs it as 48.
 using CfgSkinny = Cfg<64, 64, 2, 2>;
+// narrow problems (wav2vec2 pos_conv: per (utterance, group) 1499 x 48 x 6144 forward / dX, 48 x 6144 x 1499 dW): a 128 x 128 tile
+// spends 62 % of its MFMAs on columns (rows) that do not exist; these keep 75 %
+using CfgNarrowN = Cfg<128, 64, 2, 2>;
+using CfgNarrowM = Cfg<64, 128, 2, 2>;
 using CfgLarge = Cfg<256, 256, 4, 4>;   // 8 waves (wave tile 128 x 64), 1 block/CU: half the L2->LDS bytes per FLOP
 
 template <typename T, bool A_KMAJOR, bool B_KMAJOR, bool SEG, typename C>
@@ -749,7 +753,14 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
   //  with an act'(aux_in) epilogue, whose 128 KiB-per-tile operand read is exposed at one workgroup per CU: 0.49 vs 0.42 ms)
   static const bool all_8p = getenv("CST_GEMM_8P_ALL") != nullptr;
   static const bool no_skinny = getenv("CST_GEMM_NO_SKINNY") != nullptr;
-  if (!no_skinny && ak && bk && !seg && d->M <= 256 && nbatch == 1 && p.splits == 1) {
+  static const bool no_narrow = getenv("CST_GEMM_NO_NARROW") != nullptr;
+  if (!no_narrow && !seg && !large && ak && bk && d->N <= 64 && d->M > 256) {
+    rc = d->dtype == CST_BF16 ? launch_glds<bf16_t, true, true, CfgNarrowN, 2>(p, d->M, d->N, nbatch, s)
+                              : launch_glds<float, true, true, CfgNarrowN, 2>(p, d->M, d->N, nbatch, s);
+  } else if (!no_narrow && !seg && !large && !ak && !bk && d->M <= 64 && d->N > 256) {
+    rc = d->dtype == CST_BF16 ? launch<bf16_t, false, false, false, CfgNarrowM>(p, d->M, d->N, nbatch, s)
+                              : launch<float, false, false, false, CfgNarrowM>(p, d->M, d->N, nbatch, s);
+  } else if (!no_skinny && ak && bk && !seg && d->M <= 256 && nbatch == 1 && p.splits == 1) {
     rc = d->dtype == CST_BF16 ? launch_glds<bf16_t, true, true, CfgSkinny, 4>(p, d->M, d->N, nbatch, s)
                               : launch_glds<float, true, true, CfgSkinny, 4>(p, d->M, d->N, nbatch, s);
   } else if (d->dtype == CST_BF16 && !seg && !no_8p && (ak || all_8p || force_8p) && (!d->dact || all_8p || force_8p) && (large || force_8p) && cst_gemm8p_supported(p, ak, bk, nbatch))

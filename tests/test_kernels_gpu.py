@@ -164,6 +164,28 @@ def test_gemm_grouped_posconv(K, dt):
     check(y, ref, dt, "grouped pos-conv")
 
 
+@pytest.mark.parametrize("dt", DT)
+def test_pos_conv_function_wav2vec_small_shape(K, dt):
+    """functional.pos_conv_gelu_residual at the wav2vec2-small shape (C 768, 16 groups of 48 channels, k 128; T > 256 so the
+    narrow-tile GEMM configurations run): forward and all three gradients against torch's grouped conv1d."""
+    CF = __import__("importlib").import_module("chimera-st_amd.functional")
+    B_, T, C, G, Kp = 2, 300, 768, 16, 128
+    x = rnd(B_, T, C, dt=dt, seed=60, scale=0.5).requires_grad_(True)
+    w = rnd(C, C // G, Kp, dt=dt, seed=61, scale=0.02).requires_grad_(True)
+    bias = rnd(C, dt=dt, seed=62, scale=0.1).requires_grad_(True)
+    y = CF.pos_conv_gelu_residual(x, w, bias, G)
+    dy = rnd(B_, T, C, dt=dt, seed=63)
+    y.backward(dy)
+    xr, wr, br = (t.detach().float().requires_grad_(True) for t in (x, w, bias))
+    conv = F.conv1d(xr.transpose(1, 2), wr, br, padding=Kp // 2, groups=G)[:, :, :-1]
+    ref = xr + F.gelu(conv).transpose(1, 2)
+    ref.backward(dy.float())
+    check(y, ref, dt, "pos-conv fwd")
+    check(x.grad, xr.grad, dt, "pos-conv dx")
+    check(w.grad, wr.grad, dt, "pos-conv dw", scale=float(wr.grad.abs().max()))
+    check(bias.grad, br.grad, dt, "pos-conv db", scale=float(br.grad.abs().max()))
+
+
 # --------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("rows,cols", [(7, 64), (1000, 512), (333, 768), (50, 1024)])
