@@ -142,7 +142,8 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(const T* dy, cons
 
 // partial [nblocks][2][cols] -> dgamma/dbeta: block = 16 columns x 64 row-groups (48 blocks at 768 columns instead of 12: the
 // pass is latency-bound — 1024 partial rows, two loads each — so more, shorter chains win over wider coalescing)
-__global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* part, float* dgamma, float* dbeta, int nblocks, int cols) {
+template <typename TO>
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* part, TO* dgamma, TO* dbeta, int nblocks, int cols) {
   __shared__ float ra[64][17], rb[64][17];
   const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
@@ -158,8 +159,8 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* part, 
   if (g == 0 && c < cols) {
 #pragma unroll 8
     for (int k = 1; k < 64; ++k) { a += ra[k][cl]; b += rb[k][cl]; }
-    dgamma[c] = a;
-    dbeta[c] = b;
+    DT<TO>::st(dgamma + c, a);  // written in the parameter dtype: no conversion launches after the backward
+    DT<TO>::st(dbeta + c, b);
   }
 }
 
@@ -192,8 +193,8 @@ extern "C" int64_t cst_layernorm_bwd_workspace(int64_t rows, int64_t cols) {
 }
 
 extern "C" int cst_layernorm_bwd(const void* dy, const void* sx, const void* gamma, const float* mean, const float* rstd,
-                                 const void* dres, void* dx, float* dgamma, float* dbeta, void* workspace, int64_t rows,
-                                 int64_t cols, int dtype, cst_stream stream) {
+                                 const void* dres, void* dx, void* dgamma, void* dbeta, void* workspace, int64_t rows,
+                                 int64_t cols, int dtype, int grad_dtype, cst_stream stream) {
   CST_REQUIRE(dy && sx && gamma && mean && rstd && dx && dgamma && dbeta && workspace, "cst_layernorm_bwd: null tensor");
   CST_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 8 * 64 * LN_MAXV, "cst_layernorm_bwd: cols=%lld must be a multiple of 8 and <= %d", (long long)cols, 8 * 64 * LN_MAXV);
   hipStream_t s = (hipStream_t)stream;
@@ -207,6 +208,10 @@ extern "C" int cst_layernorm_bwd(const void* dy, const void* sx, const void* gam
   else CST_REQUIRE(false, "cst_layernorm_bwd: bad dtype %d", dtype);
   int rc = cst_check_launch("cst_layernorm_bwd");
   if (rc != CST_OK) return rc;
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)cst_ceil_div(cols, 16)), dim3(1024), 0, s, (const float*)workspace, dgamma, dbeta, nb, (int)cols);
+  CST_REQUIRE(grad_dtype == CST_F32 || grad_dtype == dtype, "cst_layernorm_bwd: grad_dtype must be f32 or dtype");
+  if (grad_dtype == CST_BF16)
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel<bf16_t>, dim3((unsigned)cst_ceil_div(cols, 16)), dim3(1024), 0, s, (const float*)workspace, (bf16_t*)dgamma, (bf16_t*)dbeta, nb, (int)cols);
+  else
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel<float>, dim3((unsigned)cst_ceil_div(cols, 16)), dim3(1024), 0, s, (const float*)workspace, (float*)dgamma, (float*)dbeta, nb, (int)cols);
   return cst_check_launch("cst_layernorm_bwd reduce");
 }

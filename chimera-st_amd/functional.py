@@ -78,7 +78,7 @@ class _LinearFn(torch.autograd.Function):
             K.gemm(dz, x2, dw, Np, Kd, M, a_kmajor=0, b_kmajor=0, lda=Np, ldb=Kd, ldc=Kd, split_k=-1)
             dw = dw[:N]
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = K.colsum(dz).to(w.dtype)[:N]
+            db = K.colsum(dz, w.dtype)[:N]
         if ctx.has_resid and ctx.needs_input_grad[3]:
             dres = dy
         return dx, dw, db, dres, None, None, None
@@ -131,7 +131,7 @@ class _FFNFn(torch.autograd.Function):
             dw2 = torch.empty(dout, F_, dtype=w2.dtype, device=w2.device)
             K.gemm(dy2, h, dw2, dout, F_, M, a_kmajor=0, b_kmajor=0, lda=dout, ldb=F_, ldc=F_, split_k=-1)
         if has_b2 and ctx.needs_input_grad[4]:
-            db2 = K.colsum(dy2).to(w2.dtype)
+            db2 = K.colsum(dy2, w2.dtype)
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, d, dtype=x2.dtype, device=x2.device)
             K.gemm(dz1, w1, dx, M, d, F_, a_kmajor=1, b_kmajor=0, lda=F_, ldb=d, ldc=d, split_k=1)
@@ -140,7 +140,7 @@ class _FFNFn(torch.autograd.Function):
             dw1 = torch.empty(F_, d, dtype=w1.dtype, device=w1.device)
             K.gemm(dz1, x2, dw1, F_, d, M, a_kmajor=0, b_kmajor=0, lda=F_, ldb=d, ldc=d, split_k=-1)
         if has_b1 and ctx.needs_input_grad[2]:
-            db1 = K.colsum(dz1).to(w1.dtype)
+            db1 = K.colsum(dz1, w1.dtype)
         return dx, dw1, db1, dw2, db2, (dy if has_res and ctx.needs_input_grad[5] else None), None, None, None, None, None
 
 
@@ -209,8 +209,8 @@ class _LayerNormPassFn(torch.autograd.Function):
         dres = _flat2d(dxp) if dxp is not None else None
         if dy is None:
             return (dxp, None, None, None)
-        dx, dg, db = K.layernorm_bwd(_flat2d(dy), x2, gamma, mean, rstd, dres)
-        return dx.view(ctx.shape), dg.to(gamma.dtype), db.to(gamma.dtype), None
+        dx, dg, db = K.layernorm_bwd(_flat2d(dy), x2, gamma, mean, rstd, dres, grad_dtype=gamma.dtype)
+        return dx.view(ctx.shape), dg, db, None
 
 
 def layer_norm_residual(x, gamma, beta, eps=1e-5):
@@ -466,7 +466,7 @@ class _Conv1dCLFn(torch.autograd.Function):
                    sa=(dz_bs, 0), sb=(xp.stride(0), 0), sc=(Cout * k * Cin, 0), a_off=dz_off, split_k=sk)
             dw = part.sum(0).to(w_cl.dtype)
         if has_bias and ctx.needs_input_grad[2]:
-            db = K.colsum(dz_rows.reshape(B * Lout, Cout) if dzp is None else dzp[:, 1:1 + Lout].reshape(B * Lout, Cout)).to(w_cl.dtype)
+            db = K.colsum(dz_rows.reshape(B * Lout, Cout) if dzp is None else dzp[:, 1:1 + Lout].reshape(B * Lout, Cout), w_cl.dtype)
         return dx, dw, db, None, None, None, None, None, None
 
 
@@ -536,7 +536,7 @@ class _PosConvFn(torch.autograd.Function):
                    sa=(T * C, cg), sb=(groups * Tp * cg, Tp * cg), sc=(groups * cg * k * cg, cg * k * cg), split_k=1)
             dw = part.sum(0).view(groups, cg, k, cg).permute(0, 1, 3, 2).reshape(C, cg, k).to(weight.dtype)
         if ctx.needs_input_grad[2]:
-            db = K.colsum(dz.view(B * T, C)).to(weight.dtype)
+            db = K.colsum(dz.view(B * T, C), weight.dtype)
         return dx, dw, db, None
 
 

@@ -87,7 +87,7 @@ SYMBOLS = [
     ("cst_prof_query", c_i64, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     ("cst_layernorm_fwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_f, c_int, c_p]),
     ("cst_layernorm_bwd_workspace", c_i64, [c_i64, c_i64]),
-    ("cst_layernorm_bwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_int, c_p]),
+    ("cst_layernorm_bwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_int, c_int, c_p]),
     ("cst_gemm_workspace", c_i64, [ctypes.POINTER(GemmDesc)]),
     ("cst_gemm", c_int, [ctypes.POINTER(GemmDesc), c_p]),
     ("cst_attn_fwd", c_int, [ctypes.POINTER(AttnDesc), c_p]),

@@ -64,12 +64,12 @@ int cst_layernorm_fwd(const void* x, const void* res, const void* gamma, const v
                       void* y, void* sum_out, float* mean, float* rstd,
                       int64_t rows, int64_t cols, float eps, int dtype, cst_stream stream);
 /* dx = LN backward w.r.t. s (s = x + res is what `s` points to); dgamma/dbeta fp32 [cols]
- * (overwritten).  dres (optional extra upstream gradient on s, e.g. the residual branch) is
+ * (overwritten) in `grad_dtype` (CST_F32 or `dtype`: accumulated in fp32, rounded once).  dres (optional extra upstream gradient on s, e.g. the residual branch) is
  * added into dx when non-NULL.  workspace: cst_layernorm_bwd_workspace() bytes. */
 int64_t cst_layernorm_bwd_workspace(int64_t rows, int64_t cols);
 int cst_layernorm_bwd(const void* dy, const void* s, const void* gamma, const float* mean,
-                      const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
-                      void* workspace, int64_t rows, int64_t cols, int dtype, cst_stream stream);
+                      const float* rstd, const void* dres, void* dx, void* dgamma, void* dbeta,
+                      void* workspace, int64_t rows, int64_t cols, int dtype, int grad_dtype, cst_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * GEMM on MFMA tiles — replaces F.linear / nn.Conv1d call sites:

@@ -203,6 +203,8 @@ def test_layernorm(K, dt, rows, cols):
     dy, dres = rnd(rows, cols, dt=dt, seed=22), rnd(rows, cols, dt=dt, seed=23)
     yr.backward(dy.float())
     dx, dg, db = k.layernorm_bwd(dy, s, g, mean, rstd, dres)
+    _, dg_t, db_t = k.layernorm_bwd(dy, s, g, mean, rstd, dres, grad_dtype=dt)  # gradients written in the parameter dtype
+    assert dg_t.dtype == dt and torch.equal(dg_t, dg.to(dt)) and torch.equal(db_t, db.to(dt))
     check(dx, sref.grad + dres.float(), dt, "ln dx")
     check(dg, gr.grad, dt, "ln dgamma")
     check(db, br.grad, dt, "ln dbeta")
@@ -334,6 +336,12 @@ def test_elementwise(K, dt):
         check(k.act_bwd(g, x, act), xr.grad, dt, "act bwd")
     x = rnd(1234, 72, dt=dt, seed=54)
     check(k.colsum(x), x.float().sum(0), dt, "colsum")
+    for rows, cols in ((47968, 768), (33, 8), (4096, 10000)):
+        big = rnd(rows, cols + 8, dt=dt, seed=55)[:, :cols]
+        ref = big.float().sum(0)
+        a = k.colsum(big, dt)
+        assert a.dtype == dt
+        check(a, ref, dt, "colsum %dx%d" % (rows, cols), scale=float(ref.abs().max()))
     m = (torch.arange(1234) % 3 == 0).to(torch.uint8).cuda()
     check(k.mask_rows(x, m), x.float() * (1 - m.float())[:, None], dt, "mask_rows")
 
