@@ -224,6 +224,15 @@ def main():
             roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                     "traffic": None, "launches": r["launches"], "avg_launch_ms": r["ms"] / max(r["launches"], 1)}
         roof["per_class_ms"] = {k: round(v["ms"], 3) for k, v in table.items() if v["launches"]}
+        roof["algorithmic_bytes"] = r["bytes"] / max(r["launches"], 1)
+        # HBM-side traffic of the same launches from the committed PMC pass of this command (counters need their own rocprofv3
+        # run and cannot be read inside the timed process); only quoted for the workload it was collected on
+        pmc = os.path.join(ROOT, "profiles", "r01b_pmc_gemm_class.json")
+        if name == "gemm" and os.path.exists(pmc) and args.model == "s2t_w2v2" and args.batch == 32 and args.seconds == 30.0 and args.dtype == "bf16":
+            rec = json.load(open(pmc))
+            if abs(rec["gemm_class_launches_per_update"] - r["launches"]) <= 8:
+                roof["traffic"] = rec["traffic_bytes_per_launch"]
+                roof["traffic_note"] = rec["note"]
         if name == "gemm" and args.dtype == "bf16":
             roof["dominant_launch"] = dominant_gemm_launch(args, device)
     cpu = None
