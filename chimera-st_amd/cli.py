@@ -36,6 +36,7 @@ def _extra_train_flags(argv):
     p.add_argument("--no-save", action="store_true")
     p.add_argument("--restore-file", default="checkpoint_last.pt")
     p.add_argument("--disable-validation", action="store_true")
+    p.add_argument("--data-buffer-size", type=int, default=8)
     p.add_argument("--label-smoothing-placeholder", default=None, help=argparse.SUPPRESS)
     return p.parse_known_args(argv)
 
@@ -89,6 +90,7 @@ def train_main(argv=None):
     itr = task.get_batch_iterator(train_ds, max_tokens=args.max_tokens, max_sentences=args.batch_size, max_positions=task.max_positions(),
                                   ignore_invalid_inputs=True, required_batch_size_multiple=8 if args.batch_size is None else 1,
                                   seed=args.seed, num_shards=world, shard_id=rank, epoch=start_epoch)
+    itr.pin_memory = True
     best = None
     max_update = args.max_update or math.inf
     max_epoch = args.max_epoch or math.inf
@@ -107,7 +109,7 @@ def train_main(argv=None):
     while epoch <= max_epoch and trainer.num_updates < max_update:
         uf = args.update_freq[min(epoch - 1, len(args.update_freq) - 1)]
         t0, group, n_it, agg = time.time(), [], 0, {}
-        for i, sample in enumerate(itr.next_epoch_itr(shuffle=True)):
+        for i, sample in enumerate(itr.next_epoch_itr(shuffle=True, buffer_size=max(getattr(args, "data_buffer_size", 8), 0))):
             if epoch == start_epoch and i < skip:
                 continue
             group.append(sample)

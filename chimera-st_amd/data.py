@@ -443,7 +443,9 @@ class EpochBatchIterator:
         mine = batches[self.shard_id::self.num_shards]
         return mine + [[] for _ in range(len(self) - len(mine))]
 
-    def next_epoch_itr(self, shuffle=True):
+    def next_epoch_itr(self, shuffle=True, buffer_size=0):
+        """buffer_size > 0: batches are decoded / collated (and pinned) by a background thread that stays that many batches ahead
+        of the consumer (iterators.py BufferedIterator :503-570): WAV decoding and padding overlap the GPU update."""
         batches = self.epoch_batches(self.epoch, shuffle)
         self.epoch += 1
 
@@ -453,7 +455,30 @@ class EpochBatchIterator:
                 if self.pin_memory and sample:
                     sample = _pin(sample)
                 yield sample
-        return gen()
+        return _buffered(gen(), buffer_size) if buffer_size > 0 else gen()
+
+
+def _buffered(source, size):
+    import queue
+    import threading
+    q, done = queue.Queue(maxsize=size), object()
+
+    def work():
+        try:
+            for item in source:
+                q.put(item)
+            q.put(done)
+        except BaseException as e:  # surface loader errors in the consumer
+            q.put(e)
+
+    threading.Thread(target=work, daemon=True).start()
+    while True:
+        item = q.get()
+        if item is done:
+            return
+        if isinstance(item, BaseException):
+            raise item
+        yield item
 
 
 def _pin(x):

@@ -82,6 +82,26 @@ def test_epoch_iterator_shuffle_and_shards(task, split, shuffle):
                 assert np.concatenate(ids).tolist() == g[key + "ids"].tolist(), key
 
 
+def test_buffered_iterator_equals_plain(task):
+    ds = task.load_dataset("train_st")
+    it = task.get_batch_iterator(ds, max_tokens=12000, seed=1, epoch=1)
+    plain = [s["id"].tolist() for s in it.next_epoch_itr(shuffle=True)]
+    it = task.get_batch_iterator(ds, max_tokens=12000, seed=1, epoch=1)
+    buffered = [s["id"].tolist() for s in it.next_epoch_itr(shuffle=True, buffer_size=2)]
+    assert plain == buffered and len(plain) > 1
+
+    class Boom:
+        def collater(self, x):
+            raise ValueError("decode failed")
+
+        def __getitem__(self, i):
+            return i
+    D = import_module("chimera-st_amd.data")
+    bad = D.EpochBatchIterator(Boom(), [[0], [1]])
+    with pytest.raises(ValueError, match="decode failed"):
+        list(bad.next_epoch_itr(shuffle=False, buffer_size=2))
+
+
 def test_batch_by_size_native_properties():
     """Edge cases of the native batcher: empty input, one oversized sample (error), multiples."""
     D = import_module("chimera-st_amd.data")
