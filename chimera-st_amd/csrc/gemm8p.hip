@@ -125,7 +125,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
       const int q = ntiles / 8, r = ntiles % 8, xcd = id % 8, loc = id / 8;
       id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    constexpr int GROUP_M = 8;
+    const int GROUP_M = kp->group_m;
     const int per_group = GROUP_M * p.tiles_n;
     const int grp = id / per_group, rem = id % per_group;
     const int gm0 = grp * GROUP_M;

@@ -26,6 +26,7 @@ struct GemmParams {
   int vec_epi;  // all epilogue operands 16-byte aligned -> staged, vectorised epilogue
   int tiles_m, tiles_n;
   int nz;  // persistent kernels: number of (batch, split) slices
+  int group_m;      // gemm8p: m tiles per group of the tile walk (the patch of tiles an XCD works on concurrently)
   int split_order;  // gemm_kernel, split-K unbatched: XCD-contiguous (split, tile) item order (see the kernel)
 };
 
