@@ -117,9 +117,13 @@ class TransformerDecoder(FairseqIncrementalDecoder):
             x = x + positions.to(x.dtype)
         x = self.dropout_module(x)
         x = to_time_major_view(x.contiguous())
-        self_attn_padding_mask = None
-        if prev_output_tokens.eq(self.padding_idx).any():
+        # transformer.py:768-770 builds this mask only `if prev_output_tokens.eq(pad).any()` — a host sync between encoder and
+        # decoder; the mask of a pad-free batch is all-False and changes nothing, so the full-sequence (training) path always
+        # builds it; the host-driven single-step path keeps the reference's test
+        if incremental_state is None:
             self_attn_padding_mask = prev_output_tokens.eq(self.padding_idx)
+        else:
+            self_attn_padding_mask = prev_output_tokens.eq(self.padding_idx) if prev_output_tokens.eq(self.padding_idx).any() else None
         inner_states = [x]
         for idx, layer in enumerate(self.layers):
             if incremental_state is None and not full_context_alignment:
@@ -229,8 +233,6 @@ class S2TTransformerEncoder(FairseqEncoder):
         x = self.dropout_module(x)
         for layer in self.transformer_layers:
             x = layer(x, encoder_padding_mask)
-        if not encoder_padding_mask.any():
-            encoder_padding_mask = None
         if self.layer_norm is not None:
             x = self.layer_norm(x)
         return EncoderOut(encoder_out=x, encoder_padding_mask=encoder_padding_mask, encoder_embedding=None,

@@ -112,8 +112,9 @@ class S2T_W2V2_TransformerEncoder(FairseqEncoder):
         x = self.dropout_module(x)
         for layer in self.transformer_layers:
             x = layer(x, encoder_padding_mask)
-        if not encoder_padding_mask.any():
-            encoder_padding_mask = None
+        # (the reference drops an all-False mask here, w2v2_transformer.py:377-378: `.any()` is a host sync in the middle of the
+        #  forward pass — the queue drains and the decoder's small kernels are then launch-bound.  An all-False mask gives the
+        #  same results in the fused attention kernels, so it is kept.)
         if self.layer_norm is not None:
             x = self.layer_norm(x)
         return EncoderOut(encoder_out=x, encoder_padding_mask=encoder_padding_mask, encoder_embedding=None,
