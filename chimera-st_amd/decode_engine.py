@@ -36,9 +36,11 @@ class BeamDecodeEngine:
         self.unk_penalty, self.temperature = float(unk_penalty), float(temperature)
         self.use_graph, self.poll = use_graph, max(1, int(poll))
         # cross attention per step: "flash" = cst_attn_fwd with batch = sentence and the beam rows as the query axis (37 us per
-        # layer at 32 x beam 5 x 750 source positions, bf16); "shared" = cst_dec_cross_attn (dedicated kernel, head-major K/V;
-        # measured 51 us on the same shape: three dependent passes per wave — kept selectable, covered by the same tests)
-        assert cross_kernel in ("flash", "shared")
+        # layer at 32 x beam 5 x 750 source positions, bf16); "flash_hm" = the same kernel over head-major K/V (contiguous per-head
+        # streams: no faster, 0.811 vs 0.812 ms per step); "shared" = cst_dec_cross_attn (VALU kernel, one pass with online
+        # softmax, K/V rows shared by the beam: ~59 us — the 5 queries' dot products per key cost more than the MFMA tile the
+        # flash kernel spends on them; kept selectable, covered by the same tests)
+        assert cross_kernel in ("flash", "flash_hm", "shared")
         self.cross_kernel = cross_kernel
         self._packed = None
         self._state = {}
@@ -128,10 +130,8 @@ class BeamDecodeEngine:
                resid=resid, ld_resid=0 if resid is None else resid.stride(0), split_k=1)
 
     def _cross_fits(self, S, D):
-        if self.cross_kernel != "shared":
-            return False
-        bq = 1 if self.beam == 1 else (5 if self.beam <= 5 else 8)
-        return (bq * S + 8 * bq + 4 * bq * D) * 4 <= 150 * 1024
+        """True: the encoder K/V of this engine are stored head-major [bsz, H, S, D]."""
+        return self.cross_kernel in ("shared", "flash_hm")
 
     def _ln(self, x, ln, out, st):
         lib = L.load()
@@ -163,7 +163,14 @@ class BeamDecodeEngine:
             self._linear(st["h"], ca.q_proj.weight, ca.q_proj.bias, st["q"])
             # cross attention: one workgroup per (sentence, head); the sentence's K/V rows serve all of its beam rows
             S = st["kx"][li].shape[1]
-            if self._cross_fits(S, D):
+            if self.cross_kernel == "flash_hm":  # the flash kernel over head-major K/V: (b, h, t) strides = (H*S*D, S*D, D)
+                q3, o3 = st["q"].view(bsz, self.beam, C), st["attn"].view(bsz, self.beam, C)
+                d = K.attn_desc(q3, st["kx"][li], st["vx"][li], o3, st["lse"], H, D, st["kpm"], False, float(ca.scaling))
+                d.k_sb = d.v_sb = H * S * D
+                d.k_sh = d.v_sh = S * D
+                d.k_st = d.v_st = D
+                K.attn_fwd_desc(d)
+            elif self.cross_kernel == "shared":
                 L.check(lib.cst_dec_cross_attn(L.ptr(st["q"]), L.ptr(st["kx"][li]), L.ptr(st["vx"][li]), L.ptr(st["kpm"]), L.ptr(st["attn"]),
                                                L.ptr(st["step"]), self.max_len, bsz, self.beam, H, D, S, float(ca.scaling), dt,
                                                L.stream_ptr()), "cst_dec_cross_attn")

@@ -301,7 +301,7 @@ int cst_dec_self_attn(const void* qkv, void* kcache, void* vcache, const int32_t
                       int64_t rows, int64_t H, int64_t D, int64_t max_len, float scale, int dtype, cst_stream stream);
 /* Cross attention of one decode step (modules/multihead_attention.py:189-293 with static_kv): q, out [bsz*beam, H*D];
  * kx, vx HEAD-MAJOR [bsz, H, S, D] — the encoder keys / values of a SENTENCE, shared by its beam hypotheses (not replicated);
- * key_padding_mask uint8 [bsz, S] or NULL.  No-op when *step > max_len.  beam * S * 4 bytes of LDS: S <= ~7000 at beam 5. */
+ * key_padding_mask uint8 [bsz, S] or NULL.  No-op when *step > max_len.  One pass, online softmax; any S. */
 int cst_dec_cross_attn(const void* q, const void* kx, const void* vx, const uint8_t* key_padding_mask, void* out,
                        const int32_t* step, int64_t max_len, int64_t bsz, int64_t beam, int64_t H, int64_t D, int64_t S, float scale,
                        int dtype, cst_stream stream);

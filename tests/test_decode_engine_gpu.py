@@ -223,7 +223,7 @@ def _build_s2t(dtype, d=256, heads=4, layers=2, V=500, seed=3, tied=True):
     return model.to("cuda", dtype).eval(), task
 
 
-@pytest.mark.parametrize("cross_kernel", ["flash", "shared"])
+@pytest.mark.parametrize("cross_kernel", ["flash", "flash_hm", "shared"])
 @pytest.mark.parametrize("beam", [1, 4])
 def test_engine_equals_mirror_loop_ragged_batch(beam, cross_kernel):
     """fp32 s2t_transformer (fbank input, ragged lengths -> encoder_padding_mask): the captured-graph device loop and the

@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--mirror", action="store_true", help="also time the host-driven loop (fused=False)")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--cross-kernel", default="flash", choices=["flash", "shared"])
+    ap.add_argument("--cross-kernel", default="flash", choices=["flash", "flash_hm", "shared"])
     ap.add_argument("--profile", action="store_true", help="per-class GPU time of one eager decode loop (hipEvent pairs)")
     args = ap.parse_args()
 
