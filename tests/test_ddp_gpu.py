@@ -76,3 +76,46 @@ def test_two_ranks_equal_one_rank_on_both_batches():
     ref = tr.buffers.flat_param.detach().cpu().numpy()
     # Adam normalises by sqrt(v): elements whose gradient is ~1e-8 amplify summation-order noise; bound = 1% of the lr-sized step
     np.testing.assert_allclose(res[0][3], ref, rtol=1e-4, atol=1e-5)
+
+
+def _worker_uneven(rank, world, port, q):
+    """Rank 1's shard of the epoch has run out: it gets the empty batch ShardedIterator pads with (iterators.py:470-500) and must
+    still take part in every collective with a zeroed contribution (trainer.py:469-477, 552-556)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    model, task, crit = _build()
+    Trainer = import_module("chimera-st_amd.trainer").Trainer
+    tr = Trainer(_targs(), task, model, crit, device="cuda")
+    a, b = _samples(task)
+    tr.train_step([a if rank == 0 else b])          # both ranks have data
+    out = tr.train_step([a if rank == 0 else {}])   # rank 1: empty batch -> dummy batch, loss * 0
+    q.put((rank, out["loss"], out["sample_size"], out["gnorm"], tr.buffers.flat_param.detach().cpu().numpy()))
+    dist.destroy_process_group()
+
+
+def test_empty_shard_batch_contributes_zero():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_uneven, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(res[0][4], res[1][4])  # replicas stay bit-identical
+    # one process: the same two updates with the second made of rank 0's batch only
+    model, task, crit = _build()
+    Trainer = import_module("chimera-st_amd.trainer").Trainer
+    tr = Trainer(_targs(), task, model, crit, device="cuda")
+    a, b = _samples(task)
+    tr.train_step([a, b])
+    out = tr.train_step([a])
+    assert out["sample_size"] == res[0][2] and out["loss"] == pytest.approx(res[0][1], rel=1e-5)
+    assert out["gnorm"] == pytest.approx(res[0][3], rel=1e-4)
+    np.testing.assert_allclose(res[0][4], tr.buffers.flat_param.detach().cpu().numpy(), rtol=1e-4, atol=2e-5)
