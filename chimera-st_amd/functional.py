@@ -2,6 +2,8 @@
 path is nn.Module.forward / autograd.Function calling ATen; here they call libcst_hip.so).
 
 Every function requires CUDA(HIP) tensors; there is no CPU path."""
+import os as _os
+
 import torch
 
 from . import kernels as K
@@ -229,6 +231,8 @@ def _mask_and_len(key_padding_mask):
     kernels skip the all-padding key tiles at the end of every utterance of a length-sorted batch (cst_attn_desc.kv_len)."""
     if key_padding_mask is None:
         return None, None
+    if _os.environ.get("CST_ATTN_NO_KVLEN"):  # test hook: walk every key tile (results are bit-identical either way)
+        return key_padding_mask.to(torch.uint8).contiguous(), None
     for src, ver, u8, kvl in _MASK_CACHE:
         if src is key_padding_mask and ver == key_padding_mask._version:
             return u8, kvl
