@@ -38,7 +38,27 @@ struct AttnParams {
   float* delta;
   uint32_t drop_thr, drop_key; float drop_scale;  // attention-probability dropout (drop_thr == 0: none)
   const int32_t* kv_len;  // optional [B]: keys >= kv_len[b] are all padding -> their tiles are skipped (they contribute exact zeros)
+  uint8_t* q_flags;       // optional [B][H][ceil(Tq/64)] (backward): 1 = the 64-query tile has a non-zero dO row
 };
+
+// last query (exclusive, multiple of 64) whose tile carries a non-zero upstream gradient; wave 0 scans the flags
+__device__ __forceinline__ int live_query_end(const AttnParams& p, int64_t b, int64_t h, int* sh, int tid) {
+  const int nqt = (int)((p.Tq + 63) / 64);
+  if (!p.q_flags) return (int)p.Tq;
+  if (tid < 64) {
+    const uint8_t* f = p.q_flags + (b * p.H + h) * nqt;
+    int last = -1;
+    for (int base = 0; base < nqt; base += 64) {
+      const int idx = base + tid;
+      const unsigned long long m = __ballot(idx < nqt && f[idx < nqt ? idx : 0] != 0);
+      if (m) last = base + 63 - __clzll(m);
+    }
+    if (tid == 0) *sh = (last + 1) * 64;
+  }
+  __syncthreads();
+  const int e = *sh;
+  return e < (int)p.Tq ? e : (int)p.Tq;
+}
 
 // the row (within a 32-row MFMA tile) that k-slot j of half-wave `hi` holds for the 16-row step t
 __device__ __forceinline__ int slot_row(int t, int j, int hi) { return 16 * t + (j & 3) + 8 * (j >> 2) + 4 * hi; }
@@ -261,25 +281,32 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_fwd_ke
   }
 }
 
-// delta[b,h,q] = sum_d dO*O
+// delta[b,h,q] = sum_d dO*O; one wave per (b, h, 64-query tile).  It also records whether the tile has any non-zero dO row: in a
+// length-sorted, right-padded batch the gradient of padded frames is exactly zero wherever nothing downstream reads them (every
+// wav2vec2 layer of the s2t model beyond the subsampler's receptive field), and a tile of zero dO rows contributes exact zeros
+// to dQ, dK and dV (dP = dO V^T = 0, delta = 0 -> dS = P (0 - 0) = 0): the backward kernels stop at the last live tile.
 template <typename T, int D>
-__global__ void attn_delta_kernel(AttnParams p) {
-  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t total = p.B * p.H * p.Tq;
-  if (row >= total) return;
-  const int64_t q = row % p.Tq, h = (row / p.Tq) % p.H, b = row / (p.Tq * p.H);
-  const T* o = (const T*)p.O + b * p.o_sb + h * p.o_sh + q * p.o_st;
-  const T* g = (const T*)p.dO + b * p.do_sb + h * p.do_sh + q * p.do_st;
-  float acc = 0.0f;
+__global__ __launch_bounds__(64) void attn_delta_kernel(AttnParams p) {
+  const int64_t b = blockIdx.z, h = blockIdx.y;
+  const int qt = blockIdx.x, lane = threadIdx.x;
+  const int64_t q = (int64_t)qt * 64 + lane;
+  bool nz = false;
+  if (q < p.Tq) {
+    const T* o = (const T*)p.O + b * p.o_sb + h * p.o_sh + q * p.o_st;
+    const T* g = (const T*)p.dO + b * p.do_sb + h * p.do_sh + q * p.do_st;
+    float acc = 0.0f;
 #pragma unroll
-  for (int d = 0; d < D; d += 8) {
-    float a[8], c[8];
-    load8(o + d, a);
-    load8(g + d, c);
+    for (int d = 0; d < D; d += 8) {
+      float a[8], c[8];
+      load8(o + d, a);
+      load8(g + d, c);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc += a[e] * c[e];
+      for (int e = 0; e < 8; ++e) { acc += a[e] * c[e]; nz = nz || c[e] != 0.0f; }
+    }
+    p.delta[(b * p.H + h) * p.Tq + q] = acc;
   }
-  p.delta[row] = acc;
+  const unsigned long long m = __ballot(nz);
+  if (p.q_flags && lane == 0) p.q_flags[(b * p.H + h) * ((p.Tq + 63) / 64) + qt] = m != 0ull ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -304,6 +331,21 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_bwd_dq
   const uint32_t hp = (uint32_t)((p.Tk + 1) >> 1);
   const uint32_t rowpair = (uint32_t)((b * p.H + h) * p.Tq + q) * hp;
 
+  {
+    int* sh_qend = reinterpret_cast<int*>(sMask + 2);
+    const int qend = live_query_end(p, b, h, sh_qend, tid);
+    if (q_blk0 >= qend) {  // every query of this workgroup has a zero upstream gradient: dQ = 0 (workgroup-uniform exit)
+      if (q < p.Tq) {
+        T* g = (T*)p.dQ + b * p.dq_sb + h * p.dq_sh + (int64_t)q * p.dq_st;
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+#pragma unroll
+        for (int dt = 0; dt < D / 32; ++dt) store_dcol<T>(g, z, dt * 32, lane, 1.0f);
+      }
+      return;
+    }
+  }
   Frag<T> fq[D / 16], fdo[D / 16];
   load_row_frags<T, D>(fq, Qg, p.q_st, q, (int)p.Tq, lane);
   load_row_frags<T, D>(fdo, dOg, p.do_st, q, (int)p.Tq, lane);
@@ -487,11 +529,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnParams p) 
     rdo.stage(smem + st * 2 * TILE + TILE, tid);
     if (tid < KT) { sStat[st * 2 * KT + tid] = rl; sStat[st * 2 * KT + KT + tid] = rd; }
   };
-  if (qstart < p.Tq) { prefetch(qstart); stage(0); }
+  const int64_t qlim = live_query_end(p, b, h, reinterpret_cast<int*>(sStat + 4 * KT), tid);  // queries beyond it have dO = 0
+  if (qstart < qlim) { prefetch(qstart); stage(0); }
   __syncthreads();
   int cur = 0;
-  for (int64_t i0 = qstart; i0 < p.Tq; i0 += KT) {
-    const bool more = i0 + KT < p.Tq;
+  for (int64_t i0 = qstart; i0 < qlim; i0 += KT) {
+    const bool more = i0 + KT < qlim;
     if (more) prefetch(i0 + KT);
     const T* sQ = smem + cur * 2 * TILE;
     const T* sdO = sQ + TILE;
@@ -615,6 +658,7 @@ int fill_params(const cst_attn_desc* d, AttnParams& p, bool bwd) {
   p.dv_sb = d->dv_sb; p.dv_sh = d->dv_sh; p.dv_st = d->dv_st;
   p.delta = d->delta;
   p.kv_len = d->kv_len;
+  p.q_flags = bwd ? d->q_flags : nullptr;
   if (bwd) {
     CST_REQUIRE(d->dO && d->dQ && d->dK && d->dV && d->delta, "cst_attn_bwd: null gradient tensor");
     CST_REQUIRE(d->do_sb % vec == 0 && d->do_sh % vec == 0 && d->do_st % vec == 0 && d->o_st % vec == 0 && d->o_sb % vec == 0 && d->o_sh % vec == 0,
@@ -626,7 +670,7 @@ int fill_params(const cst_attn_desc* d, AttnParams& p, bool bwd) {
 
 template <typename T, int D>
 constexpr size_t attn_lds_bytes() {
-  return 4 * (size_t)KT * (D + DT<T>::VEC) * sizeof(T) + 4 * KT * sizeof(float);  // 2 stages x 2 tiles + masks / (lse, delta)
+  return 4 * (size_t)KT * (D + DT<T>::VEC) * sizeof(T) + 4 * KT * sizeof(float) + 16;  // 2 stages x 2 tiles + masks / (lse, delta) + 1 int
 }
 void attn_set_lds(const void* fn) {  // tiles of the f32 / D=64 variants exceed the 64 KiB default (gfx950: 160 KiB per CU)
   (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
@@ -663,12 +707,11 @@ extern "C" int cst_attn_bwd(const cst_attn_desc* d, cst_stream stream) {
   if (rc != CST_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
   CstProfScope prof(CST_K_ATTN_BWD, s, attn_flops(d, 5.0), 0.0);
-  const int64_t rows = d->B * d->H * d->Tq;
   dim3 gq((unsigned)cst_ceil_div(d->Tq, NW * QB), (unsigned)d->H, (unsigned)d->B);
   dim3 gk((unsigned)cst_ceil_div(d->Tk, NW * QB), (unsigned)d->H, (unsigned)d->B);
 #define CST_BWD1(T, DD, DR)                                                                                \
   do {                                                                                                     \
-    hipLaunchKernelGGL((attn_delta_kernel<T, DD>), dim3((unsigned)cst_ceil_div(rows, 256)), dim3(256), 0, s, p); \
+    hipLaunchKernelGGL((attn_delta_kernel<T, DD>), dim3((unsigned)cst_ceil_div(d->Tq, 64), (unsigned)d->H, (unsigned)d->B), dim3(64), 0, s, p); \
     const size_t lds = attn_lds_bytes<T, DD>();                                                              \
     attn_set_lds(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<T, DD, DR>));                             \
     attn_set_lds(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<T, DD, DR>));                            \

@@ -176,6 +176,10 @@ def attn_bwd_fill(d, do, dq, dk, dv, delta, D, layout_q="bt", layout_kv="bt"):
     d.dK = dk.data_ptr(); d.dk_sb, d.dk_sh, d.dk_st = st(dk, layout_kv)
     d.dV = dv.data_ptr(); d.dv_sb, d.dv_sh, d.dv_st = st(dv, layout_kv)
     d.delta = delta.data_ptr()
+    # live-tile flags (cst_attn_desc.q_flags): the backward stops at the last 64-query tile with a non-zero upstream gradient
+    flags = torch.empty(int(d.B) * int(d.H) * ((int(d.Tq) + 63) // 64), dtype=torch.uint8, device=do.device)
+    d.q_flags = flags.data_ptr()
+    d._q_flags_owner = flags  # the workspace lives as long as the descriptor (i.e. until the launch has been enqueued)
 
 
 def attn_bwd(do, q, k, v, o, lse, H, D, kpm, causal, scale, layout_q="bt", layout_kv="bt", drop_p=0.0, drop_key=0, kv_len=None):

@@ -59,6 +59,7 @@ class AttnDesc(ctypes.Structure):
         ("dV", c_p), ("dv_sb", c_i64), ("dv_sh", c_i64), ("dv_st", c_i64),
         ("delta", c_p),
         ("kv_len", c_p),
+        ("q_flags", c_p),
     ]
 
 

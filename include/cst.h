@@ -160,6 +160,10 @@ typedef struct {
    * (trailing padding of a length-sorted batch).  Those key tiles are skipped in all three kernels — they contribute
    * exact zeros, so results are bit-identical to the unskipped run; key_padding_mask still governs keys < kv_len[b]. */
   const int32_t* kv_len;
+  /* optional uint8 [B, H, ceil(Tq/64)] workspace of cst_attn_bwd (NULL = off): the delta pre-pass records which 64-query tiles
+   * have a non-zero dO row and the dQ / dK-dV kernels stop at the last such tile — the tiles beyond it contribute exact zeros
+   * (dP = dO V^T = 0 and delta = 0 give dS = 0), so the gradients are bit-identical to the full walk. */
+  uint8_t* q_flags;
 } cst_attn_desc;
 
 int cst_attn_fwd(const cst_attn_desc* d, cst_stream stream);

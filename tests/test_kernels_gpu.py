@@ -287,6 +287,22 @@ def test_attention_kv_len_skip_is_bit_identical(K, dt, Tq, Tk, drop):
     for a, b, name in zip(outs[0], outs[1], ("o", "lse", "dq", "dk", "dv")):
         assert torch.equal(a, b), name
     assert float(outs[1][3][2, 65:].abs().max()) == 0.0 and float(outs[1][4][3, 1:].abs().max()) == 0.0
+    # zero upstream gradient on trailing query tiles (padded frames nothing downstream reads): the backward stops at the last live
+    # tile; gradients must equal the full walk bit for bit (here: q_flags on vs a descriptor without the workspace)
+    do2 = do.clone()
+    cut = Tq // 2
+    do2[:, cut:] = 0
+    do2[3] = 0
+    o, lse = k.attn_fwd(q, kk, v, H, D, kpm, False, scale, "bt", "bt", drop, 1234, kv_len=kvl)
+    got = k.attn_bwd(do2, q, kk, v, o, lse, H, D, kpm, False, scale, "bt", "bt", drop, 1234, kv_len=kvl)
+    dq0, dk0, dv0 = torch.empty_like(q), torch.empty_like(kk), torch.empty_like(v)
+    d = k.attn_desc(q, kk, v, o, lse, H, D, kpm, False, scale, "bt", "bt", drop, 1234, kvl)
+    k.attn_bwd_fill(d, do2, dq0, dk0, dv0, torch.empty_like(lse), D)
+    d.q_flags = None
+    k.attn_bwd_desc(d)
+    for a, b, name in zip(got, (dq0, dk0, dv0), ("dq", "dk", "dv")):
+        assert torch.equal(a, b), "live-tile skip changed " + name
+    assert float(got[0][:, cut:].abs().max()) == 0.0 and float(got[0][3].abs().max()) == 0.0
     # the host helper derives kv_len from the mask
     CF = __import__("importlib").import_module("chimera-st_amd.functional")
     u8, got = CF._mask_and_len(kpm.bool())
