@@ -86,3 +86,26 @@ def test_cfg_only_pickles_do_not_need_omegaconf(CU, tmp_path):
     assert type(loaded["cfg"]).__name__ == "DictConfig" and loaded["args"].arch == state["args"].arch
     with pytest.raises(IOError):
         CU.load_checkpoint_to_cpu(str(tmp_path / "missing.pt"))
+
+
+def test_average_checkpoints(CU, tmp_path):
+    """tools/average_checkpoints.py: fp32 mean of the floating-point entries, directory + --num-epoch-checkpoints selection."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("avg", os.path.join(os.path.dirname(GOLDEN), "..", "tools", "average_checkpoints.py"))
+    avg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(avg)
+    base = torch.load(CKPT, weights_only=False)
+    for e, scale in ((3, 1.0), (4, 3.0), (5, 5.0), (6, 100.0)):
+        st = dict(base)
+        st["model"] = {k: (v * scale if v.is_floating_point() else v) for k, v in base["model"].items()}
+        torch.save(st, str(tmp_path / ("checkpoint%d.pt" % e)))
+    out = str(tmp_path / "avg.pt")
+    avg.main(["--inputs", str(tmp_path), "--num-epoch-checkpoints", "3", "--checkpoint-upper-bound", "5", "--output", out])
+    got = CU.load_checkpoint_to_cpu(out)
+    for k, v in base["model"].items():
+        if v.is_floating_point():
+            assert torch.allclose(got["model"][k], v * 3.0, rtol=1e-6, atol=0), k
+        else:
+            assert torch.equal(got["model"][k], v), k
+    (model,), _, _ = CU.load_model_ensemble_and_task([out])  # the averaged file is a loadable checkpoint
+    assert list(model.state_dict().keys()) == list(base["model"].keys())
