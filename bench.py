@@ -184,7 +184,7 @@ def main():
     import torch.distributed as dist
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -197,7 +197,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t)
 
@@ -239,6 +239,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(trainer, task, tasks, ns, args)
 
+    # RCCL prints a version banner through C stdio, which is block-buffered when stdout is a pipe and would otherwise land AFTER
+    # the JSON line at process exit: flush every rank's C stdio, then rank 0 prints the line last.
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    if dist.is_initialized():
+        dist.barrier()
     if rank == 0:
         utt = world * args.batch * args.steps
         line = {
@@ -256,8 +262,8 @@ def main():
                        "parallelism": "dp%d" % world, "loss": float(out["loss"])},
             "roofline": roof, "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
-    if world > 1:
+        print(json.dumps(line), flush=True)
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -24,7 +24,7 @@ def distributed_init(backend=None):
         return dist.get_rank(), dist.get_world_size()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world == 1:
+    if world == 1 and os.environ.get("CST_DDP_FORCE") != "1":
         return 0, 1
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
@@ -57,6 +57,7 @@ class BucketedGradAllReduce:
         self.pg = process_group
         self.gather = gather  # callable(indices): copy those parameters' autograd-owned grads into the flat buffer
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("CST_DDP_FORCE") == "1")
         self.flat_grad = flat_grad
         self.params = list(params)
         cap = max(1, int(bucket_cap_mb * 1024 * 1024 / flat_grad.element_size()))
@@ -85,7 +86,7 @@ class BucketedGradAllReduce:
         self.reset()
 
     def _on_unused(self, params):
-        if not self.enabled or self.world == 1:
+        if not self.enabled or not self.active:
             return
         for p in params:
             idx = self._index.get(id(p))
@@ -105,7 +106,7 @@ class BucketedGradAllReduce:
 
     def _make_hook(self, idx):
         def hook(param):
-            if not self.enabled or self.world == 1:
+            if not self.enabled or not self.active:
                 return
             b = self.param_bucket[idx]
             self._pending[b] -= 1
@@ -130,7 +131,7 @@ class BucketedGradAllReduce:
 
     def finish(self):
         """Launch whatever has not been reduced yet (parameters without gradient stay zero) and wait for everything."""
-        if self.world > 1 and self.enabled:
+        if self.active and self.enabled:
             while self._next < len(self.buckets):
                 self._launch(self._next)
                 self._next += 1

@@ -3,6 +3,7 @@
 (world/sample_size, :601-606), clip (:615), optimizer step (:627), lr schedule — with the MI355X pieces swapped in:
 flat bf16 parameter/gradient buffers, bucketed RCCL all-reduce overlapped with backward, one fused Adam pass."""
 import contextlib
+import os
 import random
 
 import numpy as np
@@ -28,7 +29,9 @@ class Trainer:
         self.optimizer = FusedAdam.from_args(args, None, buffers=self.buffers)
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
-        self.model = DistributedFairseqModel(args, model, self.buffers) if self.world > 1 else model
+        # CST_DDP_FORCE=1 keeps the collective path on for a 1-rank group (a 1-GPU box can only form that RCCL communicator)
+        self.ddp = self.world > 1 or (dist.is_initialized() and os.environ.get("CST_DDP_FORCE") == "1")
+        self.model = DistributedFairseqModel(args, model, self.buffers) if self.ddp else model
         self._model = model
         self.num_updates = 0
         self.dtype = dtype
@@ -75,7 +78,7 @@ class Trainer:
                 self._dummy_batch = sample
             sample = self._prepare_sample(sample)
             last = i == len(samples) - 1
-            ctx = self.model.no_sync() if (self.world > 1 and not last) else contextlib.nullcontext()
+            ctx = self.model.no_sync() if (self.ddp and not last) else contextlib.nullcontext()
             with ctx:
                 loss, ss, log = self.task.train_step(sample, self.model, self.criterion, self.optimizer, self.num_updates,
                                                      ignore_grad=ignore)
@@ -83,7 +86,7 @@ class Trainer:
                 log, ss = {k: v * 0 for k, v in log.items()}, 0
             logs.append(log)
             sample_size += ss
-        if self.world > 1:
+        if self.ddp:
             self.model.all_reduce()  # waits for the overlapped bucket reductions; launches the stragglers
         else:
             self.buffers.gather_grads()  # one multi-tensor copy of every autograd-owned gradient into the flat buffer
@@ -91,7 +94,7 @@ class Trainer:
         # before the optimizer kernels are queued.
         keys = sorted(k for k in logs[0].keys())
         vec = torch.stack([sum(torch.as_tensor(l[k], dtype=torch.float64, device=self.device) for l in logs) for k in keys])
-        if self.world > 1:
+        if self.ddp:
             dist.all_reduce(vec)
         total_ss = vec[keys.index("sample_size")]
         gnorm = self.optimizer.step(multiply=(self.world / total_ss).float())

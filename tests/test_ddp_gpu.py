@@ -119,3 +119,44 @@ def test_empty_shard_batch_contributes_zero():
     assert out["sample_size"] == res[0][2] and out["loss"] == pytest.approx(res[0][1], rel=1e-5)
     assert out["gnorm"] == pytest.approx(res[0][3], rel=1e-4)
     np.testing.assert_allclose(res[0][4], tr.buffers.flat_param.detach().cpu().numpy(), rtol=1e-4, atol=2e-5)
+
+
+def _worker_rccl(port, q):
+    """The RCCL ("nccl") backend itself: a 1-GPU box can only form a 1-rank communicator, so CST_DDP_FORCE=1 keeps the bucketed,
+    hook-launched all-reduces, the fp64 stat all-reduce and the barrier on for it — real RCCL calls on their own stream, ordered
+    against this library's raw-HIP launches on torch's current stream."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", CST_DDP_FORCE="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    rank, world = import_module("chimera-st_amd.distributed").distributed_init()
+    assert (rank, world) == (0, 1) and dist.get_backend() == "nccl"
+    model, task, crit = _build()
+    Trainer = import_module("chimera-st_amd.trainer").Trainer
+    tr = Trainer(_targs(), task, model, crit, device="cuda")
+    assert tr.ddp and len(tr.model.reducer.buckets) >= 3
+    outs = [tr.train_step(_samples(task)) for _ in range(3)]
+    dist.barrier()
+    torch.cuda.synchronize()
+    q.put(([o["loss"] for o in outs], [o["gnorm"] for o in outs], tr.buffers.flat_param.detach().cpu().numpy()))
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_single_rank_collectives():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_rccl, args=(port, q))
+    p.start()
+    losses, gnorms, flat = q.get(timeout=600)
+    p.join(120)
+    assert p.exitcode == 0
+    model, task, crit = _build()
+    Trainer = import_module("chimera-st_amd.trainer").Trainer
+    tr = Trainer(_targs(), task, model, crit, device="cuda")
+    assert not tr.ddp
+    outs = [tr.train_step(_samples(task)) for _ in range(3)]
+    for o, l, g in zip(outs, losses, gnorms):
+        assert o["loss"] == pytest.approx(l, rel=1e-5) and o["gnorm"] == pytest.approx(g, rel=1e-4)
+    np.testing.assert_allclose(flat, tr.buffers.flat_param.detach().cpu().numpy(), rtol=1e-4, atol=4e-5)

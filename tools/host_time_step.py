@@ -8,6 +8,7 @@ import bench
 from argparse import Namespace
 args = Namespace(gpus=1, steps=8, warmup=2, batch=32, seconds=30.0, lengths="uniform", dtype="bf16", model="s2t_w2v2", dropout=0.1, layerdrop=0.0)
 dev = torch.device("cuda", 0)
+importlib.import_module("chimera-st_amd.distributed").distributed_init()  # RANK/WORLD_SIZE(+CST_DDP_FORCE=1): time the collective path
 trainer, task, tasks, ns = bench.build(args, dev)
 sample = bench.make_batch(tasks, task, args, 0, dev)
 for _ in range(3):
