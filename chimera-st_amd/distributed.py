@@ -78,6 +78,7 @@ class BucketedGradAllReduce:
             for idx in bk["members"]:
                 self.param_bucket[idx] = b
         self.enabled = True
+        self.last_early, self.last_missing = 0, []
         self._hooks = []
         self._index = {id(p): idx for idx, p in enumerate(self.params)}
         for idx, p in enumerate(self.params):
@@ -103,12 +104,14 @@ class BucketedGradAllReduce:
         self._next = 0
         self._works = []
         self._skipped = set()
+        self._fired = set()
 
     def _make_hook(self, idx):
         def hook(param):
             if not self.enabled or not self.active:
                 return
             b = self.param_bucket[idx]
+            self._fired.add(idx)
             self._pending[b] -= 1
             if self._pending[b] == 0:
                 self._ready[b] = True
@@ -132,6 +135,9 @@ class BucketedGradAllReduce:
     def finish(self):
         """Launch whatever has not been reduced yet (parameters without gradient stay zero) and wait for everything."""
         if self.active and self.enabled:
+            # overlap bookkeeping of the update that just ended: buckets launched from hooks, parameters nobody accounted for
+            self.last_early = self._next
+            self.last_missing = [i for i in range(len(self.params)) if i not in self._fired and i not in self._skipped]
             while self._next < len(self.buckets):
                 self._launch(self._next)
                 self._next += 1

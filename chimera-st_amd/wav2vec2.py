@@ -207,6 +207,13 @@ class Wav2Vec2Model(nn.Module):
 
     def forward(self, source, padding_mask=None, mask=True, features_only=False):
         assert features_only and not mask, "only the features_only / mask=False path is built (SURVEY §2.1 #2)"
+        if self.training:
+            # pre-training-only parameters never receive a gradient on this path: without this the gradient bucket that holds
+            # final_proj (the FIRST wav2vec2 bucket in backward order) would wait for finish() and un-overlap every later one
+            heads = [self.mask_emb] + list(self.final_proj.parameters())
+            if self.project_q is not None:
+                heads += list(self.project_q.parameters())
+            notify_unused_parameters(heads)
         feats = self.feature_extractor(source)  # [B, T1, C] channels-last
         if self.feature_grad_mult <= 0:
             feats = feats.detach()
