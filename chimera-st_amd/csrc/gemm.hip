@@ -706,6 +706,7 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
   }
   p.tiles_m = p.tiles_n = 0;  // set per configuration in launch()
   p.split_order = 0;
+  p.sched = nullptr;  // set by the persistent kernel's launcher
   {
     static const int gm = getenv("CST_GEMM8P_GROUP_M") ? atoi(getenv("CST_GEMM8P_GROUP_M")) : 8;
     p.group_m = gm > 0 ? gm : 8;

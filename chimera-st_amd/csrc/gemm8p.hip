@@ -23,7 +23,12 @@
 //   WAR: a region is restaged >= 2 phases after its last ds_read (B0: 1 phase, its reads are retired by lgkmcnt(8) before ph1's
 //   first barrier).  RAW: vmcnt(6) in ph4 (before its first barrier) retires everything but the 3 newest half-tiles, i.e. the
 //   whole next K tile, which is first read one phase later.
-// Persistent: the grid is one workgroup per CU; each walks work items (batch/split z, output tile) v = blockIdx.x + i * gridDim.x.
+// Persistent: the grid is one workgroup per CU.  A workgroup's first work item (batch/split z, output tile) is v = blockIdx.x; the
+//   following ones are CLAIMED from a per-XCD counter (v = gridDim.x + xcd + 8 * atomicAdd(&sched[xcd], 1)), one item ahead: the
+//   claim for the item after next is issued while the next item's first K tile streams in, and is read back after the next K
+//   loop.  The item order inside an XCD is the one a static stride would give, but a workgroup that starts late — its CU was
+//   held by another stream's kernel, e.g. an RCCL all-reduce overlapped with backward — simply takes fewer items instead of
+//   doubling the launch time.  The last workgroup to leave zeroes the counters (sched == nullptr: static stride).
 //   After an item's K loop the first K tile of the NEXT item is already streaming into buffer 0 while the epilogue runs out of
 //   the buffer-1 region, and the epilogue's global stores drain under the next item's MFMAs.
 // Epilogue: MFMA operands are swapped (D = B-frag x A-frag), so a lane holds 4 CONSECUTIVE output columns of one row per
@@ -31,6 +36,9 @@
 //   into a [128][256] bf16 image (2 passes) -> row-contiguous 16-byte read-back, activation / act' / residual on the way out.
 //   fp32 outputs and split-K slabs: fp32 image, 64 rows per pass.
 #include "gemm_common.h"
+#include <atomic>
+#include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 namespace {
@@ -287,6 +295,30 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
 
   int v = blockIdx.x;
   if (v >= total) return;
+  // dynamic item claims (see the header).  Nothing of this is kept in registers across a K loop: the state pointer is re-read
+  // from the kernarg segment at each use (nullptr = static stride; the launcher passes it only for multi-round launches on a
+  // grid that is a multiple of 8), the XCD index is recomputed from blockIdx.
+  const unsigned slot_off = lds_off(smem + 2 * BUFB + 1024);  // two 4-byte slots behind the bias row's DMA footprint, alternating per item
+  int par = 0;
+  // claim_issue: thread 0 fires the counter increment right after the next item's first-K-tile DMA; claim_land publishes the
+  // claimed item through LDS just before the epilogue's first global access, i.e. after the accumulator image has been written
+  // (LDS only) — the compiler's wait for the returned value there also covers the DMA issued before it, which have had the same
+  // time to land.  The value is live only between those two points (never across a K loop, where no VGPR is free).  (A
+  // hand-written atomic with a counted vmcnt was tried first: the register allocator spills the asm's output before it has
+  // arrived.)
+  int claim = 0;
+  auto claim_issue = [&]() {
+    int* const sched = p.sched;
+    if (sched && tid == 0) claim = __hip_atomic_fetch_add(sched + (blockIdx.x & 7), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto claim_land = [&]() {
+    // slot `par ^ 1` was last read one item ago (barriers in between); the LDS store is inline asm for the reason given above
+    if (p.sched && tid == 0) {
+      const int item = (int)gridDim.x + (int)(blockIdx.x & 7) + 8 * claim;
+      asm volatile("ds_write_b32 %0, %1" ::"v"(slot_off + 4u * (unsigned)(par ^ 1)), "v"(item) : "memory");
+    }
+    par ^= 1;
+  };
   setup(v);
   {
     const int S = 4 * nt;
@@ -295,6 +327,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
     if (2 < S) stage(I2{}, I0{}, 0);
     if (3 < S) stage(I3{}, I0{}, 0);
   }
+  claim_issue();
+  claim_land();
 #ifdef CST_TRACE
   long long* trace = (p.splits == 1 && p.ws) ? reinterpret_cast<long long*>(p.ws) + (int64_t)blockIdx.x * 64 : nullptr;
   int titem = 0;
@@ -346,7 +380,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
     CST_STAMP(2);
 
     // ---- start streaming the next item before this one's epilogue ----
-    v += gridDim.x;
+    {
+      int item;
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(item) : "v"(slot_off + 4u * (unsigned)par) : "memory");
+      v = __builtin_amdgcn_readfirstlane(p.sched ? item : v + (int)gridDim.x);
+    }
     const bool has_next = v < total;
     if (has_next) {
       setup(v);
@@ -355,6 +393,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
       if (1 < Sn) stage(I1{}, I0{}, 0);
       if (2 < Sn) stage(I2{}, I0{}, 0);
       if (3 < Sn) stage(I3{}, I0{}, 0);
+      claim_issue();  // the item after the one set up here; published in the epilogue, read back after that item's K loop
     }
 
     CST_STAMP(3);
@@ -391,6 +430,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
             }
         wait_lgkm<0>();
         __builtin_amdgcn_s_barrier();
+        if (hm == 0 && has_next) claim_land();
         if (exsrc) {
 #pragma unroll 2
           for (int it = 0; it < 8; ++it) {
@@ -506,6 +546,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
         }
         wait_lgkm<0>();
         __builtin_amdgcn_s_barrier();
+        if (ps == 0 && has_next) claim_land();
 #pragma unroll 2
         for (int itv = 0; itv < ITERS; ++itv) {
           const int vi = tid + NTHREADS * itv;
@@ -540,6 +581,38 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
     if (!has_next) break;
     __builtin_amdgcn_s_barrier();  // the image is fully read back: buffer 1 may receive the next item's second K tile
   }
+  int* const sched_exit = p.sched;
+  if (int* const sched = sched_exit; sched && tid == 0) {
+    // every workgroup passes here once, after its last (failed) claim: the last one re-arms the state for the next launch
+    if (atomicAdd(sched + 8, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) __hip_atomic_store(sched + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// Scheduling state of the dynamic item claims: a ring of 64-byte slots per device, zeroed once; a launch takes the next slot,
+// so launches in flight on different streams never share counters (each launch leaves its slot zeroed).
+int* sched_slot() {
+  constexpr int SLOTS = 1024, MAXDEV = 64;
+  static int* ring[MAXDEV] = {};
+  static std::atomic<unsigned> next[MAXDEV];
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
+  int* r = __atomic_load_n(&ring[dev], __ATOMIC_ACQUIRE);
+  if (!r) {
+    std::lock_guard<std::mutex> g(mu);
+    r = ring[dev];
+    if (!r) {
+      void* q = nullptr;
+      if (hipMalloc(&q, SLOTS * 64) != hipSuccess) return nullptr;
+      if (hipMemset(q, 0, SLOTS * 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
+      r = (int*)q;
+      __atomic_store_n(&ring[dev], r, __ATOMIC_RELEASE);
+    }
+  }
+  return r + 16 * (next[dev].fetch_add(1, std::memory_order_relaxed) % SLOTS);
 }
 
 template <bool AK, bool BKM>
@@ -560,7 +633,12 @@ int launch8p(GemmParams p, int64_t nbatch, hipStream_t s) {
     return n > 0 ? n : 256;
   }();
   dim3 grid((unsigned)(total < ncu ? total : ncu), 1, 1);
-  hipLaunchKernelGGL((gemm8p_kernel<AK, BKM>), grid, dim3(NTHREADS), LDS_BYTES + 1024, s, p);
+  static const bool static_walk = getenv("CST_GEMM8P_STATIC") != nullptr;
+  // (not under stream capture: a captured launch would pin one slot of the ring for every replay of the graph)
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+  p.sched = (!static_walk && !capturing && total > ncu && grid.x % 8 == 0) ? sched_slot() : nullptr;
+  hipLaunchKernelGGL((gemm8p_kernel<AK, BKM>), grid, dim3(NTHREADS), LDS_BYTES + 1024 + 64, s, p);
   return cst_check_launch("cst_gemm (8-phase)");
 }
 

@@ -483,6 +483,42 @@ def test_gemm_8phase_large(K, ak, bk, M, N, K_):
     check(C, ref, dt, "8-phase gemm %d%d %dx%dx%d" % (ak, bk, M, N, K_))
 
 
+@pytest.mark.parametrize("ak,bk", [(1, 1), (1, 0), (0, 0)])
+def test_gemm_8phase_claimed_items(K, ak, bk):
+    """More work items than workgroups: every item after a workgroup's first is claimed from the per-XCD counters (gemm8p.hip).
+    Each item must be computed exactly once (ragged 20 x 17 tile grid, also with split-K slabs), repeated launches re-arm their
+    own state (bit-identical results), and launches in flight on two streams do not share counters."""
+    k, L = K
+    dt = torch.bfloat16
+    M, N, K_ = 5000, 4104, 200
+    A = rnd(M, K_, dt=dt, seed=1) if ak else rnd(K_, M, dt=dt, seed=1)
+    B = rnd(N, K_, dt=dt, seed=2) if bk else rnd(K_, N, dt=dt, seed=2)
+    Af = A.float() if ak else A.float().t()
+    Bf = B.float() if bk else B.float().t()
+    ref = Af @ Bf.t()
+    outs = []
+    for _ in range(3):
+        C = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
+        k.gemm(A, B, C, M, N, K_, a_kmajor=ak, b_kmajor=bk, lda=A.shape[1], ldb=B.shape[1], ldc=N)
+        check(C, ref, dt, "claimed items %d%d" % (ak, bk))
+        outs.append(C)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    Cs = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
+    k.gemm(A, B, Cs, M, N, K_, a_kmajor=ak, b_kmajor=bk, lda=A.shape[1], ldb=B.shape[1], ldc=N, split_k=2)
+    check(Cs, ref, dt, "claimed items, split-K")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    C1 = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
+    C2 = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(4):
+        with torch.cuda.stream(s1):
+            k.gemm(A, B, C1, M, N, K_, a_kmajor=ak, b_kmajor=bk, lda=A.shape[1], ldb=B.shape[1], ldc=N)
+        with torch.cuda.stream(s2):
+            k.gemm(A, B, C2, M, N, K_, a_kmajor=ak, b_kmajor=bk, lda=A.shape[1], ldb=B.shape[1], ldc=N)
+    torch.cuda.synchronize()
+    assert torch.equal(C1, outs[0]) and torch.equal(C2, outs[0])
+
+
 # --------------------------------------------------------------------------------------------
 # dropout: the kernels' counter-based masks against the numpy statement of the same function (chimera-st_amd/rng.py)
 # --------------------------------------------------------------------------------------------
