@@ -12,7 +12,10 @@
  *     owned by the caller; the library never frees or retains a pointer past return.
  *   - errors: int return, 0 = ok, negative = cst_status; text via cst_last_error() (thread-local).
  *     Nothing throws across the boundary.
- *   - threading: re-entrant; no global mutable state except the optional profiling table.
+ *   - threading: re-entrant; no global mutable state except the optional profiling table and, per
+ *     device, one 64 KiB device allocation made on the first large cst_gemm launch: the ring of
+ *     work-item counters of the persistent GEMM (csrc/gemm8p.hip; each launch uses one 64-byte
+ *     slot and leaves it zeroed).  It is the only memory the library owns.
  *   - all kernels are asynchronous on the given stream.
  *   - accumulation is always fp32; `dtype` is the storage type of activations/weights.
  */
