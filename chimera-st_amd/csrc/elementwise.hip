@@ -70,7 +70,7 @@ __global__ void act_fwd_kernel(const T* x, T* y, int64_t n8, int act) {
 // block = 256 threads = 16 row-lanes x 16 column vectors (128 columns): each half-wave reads a 256-B row segment, 4 row
 // loads in flight per thread; LDS combine over the 16 row-lanes; one fp32 atomic per column per block (<= ~200 blocks per
 // column, so the atomics are not the bottleneck).
-template <typename T>
+template <typename T, bool PART = false>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* x, int64_t ldx, float* out, int64_t rows, int64_t cols, int64_t rows_per) {
   __shared__ float red[16][16 * 8 + 1];
   const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
@@ -106,7 +106,28 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* x, int64_t ldx, fl
 #pragma unroll
     for (int k = 0; k < 16; ++k) a += red[k][c];
     const int64_t col = (int64_t)blockIdx.x * 128 + c;
-    if (col < cols) atomicAdd(out + col, a);
+    if (col < cols) {
+      if (PART) out[(int64_t)blockIdx.y * cols + col] = a;  // row-chunk partial, reduced in fixed order by colsum_reduce_kernel
+      else atomicAdd(out + col, a);
+    }
+  }
+}
+
+// out[c] = sum over the row chunks of part[chunk][c], written in the gradient's dtype (fixed summation order: deterministic)
+template <typename TO>
+__global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* part, TO* out, int chunks, int64_t cols) {
+  __shared__ float red[64][17];
+  const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int64_t c = (int64_t)blockIdx.x * 16 + cl;
+  float a = 0.0f;
+  if (c < cols)
+    for (int i = g; i < chunks; i += 64) a += part[(int64_t)i * cols + c];
+  red[g][cl] = a;
+  __syncthreads();
+  if (g == 0 && c < cols) {
+#pragma unroll 8
+    for (int k = 1; k < 64; ++k) a += red[k][cl];
+    DT<TO>::st(out + c, a);
   }
 }
 
@@ -229,6 +250,40 @@ extern "C" int cst_colsum(const void* x, int64_t ldx, float* out, int64_t rows, 
   if (dtype == CST_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ldx, out, rows, cols, rows_per);
   else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ldx, out, rows, cols, rows_per);
   return cst_check_launch("cst_colsum");
+}
+
+static void colsum_grid(int64_t rows, int64_t cols, int64_t& cblocks, int64_t& nchunks, int64_t& rows_per) {
+  cblocks = cst_ceil_div(cols / 8, 16);
+  int64_t chunks = cst_ceil_div(1536, cblocks);  // ~1536 workgroups in total
+  if (chunks > cst_ceil_div(rows, 64)) chunks = cst_ceil_div(rows, 64);
+  if (chunks < 1) chunks = 1;
+  rows_per = cst_ceil_div(rows, chunks);
+  nchunks = cst_ceil_div(rows, rows_per);
+}
+
+extern "C" int64_t cst_colsum_workspace(int64_t rows, int64_t cols) {
+  if (rows <= 0 || cols <= 0) return 0;
+  int64_t cb, nc, rp;
+  colsum_grid(rows, cols, cb, nc, rp);
+  return nc * cols * (int64_t)sizeof(float);
+}
+
+extern "C" int cst_colsum_typed(const void* x, int64_t ldx, void* out, void* workspace, int64_t rows, int64_t cols, int dtype,
+                                int out_dtype, cst_stream stream) {
+  CST_REQUIRE(x && out && workspace && rows > 0 && cols > 0 && cols % 8 == 0 && ldx % 8 == 0, "cst_colsum_typed: cols/ldx must be multiples of 8");
+  CST_REQUIRE((dtype == CST_F32 || dtype == CST_BF16) && (out_dtype == CST_F32 || out_dtype == CST_BF16), "cst_colsum_typed: bad dtype");
+  hipStream_t s = (hipStream_t)stream;
+  CstProfScope prof(CST_K_ELEMENTWISE, s, 0.0, (double)rows * cols * cst_dtype_size(dtype));
+  int64_t cblocks, nchunks, rows_per;
+  colsum_grid(rows, cols, cblocks, nchunks, rows_per);
+  dim3 grid((unsigned)cblocks, (unsigned)nchunks);
+  float* part = (float*)workspace;
+  if (dtype == CST_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)x, ldx, part, rows, cols, rows_per);
+  else hipLaunchKernelGGL((colsum_kernel<float, true>), grid, dim3(256), 0, s, (const float*)x, ldx, part, rows, cols, rows_per);
+  const dim3 rgrid((unsigned)cst_ceil_div(cols, 16));
+  if (out_dtype == CST_BF16) hipLaunchKernelGGL(colsum_reduce_kernel<bf16_t>, rgrid, dim3(1024), 0, s, (const float*)part, (bf16_t*)out, (int)nchunks, cols);
+  else hipLaunchKernelGGL(colsum_reduce_kernel<float>, rgrid, dim3(1024), 0, s, (const float*)part, (float*)out, (int)nchunks, cols);
+  return cst_check_launch("cst_colsum_typed");
 }
 
 extern "C" int cst_col2im1d(const void* dcol, const void* z, void* dx, int64_t B, int64_t Lin, int64_t Lout, int64_t C, int k,

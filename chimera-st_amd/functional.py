@@ -177,9 +177,9 @@ class _LayerNormFn(torch.autograd.Function):
             return ds, (ds if ctx.has_res else None), None, None, None
         dy2 = _flat2d(dy)
         dres = _flat2d(ds) if ds is not None else None
-        dx, dg, db = K.layernorm_bwd(dy2, src, gamma, mean, rstd, dres)
+        dx, dg, db = K.layernorm_bwd(dy2, src, gamma, mean, rstd, dres, grad_dtype=gamma.dtype)
         dx = dx.view(ctx.shape)
-        return dx, (dx if ctx.has_res else None), dg.to(gamma.dtype), db.to(gamma.dtype), None
+        return dx, (dx if ctx.has_res else None), dg, db, None
 
 
 def layer_norm(x, gamma, beta, eps=1e-5):

@@ -252,15 +252,27 @@ def act_fwd(x, act):
 
 
 def colsum(x, out_dtype=torch.float32):
-    """Column sums (fp32 accumulation by atomics onto a zeroed vector), returned in `out_dtype`.
-    (A deterministic two-stage variant — fp32 partials + last-arriving-block finalize writing the parameter dtype, no memset /
-    conversion launches — was measured: the agent-scope release every workgroup needs before its ticket costs more than the two
-    small launches it removes: elementwise 4.4 -> 7.4 ms per update.  Not kept.)"""
+    """Column sums (bias gradients) in `out_dtype`: row-chunk fp32 partials + a fixed-order reduce that writes the parameter
+    dtype (cst_colsum_typed) — deterministic, and two launches where the atomics version needs three (zero-fill, kernel, dtype
+    conversion).  (A single-launch variant with a last-arriving-block finalize was measured earlier: the agent-scope release
+    every workgroup needs before its ticket made it slower, elementwise 4.4 -> 7.4 ms per update.)"""
+    x = _2d(x)
+    rows, cols = x.shape
+    lib = L.load()
+    out = torch.empty(cols, dtype=out_dtype, device=x.device)
+    ws = workspace(lib.cst_colsum_workspace(rows, cols), x.device)
+    L.check(lib.cst_colsum_typed(L.ptr(x), x.stride(0), L.ptr(out), L.ptr(ws), rows, cols, L.dtype_code(x.dtype), L.dtype_code(out_dtype),
+                                 L.stream_ptr()), "cst_colsum_typed")
+    return out
+
+
+def colsum_atomic(x):
+    """cst_colsum: the atomics version (fp32 output), kept in the ABI."""
     x = _2d(x)
     rows, cols = x.shape
     out = torch.empty(cols, dtype=torch.float32, device=x.device)
     L.check(L.load().cst_colsum(L.ptr(x), x.stride(0), L.ptr(out), rows, cols, L.dtype_code(x.dtype), L.stream_ptr()), "cst_colsum")
-    return out if out_dtype == torch.float32 else out.to(out_dtype)
+    return out
 
 
 def col2im1d(dcol, z, B, Lin, Lout, C, k, stride, pad, dact):

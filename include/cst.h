@@ -206,6 +206,11 @@ int cst_act_bwd(const void* dy, const void* z, void* dx, int64_t n, int act, int
 int cst_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, cst_stream stream);
 /* out[c] = sum_r x[r, c]  (bias gradients); out fp32 [cols], overwritten */
 int cst_colsum(const void* x, int64_t ldx, float* out, int64_t rows, int64_t cols, int dtype, cst_stream stream);
+/* the same sums without atomics: row-chunk partials in `workspace` (cst_colsum_workspace bytes), reduced in a fixed order and
+ * written in `out_dtype` (the bias parameter's dtype) — deterministic, no zero-fill and no conversion launch around it */
+int64_t cst_colsum_workspace(int64_t rows, int64_t cols);
+int cst_colsum_typed(const void* x, int64_t ldx, void* out, void* workspace, int64_t rows, int64_t cols, int dtype, int out_dtype,
+                     cst_stream stream);
 /* gradient of a strided conv1d input from the column-gradient rows of the implicit GEMM:
  * dx[b, l, c] = sum_{t,j : t*stride + j = l} dcol[b, t, j*C + c];  optionally multiplied by
  * act'(z[b,l,c]) (GELU of the previous conv layer).  dcol [B, Lout, k*C]; dx/z [B, Lin, C]. */

@@ -358,6 +358,8 @@ def test_elementwise(K, dt):
         a = k.colsum(big, dt)
         assert a.dtype == dt
         check(a, ref, dt, "colsum %dx%d" % (rows, cols), scale=float(ref.abs().max()))
+        assert torch.equal(a, k.colsum(big, dt))  # fixed-order partials + reduce: bit-reproducible
+        check(k.colsum_atomic(big), ref, torch.float32, "colsum (atomics) %dx%d" % (rows, cols), scale=float(ref.abs().max()) * (1 if dt == torch.float32 else 4))
     m = (torch.arange(1234) % 3 == 0).to(torch.uint8).cuda()
     check(k.mask_rows(x, m), x.float() * (1 - m.float())[:, None], dt, "mask_rows")
 
