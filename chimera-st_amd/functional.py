@@ -59,31 +59,61 @@ class _LinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w, z = ctx.saved_tensors
-        M, Kd = x2.shape
-        Np, N = w.shape[0], ctx.N
-        dy2 = _flat2d(dy)
-        if Np != N:
-            dyp = torch.zeros(M, Np, dtype=dy2.dtype, device=dy2.device)
-            dyp[:, :N] = dy2
-            dy2 = dyp
-        if ctx.drop[0] > 0.0:  # gradient of the dropped branch: the same mask, regenerated
-            dy2 = K.dropout(dy2 if dy2.is_contiguous() else dy2.contiguous(), *ctx.drop)
-        dz = K.act_bwd(dy2, z, ctx.act) if ctx.act != L.ACT_NONE else dy2
-        dx = dw = db = dres = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty(M, Kd, dtype=x2.dtype, device=x2.device)
-            K.gemm(dz, w, dx, M, Kd, Np, a_kmajor=1, b_kmajor=0, lda=Np, ldb=Kd, ldc=Kd, split_k=1)
-            dx = dx.view(ctx.xshape)
-        if ctx.needs_input_grad[1]:
-            dw = torch.empty(Np, Kd, dtype=w.dtype, device=w.device)
-            K.gemm(dz, x2, dw, Np, Kd, M, a_kmajor=0, b_kmajor=0, lda=Np, ldb=Kd, ldc=Kd, split_k=-1)
-            dw = dw[:N]
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = K.colsum(dz, w.dtype)[:N]
-        if ctx.has_resid and ctx.needs_input_grad[3]:
-            dres = dy
-        return dx, dw, db, dres, None, None, None
+        return _linear_backward(ctx, dy, None)
+
+
+def _linear_backward(ctx, dy, dxp):
+    """Shared by _LinearFn / _LinearPassFn.  dxp: gradient that reached the pass-through alias of x (the residual branch of the
+    block this projection opens); it is added in the dX GEMM's epilogue instead of by an autograd accumulation kernel."""
+    x2, w, z = ctx.saved_tensors
+    M, Kd = x2.shape
+    Np, N = w.shape[0], ctx.N
+    if dy is None:  # only the pass-through was consumed
+        return dxp, None, None, None, None, None, None
+    dy2 = _flat2d(dy)
+    if Np != N:
+        dyp = torch.zeros(M, Np, dtype=dy2.dtype, device=dy2.device)
+        dyp[:, :N] = dy2
+        dy2 = dyp
+    if ctx.drop[0] > 0.0:  # gradient of the dropped branch: the same mask, regenerated
+        dy2 = K.dropout(dy2 if dy2.is_contiguous() else dy2.contiguous(), *ctx.drop)
+    dz = K.act_bwd(dy2, z, ctx.act) if ctx.act != L.ACT_NONE else dy2
+    dx = dw = db = dres = None
+    if ctx.needs_input_grad[0]:
+        dx = torch.empty(M, Kd, dtype=x2.dtype, device=x2.device)
+        K.gemm(dz, w, dx, M, Kd, Np, a_kmajor=1, b_kmajor=0, lda=Np, ldb=Kd, ldc=Kd, split_k=1,
+               resid=_flat2d(dxp) if dxp is not None else None, ld_resid=Kd)
+        dx = dx.view(ctx.xshape)
+    if ctx.needs_input_grad[1]:
+        dw = torch.empty(Np, Kd, dtype=w.dtype, device=w.device)
+        K.gemm(dz, x2, dw, Np, Kd, M, a_kmajor=0, b_kmajor=0, lda=Np, ldb=Kd, ldc=Kd, split_k=-1)
+        dw = dw[:N]
+    if ctx.has_bias and ctx.needs_input_grad[2]:
+        db = K.colsum(dz, w.dtype)[:N]
+    if ctx.has_resid and ctx.needs_input_grad[3]:
+        dres = dy
+    return dx, dw, db, dres, None, None, None
+
+
+class _LinearPassFn(torch.autograd.Function):
+    """(y, x') = (linear(x), alias of x).  A post-norm block takes x' as its residual: the residual-branch gradient and the
+    projection's dX then arrive in ONE backward call and are summed in the dX GEMM's epilogue (same idea as _LayerNormPassFn)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, drop_p, drop_key):
+        y = _LinearFn.forward(ctx, x, weight, bias, None, act, drop_p, drop_key)
+        ctx.set_materialize_grads(False)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dxp):
+        g = _linear_backward(ctx, dy, dxp)
+        return g[0], g[1], g[2], None, None, None
+
+
+def linear_pass(x, weight, bias=None, act=None, dropout_p=0.0):
+    """Returns (linear(x), x') where x' aliases x and must be used for the enclosing block's residual connection."""
+    return _LinearPassFn.apply(x, weight, bias, _ACT[act], *_drop_args(dropout_p))
 
 
 def linear(x, weight, bias=None, act=None, resid=None, dropout_p=0.0):
@@ -112,6 +142,9 @@ class _FFNFn(torch.autograd.Function):
                drop_p=p_out, drop_key=key_out)
         ctx.save_for_backward(x2, w1, w2, z1, h)
         ctx.cfg = (act, b1 is not None, b2 is not None, resid is not None, x.shape)
+        # post-norm block: the residual IS the block input -> its gradient (dy) is added in the dX GEMM's epilogue
+        ctx.res_is_x = (resid is not None and resid.data_ptr() == x.data_ptr() and resid.shape == x.shape
+                        and resid.stride() == x.stride() and dout == d)
         ctx.drop = (p_act, key_act, p_out, key_out)
         return y.view(*x.shape[:-1], dout)
 
@@ -136,14 +169,16 @@ class _FFNFn(torch.autograd.Function):
             db2 = K.colsum(dy2, w2.dtype)
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, d, dtype=x2.dtype, device=x2.device)
-            K.gemm(dz1, w1, dx, M, d, F_, a_kmajor=1, b_kmajor=0, lda=F_, ldb=d, ldc=d, split_k=1)
+            K.gemm(dz1, w1, dx, M, d, F_, a_kmajor=1, b_kmajor=0, lda=F_, ldb=d, ldc=d, split_k=1,
+                   resid=_flat2d(dy) if ctx.res_is_x else None, ld_resid=d)
             dx = dx.view(xshape)
         if ctx.needs_input_grad[1]:
             dw1 = torch.empty(F_, d, dtype=w1.dtype, device=w1.device)
             K.gemm(dz1, x2, dw1, F_, d, M, a_kmajor=0, b_kmajor=0, lda=F_, ldb=d, ldc=d, split_k=-1)
         if has_b1 and ctx.needs_input_grad[2]:
             db1 = K.colsum(dz1, w1.dtype)
-        return dx, dw1, db1, dw2, db2, (dy if has_res and ctx.needs_input_grad[5] else None), None, None, None, None, None
+        dres = dy if has_res and ctx.needs_input_grad[5] and not (ctx.res_is_x and ctx.needs_input_grad[0]) else None
+        return dx, dw1, db1, dw2, db2, dres, None, None, None, None, None
 
 
 def ffn(x, w1, b1, w2, b2, act, resid=None, activation_dropout_p=0.0, dropout_p=0.0):

@@ -276,11 +276,15 @@ class MultiheadAttention(FairseqIncrementalState, nn.Module):
             w = torch.cat((self.q_proj.weight, self.k_proj.weight, self.v_proj.weight), 0)
             bqkv = (torch.cat((self.q_proj.bias, self.k_proj.bias, self.v_proj.bias), 0)
                     if self.q_proj.bias is not None else None)
-            qkv = CF.linear(qb, w, bqkv)
+            resid_b = to_batch_major(resid) if resid is not None else None
+            if resid is query and torch.is_grad_enabled() and qb.requires_grad:
+                qkv, resid_b = CF.linear_pass(qb, w, bqkv)  # post-norm block: residual gradient joins the packed dX GEMM
+            else:
+                qkv = CF.linear(qb, w, bqkv)
             if key_padding_mask is not None and key_padding_mask.dim() == 0:
                 key_padding_mask = None
             attn = CF.attention_packed(qkv, self.num_heads, key_padding_mask, causal, self.scaling, dropout_p=attn_p)
-            out = self.out_proj(attn, resid=to_batch_major(resid) if resid is not None else None, dropout_p=out_dropout_p)
+            out = self.out_proj(attn, resid=resid_b, dropout_p=out_dropout_p)
             return to_time_major_view(out), None
         q = self.q_proj(qb)
         k = v = None
