@@ -1,0 +1,48 @@
+"""bench.py's output contract (the driver parses it): ONE JSON line on stdout, last, with the metric / roofline / cpu_baseline
+objects.  Run on a reduced workload so the test takes seconds; the numbers themselves are not asserted."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "4", "--seconds", "3",
+                        "--cpu-seconds", "1"] + extra, capture_output=True, text=True, timeout=900, env=e, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.strip()]
+    assert lines and lines[-1].startswith("{"), "the JSON line must be the last line on stdout: %r" % lines[-3:]
+    assert sum(1 for l in lines if l.startswith("{")) == 1
+    return json.loads(lines[-1])
+
+
+def test_bench_line_contract():
+    d = _run([])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["unit"] == "utterances/s" and d["value"] > 0 and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert abs(d["value"] - 4 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("mfma", "hbm") and r["peak"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "traffic" in r
+    assert r["unit"] in ("TFLOP/s", "GB/s") and r["launches"] > 0 and r["avg_launch_ms"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == "utterances/s" and c["sample"]
+
+
+def test_bench_under_a_process_group():
+    """The N > 1 launch path on the one configuration a 1-GPU box offers: a 1-rank RCCL group with the collective path forced on
+    (RANK / WORLD_SIZE / MASTER_* from the environment, as torch.distributed.run sets them)."""
+    d = _run(["--no-cpu-baseline", "--no-roofline"], env=dict(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                                                                MASTER_PORT="29541", CST_DDP_FORCE="1"))
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
