@@ -1,6 +1,9 @@
+#!/usr/bin/env python3
+"""Which gradient buckets are launched from backward hooks (overlapped) and which parameters nobody accounted for, per update,
+for the two bench models on a 1-rank RCCL group with the collective path forced on (CST_DDP_FORCE=1)."""
 import os, sys, importlib, torch
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", CST_DDP_FORCE="1")
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(sys.path[0], "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from argparse import Namespace
 importlib.import_module("chimera-st_amd.distributed").distributed_init()
