@@ -220,17 +220,65 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  if (kt0 < kt1) {
-    load_any(kt0);
+  // ---- live K tiles (p.k_live: the weight-gradient GEMMs reduce over tokens, and dY is exactly zero at padded frames): wave 0
+  //      compacts the indices of the live tiles into LDS; the K loop walks that list and the staging pointers jump over the dead
+  //      tiles (each would have added 0 * b to every accumulator).  With split-K the LIVE tiles — not the K range — are dealt out
+  //      evenly: batches are sorted by length, so equal K ranges would leave the first split (the longest utterances) with
+  //      nearly all of its tiles and the launch no faster.  (The fp32 summation order across splits therefore differs from the
+  //      unstamped launch; with one split the result is bit-identical to it.) ----
+  constexpr int KLIST_MAX = 512;
+  __shared__ int klist[KLIST_MAX];
+  __shared__ int klist_n;
+  const bool kskip = !SEG && BK == 64 && p.k_live != nullptr && per <= KLIST_MAX;
+  int nk = kt1 > kt0 ? kt1 - kt0 : 0;
+  if (kskip) {
+    if (wave == 0) {
+      int total = 0;
+      for (int base = 0; base < ktiles; base += 64) {
+        const int kt = base + lane;
+        total += __builtin_popcountll(__builtin_amdgcn_ballot_w64(kt < ktiles && p.k_live[kt] == p.k_epoch));
+      }
+      const int lo = (int)(((int64_t)total * split) / p.splits), hi = (int)(((int64_t)total * (split + 1)) / p.splits);
+      int seen = 0, n = 0;
+      for (int base = 0; base < ktiles && seen < hi; base += 64) {
+        const int kt = base + lane;
+        const bool live = kt < ktiles && p.k_live[kt] == p.k_epoch;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(live);
+        const int idx = seen + __builtin_popcountll(m & ((1ull << lane) - 1ull));  // rank of this lane's tile among the live ones
+        if (live && idx >= lo && idx < hi) klist[idx - lo] = kt;
+        seen += __builtin_popcountll(m);
+      }
+      n = hi - lo;  // <= ceil(total / splits) <= per <= KLIST_MAX
+      if (lane == 0) klist_n = n;
+    }
+    __syncthreads();
+    nk = klist_n;
+  }
+  int pos = kt0;  // the K tile the staging pointers stand at
+  auto fetch = [&](int kt) {
+    const int d = kt - pos;
+    if (d) {
+#pragma unroll
+      for (int i = 0; i < NVA; ++i) { pa[i] += (int64_t)d * step_a; ka[i] += d * BK; }
+#pragma unroll
+      for (int i = 0; i < NVB; ++i) { pb[i] += (int64_t)d * step_b; kb[i] += d * BK; }
+    }
+    load_any(kt);
+    pos = kt + 1;
+  };
+  auto tile_at = [&](int it) { return kskip ? klist[it] : kt0 + it; };
+
+  if (nk > 0) {
+    fetch(tile_at(0));
     store_tile(0);
   }
   __syncthreads();
   int cur = 0;
   const int lrow = lane & 31, lk = 8 * (lane >> 5);
   constexpr int WROWS = TM * 32, WCOLS = TN * 32;
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const bool more = kt + 1 < kt1;
-    if (more) load_any(kt + 1);
+  for (int it = 0; it < nk; ++it) {
+    const bool more = it + 1 < nk;
+    if (more) fetch(tile_at(it + 1));
     const T* sa = smem + cur * STAGE;
     const T* sb = sa + A_ELEMS;
 #pragma unroll
@@ -579,7 +627,7 @@ int launch(GemmParams p, int64_t M, int64_t N, int64_t nbatch, hipStream_t s) {
   if (lds < stage_bytes) lds = stage_bytes;
   static bool attr_set = false;  // LDS > 64 KiB needs the opt-in attribute (160 KiB/CU on gfx950)
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, AK, BK_, SEG, C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, AK, BK_, SEG, C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);  // the kernel also has 2 KiB of static LDS (live K-tile list)
     attr_set = true;
   }
   p.tiles_m = (int)cst_ceil_div(M, C::BM);
@@ -707,6 +755,11 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
   p.tiles_m = p.tiles_n = 0;  // set per configuration in launch()
   p.split_order = 0;
   p.sched = nullptr;  // set by the persistent kernel's launcher
+  {
+    static const bool no_klive = getenv("CST_GEMM_NO_KLIVE") != nullptr;  // A/B switch: visit the all-zero K blocks too
+    p.k_live = no_klive ? nullptr : d->k_live;
+    p.k_epoch = d->k_epoch;
+  }
   {
     static const int gm = getenv("CST_GEMM8P_GROUP_M") ? atoi(getenv("CST_GEMM8P_GROUP_M")) : 8;
     p.group_m = gm > 0 ? gm : 8;

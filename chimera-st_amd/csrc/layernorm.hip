@@ -65,7 +65,7 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(const T* x, const
 template <typename T>
 __global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(const T* dy, const T* s, const T* gamma, const float* mean,
                                                               const float* rstd, const T* dres, T* dx, float* part,
-                                                              int64_t rows, int cols) {
+                                                              int64_t rows, int cols, uint32_t* tile_live, uint32_t epoch) {
   __shared__ float red[LN_WAVES][64 * 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = cols / 8;
@@ -100,6 +100,7 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(const T* dy, cons
     }
     s1 = wave_sum(s1) / (float)cols;
     s2 = wave_sum(s2) / (float)cols;
+    bool nz = false;
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
       const int vi = lane + 64 * i;
@@ -113,9 +114,14 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(const T* dy, cons
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] += r[e];
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) nz |= (o[e] != 0.0f);
         store8(dx + row * cols + vi * 8, o);
       }
     }
+    // a row with any non-zero dx marks its 64-row tile live (same value from every writer: a benign race); rows that are exactly
+    // zero in fp32 are exactly zero as stored, so an unstamped tile may be skipped by the GEMMs that reduce over rows
+    if (tile_live && __builtin_amdgcn_ballot_w64(nz) != 0 && lane == 0) tile_live[row >> 6] = epoch;
   }
   // block reduction of the per-wave partials, one vector slot at a time
   float* pg = part + (int64_t)blockIdx.x * 2 * cols;
@@ -192,9 +198,9 @@ extern "C" int64_t cst_layernorm_bwd_workspace(int64_t rows, int64_t cols) {
   return (int64_t)ln_blocks(rows) * 2 * cols * (int64_t)sizeof(float);
 }
 
-extern "C" int cst_layernorm_bwd(const void* dy, const void* sx, const void* gamma, const float* mean, const float* rstd,
-                                 const void* dres, void* dx, void* dgamma, void* dbeta, void* workspace, int64_t rows,
-                                 int64_t cols, int dtype, int grad_dtype, cst_stream stream) {
+static int layernorm_bwd_impl(const void* dy, const void* sx, const void* gamma, const float* mean, const float* rstd,
+                              const void* dres, void* dx, void* dgamma, void* dbeta, void* workspace, int64_t rows,
+                              int64_t cols, int dtype, int grad_dtype, uint32_t* tile_live, uint32_t epoch, cst_stream stream) {
   CST_REQUIRE(dy && sx && gamma && mean && rstd && dx && dgamma && dbeta && workspace, "cst_layernorm_bwd: null tensor");
   CST_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 8 * 64 * LN_MAXV, "cst_layernorm_bwd: cols=%lld must be a multiple of 8 and <= %d", (long long)cols, 8 * 64 * LN_MAXV);
   hipStream_t s = (hipStream_t)stream;
@@ -202,9 +208,9 @@ extern "C" int cst_layernorm_bwd(const void* dy, const void* sx, const void* gam
   CstProfScope prof(CST_K_LAYERNORM, s, 0.0, bytes);
   const int nb = ln_blocks(rows);
   if (dtype == CST_BF16)
-    hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(nb), dim3(LN_WAVES * 64), 0, s, (const bf16_t*)dy, (const bf16_t*)sx, (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, (float*)workspace, rows, (int)cols);
+    hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(nb), dim3(LN_WAVES * 64), 0, s, (const bf16_t*)dy, (const bf16_t*)sx, (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, (float*)workspace, rows, (int)cols, tile_live, epoch);
   else if (dtype == CST_F32)
-    hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(LN_WAVES * 64), 0, s, (const float*)dy, (const float*)sx, (const float*)gamma, mean, rstd, (const float*)dres, (float*)dx, (float*)workspace, rows, (int)cols);
+    hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(LN_WAVES * 64), 0, s, (const float*)dy, (const float*)sx, (const float*)gamma, mean, rstd, (const float*)dres, (float*)dx, (float*)workspace, rows, (int)cols, tile_live, epoch);
   else CST_REQUIRE(false, "cst_layernorm_bwd: bad dtype %d", dtype);
   int rc = cst_check_launch("cst_layernorm_bwd");
   if (rc != CST_OK) return rc;
@@ -214,4 +220,17 @@ extern "C" int cst_layernorm_bwd(const void* dy, const void* sx, const void* gam
   else
     hipLaunchKernelGGL(ln_bwd_reduce_kernel<float>, dim3((unsigned)cst_ceil_div(cols, 16)), dim3(1024), 0, s, (const float*)workspace, (float*)dgamma, (float*)dbeta, nb, (int)cols);
   return cst_check_launch("cst_layernorm_bwd reduce");
+}
+
+extern "C" int cst_layernorm_bwd(const void* dy, const void* sx, const void* gamma, const float* mean, const float* rstd,
+                                 const void* dres, void* dx, void* dgamma, void* dbeta, void* workspace, int64_t rows,
+                                 int64_t cols, int dtype, int grad_dtype, cst_stream stream) {
+  return layernorm_bwd_impl(dy, sx, gamma, mean, rstd, dres, dx, dgamma, dbeta, workspace, rows, cols, dtype, grad_dtype, nullptr, 0, stream);
+}
+
+extern "C" int cst_layernorm_bwd_tiles(const void* dy, const void* sx, const void* gamma, const float* mean, const float* rstd,
+                                       const void* dres, void* dx, void* dgamma, void* dbeta, void* workspace, int64_t rows,
+                                       int64_t cols, int dtype, int grad_dtype, uint32_t* tile_live, uint32_t epoch, cst_stream stream) {
+  CST_REQUIRE(tile_live && epoch != 0, "cst_layernorm_bwd_tiles: tile_live / non-zero epoch required");
+  return layernorm_bwd_impl(dy, sx, gamma, mean, rstd, dres, dx, dgamma, dbeta, workspace, rows, cols, dtype, grad_dtype, tile_live, epoch, stream);
 }

@@ -24,6 +24,30 @@ def _vec(dtype):
     return 8 if dtype == torch.bfloat16 else 4
 
 
+# Live-tile stamps: a LayerNorm backward knows, for free, which 64-row tiles of the gradient it writes are not exactly zero (the
+# rows of padded frames are).  The stamps ride on the gradient tensor as an attribute (PyObject preservation keeps it on the
+# way to the next node's backward; any op in between — an accumulation, a copy — yields a fresh tensor without it, which only
+# means "no skipping") and the weight-gradient GEMMs that reduce over those rows skip the dead K blocks (cst_gemm_desc.k_live).
+def _with_tiles(t, tiles):
+    if t.is_contiguous():  # row r of the producer = row r of t flattened to [rows, cols]
+        t._cst_live_tiles = (tiles[0], tiles[1], t.data_ptr(), t.numel(), t.shape[-1])
+        if t._base is not None:  # views made further down the graph report the ultimate base, not `t`
+            t._base._cst_live_tiles = t._cst_live_tiles
+    return t
+
+
+def _tiles_of(t, rows):
+    """The stamps of `t` if — and only if — t is still the very tensor they were made for: same storage, same extent, same row
+    width, contiguous (so that _flat2d(t) is a view with the producer's row order)."""
+    lt = getattr(t, "_cst_live_tiles", None)
+    if lt is None and t._base is not None:  # a view (e.g. the [T,B,C] <-> [B,T,C] transposes of the layout seam, undone again)
+        lt = getattr(t._base, "_cst_live_tiles", None)
+    if (lt is None or not t.is_contiguous() or lt[2] != t.data_ptr() or lt[3] != t.numel() or lt[4] != t.shape[-1]
+            or lt[0].numel() != (rows + 63) // 64):
+        return None
+    return (lt[0], lt[1])
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, resid, act, drop_p, drop_key):
@@ -71,6 +95,7 @@ def _linear_backward(ctx, dy, dxp):
     if dy is None:  # only the pass-through was consumed
         return dxp, None, None, None, None, None, None
     dy2 = _flat2d(dy)
+    live = _tiles_of(dy, M)  # rows of dy that are exactly zero stay zero through the mask / activation derivative below
     if Np != N:
         dyp = torch.zeros(M, Np, dtype=dy2.dtype, device=dy2.device)
         dyp[:, :N] = dy2
@@ -86,7 +111,7 @@ def _linear_backward(ctx, dy, dxp):
         dx = dx.view(ctx.xshape)
     if ctx.needs_input_grad[1]:
         dw = torch.empty(Np, Kd, dtype=w.dtype, device=w.device)
-        K.gemm(dz, x2, dw, Np, Kd, M, a_kmajor=0, b_kmajor=0, lda=Np, ldb=Kd, ldc=Kd, split_k=-1)
+        K.gemm(dz, x2, dw, Np, Kd, M, a_kmajor=0, b_kmajor=0, lda=Np, ldb=Kd, ldc=Kd, split_k=-1, k_live=live)
         dw = dw[:N]
     if ctx.has_bias and ctx.needs_input_grad[2]:
         db = K.colsum(dz, w.dtype)[:N]
@@ -155,6 +180,7 @@ class _FFNFn(torch.autograd.Function):
         M, d = x2.shape
         F_, dout = w1.shape[0], w2.shape[0]
         dy2 = _flat2d(dy)
+        live = _tiles_of(dy, M)  # zero rows of dy are zero rows of dy2 (mask) and of dz1 (row-wise GEMM, act', mask)
         p_act, key_act, p_out, key_out = ctx.drop
         if p_out > 0.0:  # d(fc2 output) = dy * mask_out
             dy2 = K.dropout(dy2 if dy2.is_contiguous() else dy2.contiguous(), p_out, key_out)
@@ -164,7 +190,7 @@ class _FFNFn(torch.autograd.Function):
         dx = dw1 = db1 = dw2 = db2 = None
         if ctx.needs_input_grad[3]:
             dw2 = torch.empty(dout, F_, dtype=w2.dtype, device=w2.device)
-            K.gemm(dy2, h, dw2, dout, F_, M, a_kmajor=0, b_kmajor=0, lda=dout, ldb=F_, ldc=F_, split_k=-1)
+            K.gemm(dy2, h, dw2, dout, F_, M, a_kmajor=0, b_kmajor=0, lda=dout, ldb=F_, ldc=F_, split_k=-1, k_live=live)
         if has_b2 and ctx.needs_input_grad[4]:
             db2 = K.colsum(dy2, w2.dtype)
         if ctx.needs_input_grad[0]:
@@ -174,7 +200,7 @@ class _FFNFn(torch.autograd.Function):
             dx = dx.view(xshape)
         if ctx.needs_input_grad[1]:
             dw1 = torch.empty(F_, d, dtype=w1.dtype, device=w1.device)
-            K.gemm(dz1, x2, dw1, F_, d, M, a_kmajor=0, b_kmajor=0, lda=F_, ldb=d, ldc=d, split_k=-1)
+            K.gemm(dz1, x2, dw1, F_, d, M, a_kmajor=0, b_kmajor=0, lda=F_, ldb=d, ldc=d, split_k=-1, k_live=live)
         if has_b1 and ctx.needs_input_grad[2]:
             db1 = K.colsum(dz1, w1.dtype)
         dres = dy if has_res and ctx.needs_input_grad[5] and not (ctx.res_is_x and ctx.needs_input_grad[0]) else None
@@ -212,8 +238,8 @@ class _LayerNormFn(torch.autograd.Function):
             return ds, (ds if ctx.has_res else None), None, None, None
         dy2 = _flat2d(dy)
         dres = _flat2d(ds) if ds is not None else None
-        dx, dg, db = K.layernorm_bwd(dy2, src, gamma, mean, rstd, dres, grad_dtype=gamma.dtype)
-        dx = dx.view(ctx.shape)
+        dx, dg, db, tiles = K.layernorm_bwd(dy2, src, gamma, mean, rstd, dres, grad_dtype=gamma.dtype, want_tiles=True)
+        dx = _with_tiles(dx.view(ctx.shape), tiles)
         return dx, (dx if ctx.has_res else None), dg, db, None
 
 

@@ -7,6 +7,7 @@ import torch
 from . import lib as L
 
 _ws = {}
+STATS = {}  # light counters for tests / tools (e.g. how many GEMM launches carried live-tile stamps)
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
@@ -28,8 +29,9 @@ def _2d(t):
 def gemm(A, B, C, M, N, K, *, a_kmajor, b_kmajor, lda, ldb, ldc, bias=None, bias_mode=L.BIAS_COL, act=L.ACT_NONE,
          aux_out=None, ld_aux_out=0, dact=L.ACT_NONE, aux_in=None, ld_aux_in=0, resid=None, ld_resid=0, alpha=1.0,
          batch0=1, batch1=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), sbias=(0, 0), a_seg=0, a_seg_stride=0, b_seg=0,
-         b_seg_stride=0, split_k=-1, a_off=0, b_off=0, c_off=0, drop_p=0.0, drop_key=0):
-    """C = epilogue(alpha * Aop @ Bop); see include/cst.h.  Offsets *_off are in elements."""
+         b_seg_stride=0, split_k=-1, a_off=0, b_off=0, c_off=0, drop_p=0.0, drop_key=0, k_live=None):
+    """C = epilogue(alpha * Aop @ Bop); see include/cst.h.  Offsets *_off are in elements.  k_live = (stamps, epoch): the 64-wide
+    K blocks of A that are not all-zero (LiveTiles.pair()); dead blocks may be skipped."""
     lib = L.load()
     d = L.GemmDesc()
     d.dtype = L.dtype_code(A.dtype)
@@ -65,6 +67,12 @@ def gemm(A, B, C, M, N, K, *, a_kmajor, b_kmajor, lda, ldb, ldc, bias=None, bias
     d.sb0, d.sb1 = sb
     d.sc0, d.sc1 = sc
     d.split_k = split_k
+    if k_live is not None:
+        assert k_live[0].numel() * 64 >= K and k_live[0].dtype == torch.int32
+        STATS["gemm_k_live"] = STATS.get("gemm_k_live", 0) + 1
+        d.k_live, d.k_epoch = k_live[0].data_ptr(), k_live[1]
+    else:
+        d.k_live, d.k_epoch = None, 0
     need = lib.cst_gemm_workspace(ctypes.byref(d))
     if need > 0:
         ws = workspace(need, A.device)
@@ -87,8 +95,18 @@ def layernorm_fwd(x, res, gamma, beta, eps, want_sum=False):
     return y, s, mean, rstd
 
 
-def layernorm_bwd(dy, s, gamma, mean, rstd, dres=None, grad_dtype=torch.float32):
-    """dgamma / dbeta come back in `grad_dtype` (fp32, or the parameter dtype: accumulated in fp32, rounded once)."""
+_EPOCH = [0]
+
+
+def next_epoch():
+    """Unique non-zero 32-bit stamp per producer call (live-tile stamps are never initialised: a tile is live iff stamp == epoch)."""
+    _EPOCH[0] = (_EPOCH[0] % 0xFFFFFFFE) + 1
+    return _EPOCH[0]
+
+
+def layernorm_bwd(dy, s, gamma, mean, rstd, dres=None, grad_dtype=torch.float32, want_tiles=False):
+    """dgamma / dbeta come back in `grad_dtype` (fp32, or the parameter dtype: accumulated in fp32, rounded once).
+    want_tiles: also returns (stamps int32 [ceil(rows/64)], epoch) marking the 64-row tiles of dx that are not exactly zero."""
     dy, s = _2d(dy), _2d(s)
     rows, cols = s.shape
     lib = L.load()
@@ -96,6 +114,12 @@ def layernorm_bwd(dy, s, gamma, mean, rstd, dres=None, grad_dtype=torch.float32)
     dg = torch.empty(cols, dtype=grad_dtype, device=s.device)
     db = torch.empty(cols, dtype=grad_dtype, device=s.device)
     ws = workspace(lib.cst_layernorm_bwd_workspace(rows, cols), s.device)
+    if want_tiles:
+        stamps, epoch = torch.empty((rows + 63) // 64, dtype=torch.int32, device=s.device), next_epoch()
+        L.check(lib.cst_layernorm_bwd_tiles(L.ptr(dy), L.ptr(s), L.ptr(gamma), L.ptr(mean), L.ptr(rstd), L.ptr(dres), L.ptr(dx), L.ptr(dg),
+                                            L.ptr(db), L.ptr(ws), rows, cols, L.dtype_code(s.dtype), L.dtype_code(grad_dtype),
+                                            L.ptr(stamps), epoch, L.stream_ptr()), "cst_layernorm_bwd_tiles")
+        return dx, dg, db, (stamps, epoch)
     L.check(lib.cst_layernorm_bwd(L.ptr(dy), L.ptr(s), L.ptr(gamma), L.ptr(mean), L.ptr(rstd), L.ptr(dres), L.ptr(dx), L.ptr(dg),
                                   L.ptr(db), L.ptr(ws), rows, cols, L.dtype_code(s.dtype), L.dtype_code(grad_dtype), L.stream_ptr()),
             "cst_layernorm_bwd")

@@ -38,6 +38,7 @@ class GemmDesc(ctypes.Structure):
         ("sa0", c_i64), ("sa1", c_i64), ("sb0", c_i64), ("sb1", c_i64), ("sc0", c_i64), ("sc1", c_i64),
         ("split_k", c_int),
         ("workspace", c_p), ("workspace_bytes", c_i64),
+        ("k_live", c_p), ("k_epoch", ctypes.c_uint32),
     ]
 
 
@@ -89,6 +90,7 @@ SYMBOLS = [
     ("cst_layernorm_fwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_f, c_int, c_p]),
     ("cst_layernorm_bwd_workspace", c_i64, [c_i64, c_i64]),
     ("cst_layernorm_bwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_int, c_int, c_p]),
+    ("cst_layernorm_bwd_tiles", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_int, c_int, c_p, ctypes.c_uint32, c_p]),
     ("cst_gemm_workspace", c_i64, [ctypes.POINTER(GemmDesc)]),
     ("cst_gemm", c_int, [ctypes.POINTER(GemmDesc), c_p]),
     ("cst_attn_fwd", c_int, [ctypes.POINTER(AttnDesc), c_p]),

@@ -73,6 +73,13 @@ int64_t cst_layernorm_bwd_workspace(int64_t rows, int64_t cols);
 int cst_layernorm_bwd(const void* dy, const void* s, const void* gamma, const float* mean,
                       const float* rstd, const void* dres, void* dx, void* dgamma, void* dbeta,
                       void* workspace, int64_t rows, int64_t cols, int dtype, int grad_dtype, cst_stream stream);
+/* the same, and additionally stamps tile_live[row / 64] = epoch for every row whose dx is not exactly zero (tile_live: uint32
+ * [ceil(rows / 64)], NOT initialised by the caller: a tile is live iff its stamp equals this call's unique, non-zero epoch) —
+ * the k_live / k_epoch operand of the weight-gradient GEMMs that consume dx (or a row-wise function of it) */
+int cst_layernorm_bwd_tiles(const void* dy, const void* s, const void* gamma, const float* mean,
+                            const float* rstd, const void* dres, void* dx, void* dgamma, void* dbeta,
+                            void* workspace, int64_t rows, int64_t cols, int dtype, int grad_dtype,
+                            uint32_t* tile_live, uint32_t epoch, cst_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * GEMM on MFMA tiles — replaces F.linear / nn.Conv1d call sites:
@@ -123,6 +130,11 @@ typedef struct {
   int64_t sa0, sa1, sb0, sb1, sc0, sc1; /* batch strides (elements) for A, B, C(+aux/resid) */
   int split_k;                       /* 0/1 = none; >1 explicit; -1 = let the library choose */
   void* workspace; int64_t workspace_bytes;
+  const uint32_t* k_live; uint32_t k_epoch; /* optional (NULL = off): one stamp per 64 consecutive k indices; a k block whose stamp
+                                        != k_epoch is declared ALL-ZERO in A (every row/column of A at those k) and may be skipped —
+                                        exact, 0 * b adds nothing.  Used for the weight-gradient GEMMs (k = token), whose dY rows
+                                        at padded frames are exactly zero; stamps come from cst_layernorm_bwd_tiles.  Kernels
+                                        that do not implement skipping ignore it. */
 } cst_gemm_desc;
 
 int64_t cst_gemm_workspace(const cst_gemm_desc* d);

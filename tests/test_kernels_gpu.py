@@ -485,6 +485,56 @@ def test_gemm_8phase_large(K, ak, bk, M, N, K_):
     check(C, ref, dt, "8-phase gemm %d%d %dx%dx%d" % (ak, bk, M, N, K_))
 
 
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_live_k_tiles_skip(K, dt):
+    """Weight-gradient GEMM (k = token, both operands token-major) with 64-token blocks of dY that are exactly zero: the launch
+    that is told so (cst_gemm_desc.k_live, stamps from the LayerNorm backward) must return the same dW (bit-identical with one
+    split), zeros when every block is dead, and the stamps themselves must mark exactly the tiles holding a non-zero dx row."""
+    k, L = K
+    from importlib import import_module
+    Kn = import_module("chimera-st_amd.kernels")
+    rows, C, F_ = 64 * 37 + 24, 256, 512
+    x = rnd(rows, C, dt=dt, seed=1)
+    gamma, beta = rnd(C, dt=dt, seed=2) + 1.0, rnd(C, dt=dt, seed=3)
+    y, _, mean, rstd = k.layernorm_fwd(x, None, gamma, beta, 1e-5)
+    dy = rnd(rows, C, dt=dt, seed=4)
+    dead = torch.zeros(rows, dtype=torch.bool, device="cuda")
+    for lo, hi in ((0, 130), (700, 1500), (2300, rows)):
+        dead[lo:hi] = True
+    dy[dead] = 0
+    dx, dg, db, (stamps, epoch) = k.layernorm_bwd(dy, x, gamma, mean, rstd, None, grad_dtype=dt, want_tiles=True)
+    dx0, dg0, db0 = k.layernorm_bwd(dy, x, gamma, mean, rstd, None, grad_dtype=dt)
+    assert torch.equal(dx, dx0) and torch.equal(dg, dg0) and torch.equal(db, db0)
+    nz_row = (dx.float() != 0).any(dim=1)
+    assert not nz_row[dead].any()
+    ntile = (rows + 63) // 64
+    live_ref = torch.stack([nz_row[i * 64:(i + 1) * 64].any() for i in range(ntile)])
+    assert torch.equal(stamps == epoch, live_ref) and 0 < int(live_ref.sum()) < ntile
+    h = rnd(rows, F_, dt=dt, seed=5)
+    n0 = Kn.STATS.get("gemm_k_live", 0)
+    for split in (-1, 1, 3):
+        dw_ref = torch.empty(C, F_, dtype=dt, device="cuda")
+        k.gemm(dx, h, dw_ref, C, F_, rows, a_kmajor=0, b_kmajor=0, lda=C, ldb=F_, ldc=F_, split_k=split)
+        dw = torch.full((C, F_), float("nan"), dtype=dt, device="cuda")
+        k.gemm(dx, h, dw, C, F_, rows, a_kmajor=0, b_kmajor=0, lda=C, ldb=F_, ldc=F_, split_k=split, k_live=(stamps, epoch))
+        if split == 1:
+            assert torch.equal(dw, dw_ref)  # one split: the same products in the same order, minus exact zeros
+        else:  # split-K deals the LIVE tiles out evenly: another (equally valid, deterministic) fp32 summation order
+            ref32 = dx.float().t() @ h.float()
+            check(dw, ref32, dt, "dW, live tiles, split %d" % split, scale=float(ref32.abs().max()))
+            dw2 = torch.full((C, F_), float("nan"), dtype=dt, device="cuda")
+            k.gemm(dx, h, dw2, C, F_, rows, a_kmajor=0, b_kmajor=0, lda=C, ldb=F_, ldc=F_, split_k=split, k_live=(stamps, epoch))
+            assert torch.equal(dw, dw2)
+    assert Kn.STATS.get("gemm_k_live", 0) == n0 + 5  # 3 + the two determinism re-runs
+    check(dw_ref, dx.float().t() @ h.float(), dt, "dW", scale=float((dx.float().t() @ h.float()).abs().max()))
+    # every block dead: zeros
+    z = torch.zeros_like(dx)
+    none_live = torch.zeros(ntile, dtype=torch.int32, device="cuda")
+    dwz = torch.full((C, F_), float("nan"), dtype=dt, device="cuda")
+    k.gemm(z, h, dwz, C, F_, rows, a_kmajor=0, b_kmajor=0, lda=C, ldb=F_, ldc=F_, split_k=-1, k_live=(none_live, 7))
+    assert torch.equal(dwz, torch.zeros_like(dwz))
+
+
 @pytest.mark.parametrize("ak,bk", [(1, 1), (1, 0), (0, 0)])
 def test_gemm_8phase_claimed_items(K, ak, bk):
     """More work items than workgroups: every item after a workgroup's first is claimed from the per-XCD counters (gemm8p.hip).
