@@ -109,6 +109,8 @@ def _linear_backward(ctx, dy, dxp):
         K.gemm(dz, w, dx, M, Kd, Np, a_kmajor=1, b_kmajor=0, lda=Np, ldb=Kd, ldc=Kd, split_k=1,
                resid=_flat2d(dxp) if dxp is not None else None, ld_resid=Kd)
         dx = dx.view(ctx.xshape)
+        if live is not None and dxp is None:
+            dx = _with_tiles(dx, live)  # a zero row of dz is a zero row of dz W
     if ctx.needs_input_grad[1]:
         dw = torch.empty(Np, Kd, dtype=w.dtype, device=w.device)
         K.gemm(dz, x2, dw, Np, Kd, M, a_kmajor=0, b_kmajor=0, lda=Np, ldb=Kd, ldc=Kd, split_k=-1, k_live=live)
@@ -287,6 +289,24 @@ def layer_norm_residual(x, gamma, beta, eps=1e-5):
 _MASK_CACHE = []  # [(source mask (kept alive), version, uint8 mask, kv_len)] — one padding mask serves every layer of a pass
 
 
+_PAD_TILES = []  # [(uint8 mask (kept alive), bool [ceil(B*T/64)]: every row of the 64-row tile of the flattened [B*T] rows is padding)]
+
+
+def _pad_tiles(u8):
+    for src, pt in _PAD_TILES:
+        if src is u8:
+            return pt
+    flat = u8.reshape(-1)
+    pad = (-flat.numel()) % 64
+    if pad:
+        flat = torch.cat([flat, torch.ones(pad, dtype=flat.dtype, device=flat.device)])
+    pt = flat.view(-1, 64).amin(dim=1) > 0
+    _PAD_TILES.append((u8, pt))
+    if len(_PAD_TILES) > 8:
+        _PAD_TILES.pop(0)
+    return pt
+
+
 def _mask_and_len(key_padding_mask):
     """(uint8 [B,Tk] mask, int32 [B] kv_len) of a key padding mask; kv_len[b] = 1 + index of the last real key, so that the
     kernels skip the all-padding key tiles at the end of every utterance of a length-sorted batch (cst_attn_desc.kv_len)."""
@@ -352,7 +372,8 @@ class _AttnPackedFn(torch.autograd.Function):
     into ONE [B, T, 3C] buffer, so the projection's dX / dW are single GEMMs and x receives a single gradient."""
 
     @staticmethod
-    def forward(ctx, qkv, kpm, kvl, H, causal, scale, drop_p, drop_key):
+    def forward(ctx, qkv, kpm, kvl, H, causal, scale, drop_p, drop_key, pad_tiles=None):
+        ctx.pad_tiles = pad_tiles
         C = qkv.shape[-1] // 3
         D = C // H
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
@@ -369,6 +390,7 @@ class _AttnPackedFn(torch.autograd.Function):
     def backward(ctx, do):
         qkv, o, lse, kpm, kvl = ctx.saved_tensors
         H, D, C, causal, scale, drop_p, drop_key = ctx.cfg
+        live = _tiles_of(do, qkv.shape[0] * qkv.shape[1]) if ctx.pad_tiles is not None else None
         if not do.is_contiguous():
             do = do.contiguous()
         dqkv = torch.empty_like(qkv)
@@ -378,7 +400,12 @@ class _AttnPackedFn(torch.autograd.Function):
         d = K.attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, "bt", "bt", drop_p, drop_key, kvl)
         K.attn_bwd_fill(d, do, dq, dk, dv, delta, D, "bt", "bt")
         K.attn_bwd_desc(d)
-        return dqkv, None, None, None, None, None, None, None
+        if live is not None:
+            # row t of dq|dk|dv is exactly zero when dO_t is (dS_t. = P_t. * 0) AND key t is padding (P_.t = 0): a 64-row tile
+            # that is dead in dO and all padding is dead here; every other tile is declared live
+            stamps = torch.where(ctx.pad_tiles, live[0], torch.full_like(live[0], live[1] if live[1] < 2 ** 31 else live[1] - 2 ** 32))
+            dqkv = _with_tiles(dqkv, (stamps, live[1]))
+        return dqkv, None, None, None, None, None, None, None, None
 
 
 def attention_packed(qkv, num_heads, key_padding_mask=None, causal=False, scale=None, dropout_p=0.0):
@@ -388,7 +415,8 @@ def attention_packed(qkv, num_heads, key_padding_mask=None, causal=False, scale=
         scale = (C // num_heads) ** -0.5
     key_padding_mask, kv_len = _mask_and_len(key_padding_mask)
     assert qkv.is_contiguous()
-    return _AttnPackedFn.apply(qkv, key_padding_mask, kv_len, num_heads, bool(causal), float(scale), *_drop_args(dropout_p))
+    pad_tiles = _pad_tiles(key_padding_mask) if (key_padding_mask is not None and qkv.requires_grad) else None
+    return _AttnPackedFn.apply(qkv, key_padding_mask, kv_len, num_heads, bool(causal), float(scale), *_drop_args(dropout_p), pad_tiles)
 
 
 # ------------------------------------------------------------------------------------------------

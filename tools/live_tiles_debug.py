@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Which weight-gradient GEMMs of one full-size update receive live-tile stamps, and the fraction of 64-token blocks that are live
+(the rest is skipped: cst_gemm_desc.k_live)."""
 import os, sys, importlib, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
