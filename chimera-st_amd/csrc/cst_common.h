@@ -19,6 +19,7 @@ struct CstProfScope {
   ~CstProfScope();
 };
 int cst_check_launch(const char* what);
+bool cst_prof_is_on();  // the hipEvent profiling table of bench.py's roofline step is recording
 
 #define CST_REQUIRE(cond, ...)                         \
   do {                                                 \

@@ -43,6 +43,8 @@ CstProfScope::CstProfScope(int cls_, hipStream_t s_, double flops, double bytes)
   g_prof[cls].push_back(r);
   slot = (int)g_prof[cls].size() - 1;
 }
+bool cst_prof_is_on() { return g_prof_on; }
+
 CstProfScope::~CstProfScope() {
   if (slot < 0) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
