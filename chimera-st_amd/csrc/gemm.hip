@@ -255,6 +255,14 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmParams p) {
     __syncthreads();
     nk = klist_n;
   }
+  if (p.m_live) {  // an output tile all of whose A rows are stamped dead: accumulators stay exactly 0, only the epilogue runs
+    typedef const __attribute__((address_space(4))) uint32_t* cptr_t;  // scalar loads (the stamps were written by an earlier kernel)
+    cptr_t ml = (cptr_t)p.m_live;
+    const int t0 = (int)(m0 >> 6), t1 = (int)((((m0 + BM < p.M) ? m0 + BM : p.M) + 63) >> 6);
+    bool live = false;
+    for (int t = t0; t < t1; ++t) live |= ml[t] == p.m_epoch;
+    if (!live) nk = 0;
+  }
   int pos = kt0;  // the K tile the staging pointers stand at
   auto fetch = [&](int kt) {
     const int d = kt - pos;
@@ -760,6 +768,8 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
     static const bool no_klive = getenv("CST_GEMM_NO_KLIVE") != nullptr;  // A/B switch: visit the all-zero K blocks too
     p.k_live = no_klive ? nullptr : d->k_live;
     p.k_epoch = d->k_epoch;
+    p.m_live = no_klive ? nullptr : d->m_live;
+    p.m_epoch = d->m_epoch;
   }
   {
     static const int gm = getenv("CST_GEMM8P_GROUP_M") ? atoi(getenv("CST_GEMM8P_GROUP_M")) : 8;
@@ -792,6 +802,19 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
       int64_t live = 0;
       for (int64_t i = 0; i < nt; ++i) live += st[i] == p.k_epoch;
       kfrac = (double)live / (double)nt;
+    }
+  }
+  if (p.m_live && cst_prof_is_on()) {  // dX GEMMs: credit the 256-row output tiles that still run their K loop (8p / 16-wave tile)
+    const int64_t nt = cst_ceil_div(d->M, 64);
+    std::vector<uint32_t> st((size_t)nt);
+    if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(st.data(), p.m_live, sizeof(uint32_t) * nt, hipMemcpyDeviceToHost) == hipSuccess) {
+      int64_t live = 0, tiles = cst_ceil_div(d->M, 256);
+      for (int64_t t = 0; t < tiles; ++t) {
+        bool l = false;
+        for (int64_t i = 4 * t; i < 4 * t + 4 && i < nt; ++i) l |= st[i] == p.m_epoch;
+        live += l;
+      }
+      kfrac *= (double)live / (double)tiles;
     }
   }
   const double flops = 2.0 * (double)d->M * (double)d->N * (double)d->K * (double)nbatch * kfrac;

@@ -152,6 +152,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
     const int kt0 = split * per;
     const int kt1 = (kt0 + per < ktiles) ? kt0 + per : ktiles;
     nt = kt1 > kt0 ? kt1 - kt0 : 0;
+    if (kp->m_live) {  // all four 64-row blocks of this tile's A rows stamped dead: no K loop, the epilogue runs on zero accumulators
+      typedef const __attribute__((address_space(4))) uint32_t* cptr_t;
+      cptr_t ml = (cptr_t)kp->m_live;
+      const uint32_t ep = kp->m_epoch;
+      const int t0 = (int)(m0 >> 6), tn = (int)((p.M + 63) >> 6);
+      bool live = false;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) live |= (t0 + i < tn) && ml[t0 + i < tn ? t0 + i : t0] == ep;
+      if (!live) nt = 0;
+    }
     krem0 = (int)p.K - kt0 * BK;
     const T* abase = AK ? A + m0 * p.lda + (int64_t)kt0 * BK : A + (int64_t)kt0 * BK * p.lda + m0;
     const T* bbase = BKM ? B + n0 * p.ldb + (int64_t)kt0 * BK : B + (int64_t)kt0 * BK * p.ldb + n0;

@@ -29,6 +29,7 @@ struct GemmParams {
   int group_m;      // gemm8p: m tiles per group of the tile walk (the patch of tiles an XCD works on concurrently)
   int split_order;  // gemm_kernel, split-K unbatched: XCD-contiguous (split, tile) item order (see the kernel)
   int* sched;       // gemm8p: 16 zeroed ints of scheduling state (8 per-XCD item counters, 1 exit counter), nullptr = static walk
+  const uint32_t* m_live; uint32_t m_epoch;  // rows of A in blocks of 64: an output tile with no live block skips its K loop
   const uint32_t* k_live; uint32_t k_epoch;  // gemm_kernel: K blocks of 64 whose stamp != k_epoch are all-zero in A and skipped
 };
 

@@ -107,7 +107,7 @@ def _linear_backward(ctx, dy, dxp):
     if ctx.needs_input_grad[0]:
         dx = torch.empty(M, Kd, dtype=x2.dtype, device=x2.device)
         K.gemm(dz, w, dx, M, Kd, Np, a_kmajor=1, b_kmajor=0, lda=Np, ldb=Kd, ldc=Kd, split_k=1,
-               resid=_flat2d(dxp) if dxp is not None else None, ld_resid=Kd)
+               resid=_flat2d(dxp) if dxp is not None else None, ld_resid=Kd, m_live=live)
         dx = dx.view(ctx.xshape)
         if live is not None and dxp is None:
             dx = _with_tiles(dx, live)  # a zero row of dz is a zero row of dz W
@@ -188,7 +188,7 @@ class _FFNFn(torch.autograd.Function):
             dy2 = K.dropout(dy2 if dy2.is_contiguous() else dy2.contiguous(), p_out, key_out)
         dz1 = torch.empty(M, F_, dtype=dy2.dtype, device=dy2.device)
         K.gemm(dy2, w2, dz1, M, F_, dout, a_kmajor=1, b_kmajor=0, lda=dout, ldb=F_, ldc=F_, dact=act, aux_in=z1, ld_aux_in=F_, split_k=1,
-               drop_p=p_act, drop_key=key_act)
+               drop_p=p_act, drop_key=key_act, m_live=live)
         dx = dw1 = db1 = dw2 = db2 = None
         if ctx.needs_input_grad[3]:
             dw2 = torch.empty(dout, F_, dtype=w2.dtype, device=w2.device)
@@ -198,7 +198,7 @@ class _FFNFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, d, dtype=x2.dtype, device=x2.device)
             K.gemm(dz1, w1, dx, M, d, F_, a_kmajor=1, b_kmajor=0, lda=F_, ldb=d, ldc=d, split_k=1,
-                   resid=_flat2d(dy) if ctx.res_is_x else None, ld_resid=d)
+                   resid=_flat2d(dy) if ctx.res_is_x else None, ld_resid=d, m_live=live)
             dx = dx.view(xshape)
         if ctx.needs_input_grad[1]:
             dw1 = torch.empty(F_, d, dtype=w1.dtype, device=w1.device)

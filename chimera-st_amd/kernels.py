@@ -29,9 +29,10 @@ def _2d(t):
 def gemm(A, B, C, M, N, K, *, a_kmajor, b_kmajor, lda, ldb, ldc, bias=None, bias_mode=L.BIAS_COL, act=L.ACT_NONE,
          aux_out=None, ld_aux_out=0, dact=L.ACT_NONE, aux_in=None, ld_aux_in=0, resid=None, ld_resid=0, alpha=1.0,
          batch0=1, batch1=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), sbias=(0, 0), a_seg=0, a_seg_stride=0, b_seg=0,
-         b_seg_stride=0, split_k=-1, a_off=0, b_off=0, c_off=0, drop_p=0.0, drop_key=0, k_live=None):
+         b_seg_stride=0, split_k=-1, a_off=0, b_off=0, c_off=0, drop_p=0.0, drop_key=0, k_live=None, m_live=None):
     """C = epilogue(alpha * Aop @ Bop); see include/cst.h.  Offsets *_off are in elements.  k_live = (stamps, epoch): the 64-wide
-    K blocks of A that are not all-zero (LiveTiles.pair()); dead blocks may be skipped."""
+    K blocks of A that are not all-zero (LiveTiles.pair()); dead blocks may be skipped; m_live: the same stamps for the rows of A of a
+    row-wise GEMM (dX): output tiles without a live row skip their K loop."""
     lib = L.load()
     d = L.GemmDesc()
     d.dtype = L.dtype_code(A.dtype)
@@ -73,6 +74,12 @@ def gemm(A, B, C, M, N, K, *, a_kmajor, b_kmajor, lda, ldb, ldc, bias=None, bias
         d.k_live, d.k_epoch = k_live[0].data_ptr(), k_live[1]
     else:
         d.k_live, d.k_epoch = None, 0
+    if m_live is not None:
+        assert m_live[0].numel() * 64 >= M and m_live[0].dtype == torch.int32
+        d.m_live, d.m_epoch = m_live[0].data_ptr(), m_live[1]
+        STATS["gemm_m_live"] = STATS.get("gemm_m_live", 0) + 1
+    else:
+        d.m_live, d.m_epoch = None, 0
     need = lib.cst_gemm_workspace(ctypes.byref(d))
     if need > 0:
         ws = workspace(need, A.device)

@@ -39,6 +39,7 @@ class GemmDesc(ctypes.Structure):
         ("split_k", c_int),
         ("workspace", c_p), ("workspace_bytes", c_i64),
         ("k_live", c_p), ("k_epoch", ctypes.c_uint32),
+        ("m_live", c_p), ("m_epoch", ctypes.c_uint32),
     ]
 
 

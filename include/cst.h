@@ -135,6 +135,9 @@ typedef struct {
                                         exact, 0 * b adds nothing.  Used for the weight-gradient GEMMs (k = token), whose dY rows
                                         at padded frames are exactly zero; stamps come from cst_layernorm_bwd_tiles.  Kernels
                                         that do not implement skipping ignore it. */
+  const uint32_t* m_live; uint32_t m_epoch; /* optional: the same stamps on the M side — one per 64 consecutive rows of A (= rows
+                                        of C); an output tile whose rows of A are all dead skips its K loop (its accumulators
+                                        are exactly 0; the epilogue still runs: act', residual, stores).  Used for the dX GEMMs. */
 } cst_gemm_desc;
 
 int64_t cst_gemm_workspace(const cst_gemm_desc* d);

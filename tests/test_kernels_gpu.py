@@ -535,6 +535,35 @@ def test_gemm_live_k_tiles_skip(K, dt):
     assert torch.equal(dwz, torch.zeros_like(dwz))
 
 
+@pytest.mark.parametrize("rows,N,Kd", [(64 * 37 + 24, 512, 256), (64 * 700 + 8, 768, 3072), (64 * 700 + 8, 3072, 768)])
+def test_gemm_live_m_tiles_skip_is_bit_identical(K, rows, N, Kd):
+    """dX-type GEMMs (row-wise in A) with 64-row blocks of A that are exactly zero: told so through cst_gemm_desc.m_live, the
+    generic and the persistent kernel skip the K loop of all-dead output tiles; plain, act'(aux_in) and residual epilogues must give
+    bit-identical results."""
+    k, L = K
+    dt = torch.bfloat16
+    A = rnd(rows, Kd, dt=dt, seed=1)
+    nt = (rows + 63) // 64
+    g = torch.Generator().manual_seed(3)
+    live = torch.rand(nt, generator=g) > 0.45
+    live[5:12] = False  # a run long enough to cover whole 256-row tiles
+    live[nt // 2: nt // 2 + 40] = False
+    rowlive = live.repeat_interleave(64)[:rows].cuda()
+    A[~rowlive] = 0
+    epoch = 0x9ABCDEF1
+    stamps = torch.where(live, torch.tensor(epoch - 2 ** 32, dtype=torch.int64), torch.tensor(12345, dtype=torch.int64)).to(torch.int32).cuda()
+    W = rnd(Kd, N, dt=dt, seed=2)  # mn-major B ([K, N]), as the dX GEMMs have it
+    z = rnd(rows, N, dt=dt, seed=4)
+    res = rnd(rows, N, dt=dt, seed=5)
+    for kw in (dict(), dict(dact=L.ACT_GELU, aux_in=z, ld_aux_in=N), dict(resid=res, ld_resid=N)):
+        ref = torch.full((rows, N), float("nan"), dtype=dt, device="cuda")
+        k.gemm(A, W, ref, rows, N, Kd, a_kmajor=1, b_kmajor=0, lda=Kd, ldb=N, ldc=N, split_k=1, **kw)
+        out = torch.full((rows, N), float("nan"), dtype=dt, device="cuda")
+        k.gemm(A, W, out, rows, N, Kd, a_kmajor=1, b_kmajor=0, lda=Kd, ldb=N, ldc=N, split_k=1, m_live=(stamps, epoch), **kw)
+        assert torch.equal(out, ref), sorted(kw)
+    check(ref, A.float() @ W.float() + res.float(), dt, "dX + resid", scale=float((A.float() @ W.float()).abs().max()))
+
+
 @pytest.mark.parametrize("ak,bk", [(1, 1), (1, 0), (0, 0)])
 def test_gemm_8phase_claimed_items(K, ak, bk):
     """More work items than workgroups: every item after a workgroup's first is claimed from the per-XCD counters (gemm8p.hip).
