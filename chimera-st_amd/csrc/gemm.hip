@@ -108,8 +108,14 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmParams p) {
   const int64_t cofs = b0 * p.sc0 + b1 * p.sc1;
   const int64_t bofs = b0 * p.sbias0 + b1 * p.sbias1;
 
-  const int ktiles = (int)((p.K + BK - 1) / BK);
+  int ktiles = (int)((p.K + BK - 1) / BK);
   const int kfull = (int)(p.K / BK);  // tiles [0, kfull) need no K bound check
+  if (p.k_len) {  // this batch's A is zero from row k_len[b0] on: the K loop (and the split-K partition) ends there
+    typedef const __attribute__((address_space(4))) int32_t* cptr_t;
+    const int kl = ((cptr_t)p.k_len)[b0];
+    const int live = kl <= 0 ? 0 : (kl + BK - 1) / BK;
+    ktiles = live < ktiles ? live : ktiles;
+  }
   const int per = (ktiles + p.splits - 1) / p.splits;
   const int kt0 = split * per;
   const int kt1 = (kt0 + per < ktiles) ? kt0 + per : ktiles;
@@ -770,6 +776,7 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
     p.k_epoch = d->k_epoch;
     p.m_live = no_klive ? nullptr : d->m_live;
     p.m_epoch = d->m_epoch;
+    p.k_len = no_klive ? nullptr : d->k_len;
   }
   {
     static const int gm = getenv("CST_GEMM8P_GROUP_M") ? atoi(getenv("CST_GEMM8P_GROUP_M")) : 8;
@@ -802,6 +809,14 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
       int64_t live = 0;
       for (int64_t i = 0; i < nt; ++i) live += st[i] == p.k_epoch;
       kfrac = (double)live / (double)nt;
+    }
+  }
+  if (p.k_len && cst_prof_is_on()) {
+    std::vector<int32_t> kl((size_t)d->batch0);
+    if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(kl.data(), p.k_len, sizeof(int32_t) * d->batch0, hipMemcpyDeviceToHost) == hipSuccess) {
+      double sum = 0.0;
+      for (int64_t b = 0; b < d->batch0; ++b) sum += (double)(kl[b] < 0 ? 0 : (kl[b] < d->K ? kl[b] : d->K));
+      kfrac *= sum / ((double)d->batch0 * (double)d->K);
     }
   }
   if (p.m_live && cst_prof_is_on()) {  // dX GEMMs: credit the 256-row output tiles that still run their K loop (8p / 16-wave tile)

@@ -30,6 +30,7 @@ struct GemmParams {
   int split_order;  // gemm_kernel, split-K unbatched: XCD-contiguous (split, tile) item order (see the kernel)
   int* sched;       // gemm8p: 16 zeroed ints of scheduling state (8 per-XCD item counters, 1 exit counter), nullptr = static walk
   const uint32_t* m_live; uint32_t m_epoch;  // rows of A in blocks of 64: an output tile with no live block skips its K loop
+  const int32_t* k_len;  // gemm_kernel, per batch0: K rows >= k_len[b0] of A are zero
   const uint32_t* k_live; uint32_t k_epoch;  // gemm_kernel: K blocks of 64 whose stamp != k_epoch are all-zero in A and skipped
 };
 

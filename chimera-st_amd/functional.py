@@ -469,7 +469,8 @@ class _Conv1dCLFn(torch.autograd.Function):
     so the zero rows the dX windows need at utterance boundaries exist without copying."""
 
     @staticmethod
-    def forward(ctx, x, w_cl, bias, k, stride, pad, act, prev_z, grad_is_dz):
+    def forward(ctx, x, w_cl, bias, k, stride, pad, act, prev_z, grad_is_dz, nz_out=None):
+        ctx.nz_out = nz_out  # int32 [B]: the incoming gradient's rows t >= nz_out[b] are exactly zero (frames past the utterance's end)
         B, Lin, Cin = x.shape
         Cout = w_cl.shape[0]
         if pad:
@@ -556,14 +557,14 @@ class _Conv1dCLFn(torch.autograd.Function):
             rem = wgs % 256
             sk = 2 if (wgs >= 256 and 0 < rem < 192 and Lout >= 2048) else 1
             K.gemm(dz_rows, xp, part, Cout, k * Cin, Lout, a_kmajor=0, b_kmajor=0, lda=Cout, ldb=stride * Cin, ldc=k * Cin, batch0=B,
-                   sa=(dz_bs, 0), sb=(xp.stride(0), 0), sc=(Cout * k * Cin, 0), a_off=dz_off, split_k=sk)
+                   sa=(dz_bs, 0), sb=(xp.stride(0), 0), sc=(Cout * k * Cin, 0), a_off=dz_off, split_k=sk, k_len=ctx.nz_out)
             dw = part.sum(0).to(w_cl.dtype)
         if has_bias and ctx.needs_input_grad[2]:
             db = K.colsum(dz_rows.reshape(B * Lout, Cout) if dzp is None else dzp[:, 1:1 + Lout].reshape(B * Lout, Cout), w_cl.dtype)
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
-def conv1d_cl(x, weight, bias, stride, pad=0, act=None, prev_z=None, grad_is_dz=False):
+def conv1d_cl(x, weight, bias, stride, pad=0, act=None, prev_z=None, grad_is_dz=False, nz_out=None):
     """Channels-last conv1d.  x [B,Lin,Cin]; weight [Cout,Cin,k] (torch layout).  Returns (y, z) where z is
     the pre-activation (None without activation).  If `prev_z` (pre-GELU tensor that produced x = GELU(prev_z))
     is given, the returned input-gradient is already multiplied by GELU'(prev_z), i.e. it is d/d prev_z; the
@@ -573,7 +574,7 @@ def conv1d_cl(x, weight, bias, stride, pad=0, act=None, prev_z=None, grad_is_dz=
     w_cl = weight.permute(0, 2, 1).reshape(Cout, k * Cin)
     if not w_cl.is_contiguous():
         w_cl = w_cl.contiguous()
-    return _Conv1dCLFn.apply(x, w_cl, bias, k, stride, pad, _ACT[act], prev_z, bool(grad_is_dz))
+    return _Conv1dCLFn.apply(x, w_cl, bias, k, stride, pad, _ACT[act], prev_z, bool(grad_is_dz), nz_out)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -40,6 +40,7 @@ class GemmDesc(ctypes.Structure):
         ("workspace", c_p), ("workspace_bytes", c_i64),
         ("k_live", c_p), ("k_epoch", ctypes.c_uint32),
         ("m_live", c_p), ("m_epoch", ctypes.c_uint32),
+        ("k_len", c_p),
     ]
 
 

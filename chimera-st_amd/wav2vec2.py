@@ -49,8 +49,24 @@ class ConvFeatureExtractionModel(nn.Module):
             self.conv_layers.append(blk)
             in_d = dim
 
-    def forward(self, x):
-        """x [B,S] raw samples -> channels-last features [B, T1, C] (the reference returns [B,C,T1])."""
+    def forward(self, x, nz_last=None):
+        """x [B,S] raw samples -> channels-last features [B, T1, C] (the reference returns [B,C,T1]).
+        nz_last (int32 [B], optional): the caller guarantees that the gradient of the returned features is exactly zero at frames
+        t >= nz_last[b] (wav2vec2 zeroes the padded frames, wav2vec2.py:820-821).  The bound is carried down the stack — a
+        frame t of layer i+1 reads rows [s t, s t + k) of layer i, so layer i's gradient is zero from (nz - 1) s + k on — and the
+        weight-gradient GEMMs of each layer stop their reduction over frames there (cst_gemm_desc.k_len): exact."""
+        nz = [None] * len(self.conv_spec)
+        if nz_last is not None and torch.is_grad_enabled():
+            cur, lens = nz_last, []
+            s_ = x.shape[1]
+            for (_, k_, st_) in self.conv_spec:
+                s_ = (s_ - k_) // st_ + 1
+                lens.append(s_)
+            for i in range(len(self.conv_spec) - 1, 0, -1):
+                cur = torch.clamp(cur, max=lens[i]).to(torch.int32).contiguous()
+                nz[i] = cur
+                _, k_, st_ = self.conv_spec[i]
+                cur = torch.where(cur > 0, (cur - 1) * st_ + k_, torch.zeros_like(cur))
         l0 = self.conv_layers[0]
         dim, k, stride = self.conv_spec[0]
         y = CF.conv0_gn_gelu(x, getattr(l0, "0").weight, getattr(l0, "2").weight, getattr(l0, "2").bias, stride)
@@ -60,7 +76,7 @@ class ConvFeatureExtractionModel(nn.Module):
             dim, k, stride = self.conv_spec[i]
             w = getattr(self.conv_layers[i], "0").weight
             # fold GELU' of layer i-1 into layer i's col2im pass; layer i then receives d/dz directly
-            y, z = CF.conv1d_cl(y, w, None, stride, pad=0, act="gelu", prev_z=z, grad_is_dz=(i < n - 1))
+            y, z = CF.conv1d_cl(y, w, None, stride, pad=0, act="gelu", prev_z=z, grad_is_dz=(i < n - 1), nz_out=nz[i])
         return y
 
     def output_length(self, s):
@@ -214,7 +230,19 @@ class Wav2Vec2Model(nn.Module):
             if self.project_q is not None:
                 heads += list(self.project_q.parameters())
             notify_unused_parameters(heads)
-        feats = self.feature_extractor(source)  # [B, T1, C] channels-last
+        nz_last = None
+        if padding_mask is not None and self.training:
+            # the frame-level padding mask of :543-548, known before the CNN runs: frames past the last real one get a zero gradient
+            # (they are overwritten with zeros at the encoder input), which bounds every conv layer's weight-gradient reduction
+            t1 = self.feature_extractor.output_length(source.shape[1])
+            pm = padding_mask
+            extra = pm.size(1) % t1
+            if extra > 0:
+                pm = pm[:, :-extra]
+            fm = pm.view(pm.size(0), t1, -1).all(-1)
+            pos = torch.arange(1, t1 + 1, device=fm.device, dtype=torch.int32)
+            nz_last = (pos * (~fm)).amax(dim=1).to(torch.int32)
+        feats = self.feature_extractor(source, nz_last)  # [B, T1, C] channels-last
         if self.feature_grad_mult <= 0:
             feats = feats.detach()
         elif self.feature_grad_mult != 1.0:

@@ -138,6 +138,9 @@ typedef struct {
   const uint32_t* m_live; uint32_t m_epoch; /* optional: the same stamps on the M side — one per 64 consecutive rows of A (= rows
                                         of C); an output tile whose rows of A are all dead skips its K loop (its accumulators
                                         are exactly 0; the epilogue still runs: act', residual, stores).  Used for the dX GEMMs. */
+  const int32_t* k_len;              /* optional, [batch0]: rows k >= k_len[b0] of batch b0's A are all zero (a trailing run — the
+                                        frames past an utterance's end in the conv weight-gradient GEMMs); the K loop of that batch
+                                        stops there and split-K divides the live range.  Exact. */
 } cst_gemm_desc;
 
 int64_t cst_gemm_workspace(const cst_gemm_desc* d);

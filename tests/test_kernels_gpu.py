@@ -564,6 +564,34 @@ def test_gemm_live_m_tiles_skip_is_bit_identical(K, rows, N, Kd):
     check(ref, A.float() @ W.float() + res.float(), dt, "dX + resid", scale=float((A.float() @ W.float()).abs().max()))
 
 
+@pytest.mark.parametrize("split", [1, 2])
+def test_gemm_batched_k_len_is_exact(K, split):
+    """Per-utterance weight-gradient GEMM of a conv layer (batch0 = utterances, k = frame, both operands frame-major) whose A rows
+    are zero from k_len[b] on: the launch told so (cst_gemm_desc.k_len) stops each batch's reduction there — bit-identical with one
+    split, the same sums in another split order otherwise; k_len = 0 gives zeros."""
+    k, L = K
+    dt = torch.bfloat16
+    B, Lf, Cout, Cin = 5, 1000, 256, 384
+    dz = rnd(B, Lf, Cout, dt=dt, seed=1)
+    x = rnd(B, Lf, Cin, dt=dt, seed=2)
+    klen = torch.tensor([1000, 777, 64, 1, 0], dtype=torch.int32, device="cuda")
+    for b in range(B):
+        dz[b, int(klen[b]):] = 0
+    def run(**kw):
+        out = torch.full((B, Cout, Cin), float("nan"), dtype=torch.float32, device="cuda")
+        k.gemm(dz, x, out, Cout, Cin, Lf, a_kmajor=0, b_kmajor=0, lda=Cout, ldb=Cin, ldc=Cin, batch0=B, sa=(Lf * Cout, 0), sb=(Lf * Cin, 0),
+               sc=(Cout * Cin, 0), split_k=split, **kw)
+        return out
+    ref, got = run(), run(k_len=klen)
+    if split == 1:
+        assert torch.equal(got, ref)
+    else:
+        assert torch.equal(got, run(k_len=klen))
+    ref32 = torch.einsum("blo,bli->boi", dz.float(), x.float())
+    check(got, ref32, torch.float32, "batched dW with k_len", scale=float(ref32.abs().max()) * 4)
+    assert torch.equal(got[4], torch.zeros_like(got[4]))
+
+
 @pytest.mark.parametrize("ak,bk", [(1, 1), (1, 0), (0, 0)])
 def test_gemm_8phase_claimed_items(K, ak, bk):
     """More work items than workgroups: every item after a workgroup's first is claimed from the per-XCD counters (gemm8p.hip).

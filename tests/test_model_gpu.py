@@ -218,3 +218,40 @@ def test_dropout_training_step_consistency():
     lm, _ = run(5, backward=False)
     numeric = (lp - lm) / (2 * eps)
     assert abs(numeric - analytic) <= 2e-2 * abs(analytic) + 1e-3, "directional derivative %.6f vs analytic %.6f" % (numeric, analytic)
+
+
+def test_cnn_gradient_is_zero_past_the_bound_the_weight_gradients_use():
+    """The conv layers' weight-gradient GEMMs stop at nz_out[b] frames (cst_gemm_desc.k_len, wav2vec2.ConvFeatureExtractionModel):
+    the gradient that reaches each layer's output must be EXACTLY zero from there on, and non-zero somewhere just before it."""
+    from importlib import import_module
+    g = load_golden("s2t_w2v2_tiny.npz")
+    model, task, args = build_from_golden(g, "s2t_w2v2", torch.float32)
+    model.train()
+    CF = import_module("chimera-st_amd.functional")
+    seen = []
+    orig = CF.conv1d_cl
+
+    def spy(x, weight, bias, stride, pad=0, act=None, prev_z=None, grad_is_dz=False, nz_out=None):
+        y, z = orig(x, weight, bias, stride, pad=pad, act=act, prev_z=prev_z, grad_is_dz=grad_is_dz, nz_out=nz_out)
+        if nz_out is not None:
+            y.register_hook(lambda gr, nz=nz_out: seen.append((gr.detach().clone(), nz.clone())))
+        return y, z
+
+    CF.conv1d_cl = spy
+    import_module("chimera-st_amd.wav2vec2").CF.conv1d_cl = spy
+    try:
+        sample = to_cuda(golden_sample(g))
+        logits, _ = model(**sample["net_input"])
+        logits.float().pow(2).sum().backward()
+    finally:
+        CF.conv1d_cl = orig
+        import_module("chimera-st_amd.wav2vec2").CF.conv1d_cl = orig
+    assert len(seen) >= 2
+    ragged = 0
+    for gr, nz in seen:
+        for b in range(gr.shape[0]):
+            n = int(nz[b])
+            assert float(gr[b, n:].abs().max()) == 0.0 if n < gr.shape[1] else True
+            assert n == 0 or float(gr[b, max(0, n - 3):n].abs().max()) > 0.0
+            ragged += n < gr.shape[1]
+    assert ragged > 0  # the fixture has utterances shorter than the batch maximum
