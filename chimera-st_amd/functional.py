@@ -30,7 +30,7 @@ def _vec(dtype):
 # means "no skipping") and the weight-gradient GEMMs that reduce over those rows skip the dead K blocks (cst_gemm_desc.k_live).
 def _with_tiles(t, tiles):
     if t.is_contiguous():  # row r of the producer = row r of t flattened to [rows, cols]
-        t._cst_live_tiles = (tiles[0], tiles[1], t.data_ptr(), t.numel(), t.shape[-1])
+        t._cst_live_tiles = (tiles[0], tiles[1], t.data_ptr(), t.numel(), t.shape[-1], t._version)
         if t._base is not None:  # views made further down the graph report the ultimate base, not `t`
             t._base._cst_live_tiles = t._cst_live_tiles
     return t
@@ -38,12 +38,13 @@ def _with_tiles(t, tiles):
 
 def _tiles_of(t, rows):
     """The stamps of `t` if — and only if — t is still the very tensor they were made for: same storage, same extent, same row
-    width, contiguous (so that _flat2d(t) is a view with the producer's row order)."""
+    width, contiguous (so that _flat2d(t) is a view with the producer's row order) and not written since (the version counter is
+    shared by a base and its views; autograd may accumulate a second incoming gradient into the first one IN PLACE)."""
     lt = getattr(t, "_cst_live_tiles", None)
     if lt is None and t._base is not None:  # a view (e.g. the [T,B,C] <-> [B,T,C] transposes of the layout seam, undone again)
         lt = getattr(t._base, "_cst_live_tiles", None)
     if (lt is None or not t.is_contiguous() or lt[2] != t.data_ptr() or lt[3] != t.numel() or lt[4] != t.shape[-1]
-            or lt[0].numel() != (rows + 63) // 64):
+            or lt[5] != t._version or lt[0].numel() != (rows + 63) // 64):
         return None
     return (lt[0], lt[1])
 

@@ -728,3 +728,22 @@ def test_contrastive(K, dt, B, M, C):
     da, dtt = k.contrastive_bwd(a, t, sim, na, nt, g, temp)
     check(da, 0.7 * ar.grad, dt, "contrastive da", scale=float(ar.grad.abs().max()))
     check(dtt, 0.7 * tr.grad, dt, "contrastive dt", scale=float(tr.grad.abs().max()))
+
+
+def test_live_tile_stamps_are_dropped_when_the_gradient_is_rewritten():
+    """functional._tiles_of must not hand out stamps for a tensor that was written after stamping (autograd may accumulate a
+    second gradient into the first one in place), for a transposed view, or for a different tensor."""
+    from importlib import import_module
+    load_pkg()
+    F_ = import_module("chimera-st_amd.functional")
+    rows, C = 640, 64
+    base = torch.zeros(rows, C, device="cuda")
+    stamps = torch.zeros(rows // 64, dtype=torch.int32, device="cuda")
+    t = F_._with_tiles(base.view(10, 64, C), (stamps, 5))
+    assert F_._tiles_of(t, rows) is not None
+    assert F_._tiles_of(t.transpose(0, 1).transpose(0, 1), rows) is not None      # the layout seam: transposed and back
+    assert F_._tiles_of(t.transpose(0, 1), rows) is None                          # another row order
+    assert F_._tiles_of(t.clone(), rows) is None                                  # another tensor
+    assert F_._tiles_of(t, rows + 64) is None
+    t.add_(1.0)                                                                   # in-place accumulation
+    assert F_._tiles_of(t, rows) is None and F_._tiles_of(t.transpose(0, 1).transpose(0, 1), rows) is None
