@@ -71,7 +71,8 @@ __global__ void act_fwd_kernel(const T* x, T* y, int64_t n8, int act) {
 // loads in flight per thread; LDS combine over the 16 row-lanes; one fp32 atomic per column per block (<= ~200 blocks per
 // column, so the atomics are not the bottleneck).
 template <typename T, bool PART = false>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* x, int64_t ldx, float* out, int64_t rows, int64_t cols, int64_t rows_per) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* x, int64_t ldx, float* out, int64_t rows, int64_t cols, int64_t rows_per,
+                                                     const uint32_t* row_live = nullptr, uint32_t epoch = 0) {
   __shared__ float red[16][16 * 8 + 1];
   const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
   const int64_t cv = (int64_t)blockIdx.x * 16 + cl;
@@ -82,6 +83,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* x, int64_t ldx, fl
   if (ok) {
     int64_t r = r0 + g;
     for (; r + 48 < r1; r += 64) {
+      // rows_per is a multiple of 64 when stamps are given: this iteration is exactly the 64-row tile (r - g) / 64; a tile whose
+      // stamp is not this epoch holds only zero rows and adds nothing
+      if (row_live && row_live[(r - g) >> 6] != epoch) continue;
       float v0[8], v1[8], v2[8], v3[8];
       load8(x + r * ldx + cv * 8, v0);
       load8(x + (r + 16) * ldx + cv * 8, v1);
@@ -257,7 +261,7 @@ static void colsum_grid(int64_t rows, int64_t cols, int64_t& cblocks, int64_t& n
   int64_t chunks = cst_ceil_div(1536, cblocks);  // ~1536 workgroups in total
   if (chunks > cst_ceil_div(rows, 64)) chunks = cst_ceil_div(rows, 64);
   if (chunks < 1) chunks = 1;
-  rows_per = cst_ceil_div(rows, chunks);
+  rows_per = cst_ceil_div(cst_ceil_div(rows, chunks), 64) * 64;  // whole 64-row tiles per chunk (live-tile stamps)
   nchunks = cst_ceil_div(rows, rows_per);
 }
 
@@ -268,8 +272,8 @@ extern "C" int64_t cst_colsum_workspace(int64_t rows, int64_t cols) {
   return nc * cols * (int64_t)sizeof(float);
 }
 
-extern "C" int cst_colsum_typed(const void* x, int64_t ldx, void* out, void* workspace, int64_t rows, int64_t cols, int dtype,
-                                int out_dtype, cst_stream stream) {
+static int colsum_typed_impl(const void* x, int64_t ldx, void* out, void* workspace, int64_t rows, int64_t cols, int dtype,
+                             int out_dtype, const uint32_t* row_live, uint32_t epoch, cst_stream stream) {
   CST_REQUIRE(x && out && workspace && rows > 0 && cols > 0 && cols % 8 == 0 && ldx % 8 == 0, "cst_colsum_typed: cols/ldx must be multiples of 8");
   CST_REQUIRE((dtype == CST_F32 || dtype == CST_BF16) && (out_dtype == CST_F32 || out_dtype == CST_BF16), "cst_colsum_typed: bad dtype");
   hipStream_t s = (hipStream_t)stream;
@@ -278,12 +282,23 @@ extern "C" int cst_colsum_typed(const void* x, int64_t ldx, void* out, void* wor
   colsum_grid(rows, cols, cblocks, nchunks, rows_per);
   dim3 grid((unsigned)cblocks, (unsigned)nchunks);
   float* part = (float*)workspace;
-  if (dtype == CST_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)x, ldx, part, rows, cols, rows_per);
-  else hipLaunchKernelGGL((colsum_kernel<float, true>), grid, dim3(256), 0, s, (const float*)x, ldx, part, rows, cols, rows_per);
+  if (dtype == CST_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)x, ldx, part, rows, cols, rows_per, row_live, epoch);
+  else hipLaunchKernelGGL((colsum_kernel<float, true>), grid, dim3(256), 0, s, (const float*)x, ldx, part, rows, cols, rows_per, row_live, epoch);
   const dim3 rgrid((unsigned)cst_ceil_div(cols, 16));
   if (out_dtype == CST_BF16) hipLaunchKernelGGL(colsum_reduce_kernel<bf16_t>, rgrid, dim3(1024), 0, s, (const float*)part, (bf16_t*)out, (int)nchunks, cols);
   else hipLaunchKernelGGL(colsum_reduce_kernel<float>, rgrid, dim3(1024), 0, s, (const float*)part, (float*)out, (int)nchunks, cols);
   return cst_check_launch("cst_colsum_typed");
+}
+
+extern "C" int cst_colsum_typed(const void* x, int64_t ldx, void* out, void* workspace, int64_t rows, int64_t cols, int dtype,
+                                int out_dtype, cst_stream stream) {
+  return colsum_typed_impl(x, ldx, out, workspace, rows, cols, dtype, out_dtype, nullptr, 0, stream);
+}
+
+extern "C" int cst_colsum_typed_live(const void* x, int64_t ldx, void* out, void* workspace, int64_t rows, int64_t cols, int dtype,
+                                     int out_dtype, const uint32_t* row_live, uint32_t epoch, cst_stream stream) {
+  CST_REQUIRE(row_live && epoch != 0, "cst_colsum_typed_live: stamps / non-zero epoch required");
+  return colsum_typed_impl(x, ldx, out, workspace, rows, cols, dtype, out_dtype, row_live, epoch, stream);
 }
 
 extern "C" int cst_col2im1d(const void* dcol, const void* z, void* dx, int64_t B, int64_t Lin, int64_t Lout, int64_t C, int k,

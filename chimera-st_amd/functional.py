@@ -117,7 +117,7 @@ def _linear_backward(ctx, dy, dxp):
         K.gemm(dz, x2, dw, Np, Kd, M, a_kmajor=0, b_kmajor=0, lda=Np, ldb=Kd, ldc=Kd, split_k=-1, k_live=live)
         dw = dw[:N]
     if ctx.has_bias and ctx.needs_input_grad[2]:
-        db = K.colsum(dz, w.dtype)[:N]
+        db = K.colsum(dz, w.dtype, live)[:N]
     if ctx.has_resid and ctx.needs_input_grad[3]:
         dres = dy
     return dx, dw, db, dres, None, None, None
@@ -195,7 +195,7 @@ class _FFNFn(torch.autograd.Function):
             dw2 = torch.empty(dout, F_, dtype=w2.dtype, device=w2.device)
             K.gemm(dy2, h, dw2, dout, F_, M, a_kmajor=0, b_kmajor=0, lda=dout, ldb=F_, ldc=F_, split_k=-1, k_live=live)
         if has_b2 and ctx.needs_input_grad[4]:
-            db2 = K.colsum(dy2, w2.dtype)
+            db2 = K.colsum(dy2, w2.dtype, live)
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, d, dtype=x2.dtype, device=x2.device)
             K.gemm(dz1, w1, dx, M, d, F_, a_kmajor=1, b_kmajor=0, lda=F_, ldb=d, ldc=d, split_k=1,
@@ -205,7 +205,7 @@ class _FFNFn(torch.autograd.Function):
             dw1 = torch.empty(F_, d, dtype=w1.dtype, device=w1.device)
             K.gemm(dz1, x2, dw1, F_, d, M, a_kmajor=0, b_kmajor=0, lda=F_, ldb=d, ldc=d, split_k=-1, k_live=live)
         if has_b1 and ctx.needs_input_grad[2]:
-            db1 = K.colsum(dz1, w1.dtype)
+            db1 = K.colsum(dz1, w1.dtype, live)
         dres = dy if has_res and ctx.needs_input_grad[5] and not (ctx.res_is_x and ctx.needs_input_grad[0]) else None
         return dx, dw1, db1, dw2, db2, dres, None, None, None, None, None
 

@@ -288,7 +288,7 @@ def act_fwd(x, act):
     return y
 
 
-def colsum(x, out_dtype=torch.float32):
+def colsum(x, out_dtype=torch.float32, live=None):
     """Column sums (bias gradients) in `out_dtype`: row-chunk fp32 partials + a fixed-order reduce that writes the parameter
     dtype (cst_colsum_typed) — deterministic, and two launches where the atomics version needs three (zero-fill, kernel, dtype
     conversion).  (A single-launch variant with a last-arriving-block finalize was measured earlier: the agent-scope release
@@ -298,6 +298,11 @@ def colsum(x, out_dtype=torch.float32):
     lib = L.load()
     out = torch.empty(cols, dtype=out_dtype, device=x.device)
     ws = workspace(lib.cst_colsum_workspace(rows, cols), x.device)
+    if live is not None:  # (stamps, epoch) of x's 64-row tiles: dead tiles are all zero and skipped
+        assert live[0].numel() * 64 >= rows
+        L.check(lib.cst_colsum_typed_live(L.ptr(x), x.stride(0), L.ptr(out), L.ptr(ws), rows, cols, L.dtype_code(x.dtype),
+                                          L.dtype_code(out_dtype), L.ptr(live[0]), live[1], L.stream_ptr()), "cst_colsum_typed_live")
+        return out
     L.check(lib.cst_colsum_typed(L.ptr(x), x.stride(0), L.ptr(out), L.ptr(ws), rows, cols, L.dtype_code(x.dtype), L.dtype_code(out_dtype),
                                  L.stream_ptr()), "cst_colsum_typed")
     return out

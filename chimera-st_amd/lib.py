@@ -107,6 +107,7 @@ SYMBOLS = [
     ("cst_colsum", c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_int, c_p]),
     ("cst_colsum_workspace", c_i64, [c_i64, c_i64]),
     ("cst_colsum_typed", c_int, [c_p, c_i64, c_p, c_p, c_i64, c_i64, c_int, c_int, c_p]),
+    ("cst_colsum_typed_live", c_int, [c_p, c_i64, c_p, c_p, c_i64, c_i64, c_int, c_int, c_p, ctypes.c_uint32, c_p]),
     ("cst_col2im1d", c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, c_p]),
     ("cst_mask_rows", c_int, [c_p, c_p, c_p, c_i64, c_i64, c_int, c_p]),
     ("cst_dropout", c_int, [c_p, c_p, c_i64, c_f, ctypes.c_uint32, c_int, c_p]),

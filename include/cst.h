@@ -229,6 +229,9 @@ int cst_colsum(const void* x, int64_t ldx, float* out, int64_t rows, int64_t col
 int64_t cst_colsum_workspace(int64_t rows, int64_t cols);
 int cst_colsum_typed(const void* x, int64_t ldx, void* out, void* workspace, int64_t rows, int64_t cols, int dtype, int out_dtype,
                      cst_stream stream);
+/* the same with live-tile stamps of x's rows (cst_layernorm_bwd_tiles): 64-row tiles whose stamp != epoch are all zero and skipped */
+int cst_colsum_typed_live(const void* x, int64_t ldx, void* out, void* workspace, int64_t rows, int64_t cols, int dtype,
+                          int out_dtype, const uint32_t* row_live, uint32_t epoch, cst_stream stream);
 /* gradient of a strided conv1d input from the column-gradient rows of the implicit GEMM:
  * dx[b, l, c] = sum_{t,j : t*stride + j = l} dcol[b, t, j*C + c];  optionally multiplied by
  * act'(z[b,l,c]) (GELU of the previous conv layer).  dcol [B, Lout, k*C]; dx/z [B, Lin, C]. */

@@ -510,6 +510,7 @@ def test_gemm_live_k_tiles_skip(K, dt):
     ntile = (rows + 63) // 64
     live_ref = torch.stack([nz_row[i * 64:(i + 1) * 64].any() for i in range(ntile)])
     assert torch.equal(stamps == epoch, live_ref) and 0 < int(live_ref.sum()) < ntile
+    assert torch.equal(k.colsum(dx, dt, (stamps, epoch)), k.colsum(dx, dt))  # bias gradient: dead tiles skipped, same bits
     h = rnd(rows, F_, dt=dt, seed=5)
     n0 = Kn.STATS.get("gemm_k_live", 0)
     for split in (-1, 1, 3):
