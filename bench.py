@@ -240,7 +240,7 @@ def main():
         roof["algorithmic_bytes"] = r["bytes"] / max(r["launches"], 1)
         # HBM-side traffic of the same launches from the committed PMC pass of this command (counters need their own rocprofv3
         # run and cannot be read inside the timed process); only quoted for the workload it was collected on
-        pmc = os.path.join(ROOT, "profiles", "r01d_pmc_gemm_class.json")
+        pmc = os.path.join(ROOT, "profiles", "r01f_pmc_gemm_class.json")
         if name == "gemm" and os.path.exists(pmc) and args.model == "s2t_w2v2" and args.batch == 32 and args.seconds == 30.0 and args.dtype == "bf16":
             rec = json.load(open(pmc))
             if abs(rec["gemm_class_launches_per_update"] - r["launches"]) <= 8:
