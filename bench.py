@@ -119,15 +119,20 @@ def dominant_gemm_launch(args, device):
     return out
 
 
+def oracle_cfg(ns):
+    """The oracle's config dict for the model `build` made (checker side only: cpu_baseline and tests/test_fullsize_gpu.py)."""
+    wa = importlib.import_module("chimera-st_amd.w2v2_transformer").SYNTHETIC_W2V["wav2vec_small_bench"]
+    return dict(conv_layers=eval(wa.conv_feature_layers), conv_pos=wa.conv_pos, conv_pos_groups=wa.conv_pos_groups,
+                w2v_layers=wa.encoder_layers, w2v_heads=wa.encoder_attention_heads, feature_grad_mult=wa.feature_grad_mult,
+                d=ns.encoder_embed_dim, heads=ns.encoder_attention_heads, dec_heads=ns.decoder_attention_heads,
+                enc_layers=ns.encoder_layers, dec_layers=ns.decoder_layers, mem_layers=getattr(ns, "interlingua_layers", 0))
+
+
 def cpu_baseline(trainer, task, tasks, ns, args):
     """The oracle (CPU fp32 restatement pinned to the reference, oracle/chimera_oracle.py) timed on this box's host
     cores on a bounded sample of the same workload: ONE full update (fwd + bwd + Adam) on one 30 s utterance."""
     from oracle import chimera_oracle as O
-    wa = importlib.import_module("chimera-st_amd.w2v2_transformer").SYNTHETIC_W2V["wav2vec_small_bench"]
-    cfg = dict(conv_layers=eval(wa.conv_feature_layers), conv_pos=wa.conv_pos, conv_pos_groups=wa.conv_pos_groups,
-               w2v_layers=wa.encoder_layers, w2v_heads=wa.encoder_attention_heads, feature_grad_mult=wa.feature_grad_mult,
-               d=ns.encoder_embed_dim, heads=ns.encoder_attention_heads, dec_heads=ns.decoder_attention_heads,
-               enc_layers=ns.encoder_layers, dec_layers=ns.decoder_layers, mem_layers=getattr(ns, "interlingua_layers", 0))
+    cfg = oracle_cfg(ns)
     p = {k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point() and "_float_tensor" not in k and k != "decoder.version")
          for k, v in trainer.get_model().state_dict().items()}
     p["decoder.output_projection.weight"] = p["decoder.embed_tokens.weight"]

@@ -177,6 +177,7 @@ def attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, layout_q="bt", layout_k
     if kv_len is not None:
         assert kpm is not None and kv_len.dtype == torch.int32 and kv_len.numel() == B and kv_len.is_contiguous()
         d.kv_len = kv_len.data_ptr()
+        STATS["attn_kv_len"] = STATS.get("attn_kv_len", 0) + 1
     else:
         d.kv_len = None
     return d
@@ -216,6 +217,7 @@ def attn_bwd_fill(d, do, dq, dk, dv, delta, D, layout_q="bt", layout_kv="bt"):
     # live-tile flags (cst_attn_desc.q_flags): the backward stops at the last 64-query tile with a non-zero upstream gradient
     flags = torch.empty(int(d.B) * int(d.H) * ((int(d.Tq) + 63) // 64), dtype=torch.uint8, device=do.device)
     d.q_flags = flags.data_ptr()
+    STATS["attn_q_flags"] = STATS.get("attn_q_flags", 0) + 1
     d._q_flags_owner = flags  # the workspace lives as long as the descriptor (i.e. until the launch has been enqueued)
 
 

@@ -206,15 +206,35 @@ class Wav2Vec2Model(nn.Module):
         self.feature_grad_mult = args.feature_grad_mult
         self.dropout_input_p = getattr(args, "dropout_input", 0)
         final_dim = args.final_dim if args.final_dim > 0 else args.encoder_embed_dim
-        # registration ORDER follows wav2vec2.py:306-420 (post_extract_proj, project_q, encoder, layer_norm, final_proj):
-        # model.parameters() order is the index space of the reference's optimizer state (checkpoint interop)
-        # pre-training heads (project_q, final_proj): never on the ST path, kept for checkpoint compatibility
-        self.project_q = Linear(self.embed, final_dim) if not getattr(args, "quantize_targets", False) else None
+        # registration ORDER follows wav2vec2.py:306-420 (post_extract_proj, quantizer, project_q, [input_quantizer, project_inp],
+        # mask_emb, encoder, layer_norm, [target_glu], final_proj): model.parameters() order is the index space of the
+        # reference's optimizer state and state_dict() its key set (checkpoint interop).  The pre-training heads
+        # (quantizer, project_q, final_proj, ...) are never on the ST path; they are instantiated as inert parameters with the
+        # reference's shapes so that real checkpoints (wav2vec_small: quantize_targets=True) load with strict=True through
+        # ANY enclosing module, are re-emitted by state_dict(), and keep every later optimizer-state index where the
+        # reference has it.
+        self.quantizer = self.input_quantizer = self.project_inp = self.target_glu = None
+        if getattr(args, "quantize_targets", False):
+            vq_dim = args.latent_dim if getattr(args, "latent_dim", 0) > 0 else final_dim
+            self.quantizer = _InertGumbelVectorQuantizer(self.embed, args.latent_vars, args.latent_groups, vq_dim)
+            self.project_q = Linear(vq_dim, final_dim)
+        else:
+            self.project_q = Linear(self.embed, final_dim)
+        if getattr(args, "quantize_input", False):
+            if getattr(args, "same_quantizer", False) and self.quantizer is not None:
+                vq_dim = final_dim
+                self.input_quantizer = self.quantizer
+            else:
+                vq_dim = args.latent_dim if getattr(args, "latent_dim", 0) > 0 else args.encoder_embed_dim
+                self.input_quantizer = _InertGumbelVectorQuantizer(self.embed, args.latent_vars, args.latent_groups, vq_dim)
+            self.project_inp = Linear(vq_dim, args.encoder_embed_dim)
+            raise NotImplementedError("quantize_input wav2vec2 models feed the quantised features to the encoder: not on the ST path")
         self.mask_emb = nn.Parameter(torch.FloatTensor(args.encoder_embed_dim).uniform_())
         self.encoder = TransformerEncoder(args)
         self.layer_norm = LayerNorm(self.embed)
+        if getattr(args, "target_glu", False):
+            self.target_glu = nn.Sequential(Linear(final_dim, final_dim * 2), nn.GLU())
         self.final_proj = Linear(args.encoder_embed_dim, final_dim)
-        self._passthrough_state = {}
 
     @classmethod
     def build_model(cls, args, task=None):
@@ -226,9 +246,10 @@ class Wav2Vec2Model(nn.Module):
         if self.training:
             # pre-training-only parameters never receive a gradient on this path: without this the gradient bucket that holds
             # final_proj (the FIRST wav2vec2 bucket in backward order) would wait for finish() and un-overlap every later one
-            heads = [self.mask_emb] + list(self.final_proj.parameters())
-            if self.project_q is not None:
-                heads += list(self.project_q.parameters())
+            heads = [self.mask_emb] + list(self.final_proj.parameters()) + list(self.project_q.parameters())
+            for m in (self.quantizer, self.target_glu):
+                if m is not None:
+                    heads += list(m.parameters())
             notify_unused_parameters(heads)
         nz_last = None
         if padding_mask is not None and self.training:
@@ -265,14 +286,21 @@ class Wav2Vec2Model(nn.Module):
         res = self.forward(source, padding_mask, mask=mask, features_only=True)
         return res["x"], res["padding_mask"]
 
-    def load_state_dict(self, state_dict, strict=True):
-        """Accept full pre-training checkpoints: quantizer.* / project_q etc. that this build does not instantiate
-        are parked and re-emitted by state_dict()."""
-        own = set(super().state_dict().keys())
-        extra = {k: v for k, v in state_dict.items() if k not in own}
-        self._passthrough_state = {k: v for k, v in extra.items() if k.split(".")[0] in ("quantizer", "input_quantizer", "project_inp", "target_glu", "project_q")}
-        rest = {k: v for k, v in state_dict.items() if k not in self._passthrough_state}
-        return super().load_state_dict(rest, strict=strict)
+class _InertGumbelVectorQuantizer(nn.Module):
+    """Parameter shapes of modules/gumbel_vector_quantizer.py:12-76 (combine_groups=False, weight_proj_depth=1): `vars`
+    [1, groups * num_vars, vq_dim / groups] and `weight_proj` Linear(dim, groups * num_vars).  Pre-training only (the
+    contrastive targets): never called on the ST path."""
+
+    def __init__(self, dim, num_vars, groups, vq_dim):
+        super().__init__()
+        assert vq_dim % groups == 0
+        self.vars = nn.Parameter(torch.FloatTensor(1, groups * num_vars, vq_dim // groups).uniform_())
+        self.weight_proj = nn.Linear(dim, groups * num_vars)
+        nn.init.normal_(self.weight_proj.weight, mean=0, std=1)
+        nn.init.zeros_(self.weight_proj.bias)
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("the wav2vec2 quantizer is a pre-training module; the ST path never calls it")
 
 
 class _GradMultiply(torch.autograd.Function):

@@ -30,6 +30,42 @@ P = Dict[str, torch.Tensor]
 
 NEG_INF = float("-inf")
 
+# Storage-rounding emulation (tests/test_fullsize_gpu.py, bf16 check): with STORAGE = torch.bfloat16 every tensor the HIP path
+# keeps in HBM in the storage dtype — projection / conv / LayerNorm / activation outputs, residual sums, attention
+# probabilities and outputs, embeddings — is rounded to that dtype here too, forward AND backward (the gradient of a stored
+# tensor is itself stored), while every reduction stays fp32 exactly as the kernels accumulate.  None (default) = the plain
+# fp32 restatement that the golden fixtures pin; the emulation shows how much of a bf16-vs-fp32 gap is storage rounding.
+STORAGE = None
+
+
+class _RoundStored(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(STORAGE).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(STORAGE).to(g.dtype)
+
+
+class _RoundFwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(STORAGE).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _st(x):
+    return x if STORAGE is None else _RoundStored.apply(x)
+
+
+def _st_fwd(x):
+    """Rounded where it is consumed (MFMA operand), but its gradient never leaves fp32 registers (attention's dP)."""
+    return x if STORAGE is None else _RoundFwd.apply(x)
+
 
 # --------------------------------------------------------------------------------------------
 # small helpers
@@ -46,17 +82,17 @@ def layer_norm(x, w, b, eps=1e-5):
     """modules/layer_norm.py:30-35 (torch.nn.LayerNorm, eps 1e-5, affine), written out."""
     mu = x.mean(-1, keepdim=True)
     var = ((x - mu) ** 2).mean(-1, keepdim=True)
-    return (x - mu) * torch.rsqrt(var + eps) * w + b
+    return _st((x - mu) * torch.rsqrt(var + eps) * w + b)
 
 
 def gelu(x):
     """modules/gelu.py:25 / nn.GELU — exact erf form."""
-    return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
+    return _st(0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0)))))
 
 
 def linear(x, w, b=None):
     y = x.matmul(w.t())
-    return y if b is None else y + b
+    return _st(y if b is None else y + b)
 
 
 def sinusoidal_table(num: int, dim: int, padding_idx: Optional[int]) -> torch.Tensor:
@@ -113,8 +149,8 @@ def mha(p: P, pre: str, query, key, value, num_heads: int,
     if key_padding_mask is not None:
         w = w.view(bsz, num_heads, tq, tk).masked_fill(
             key_padding_mask.unsqueeze(1).unsqueeze(2).to(torch.bool), NEG_INF).view(bsz * num_heads, tq, tk)
-    w = torch.softmax(w.float(), dim=-1).type_as(w)
-    a = torch.bmm(w, v)
+    w = _st_fwd(torch.softmax(w.float(), dim=-1).type_as(w))  # the kernels feed P to the PV MFMA in the storage dtype
+    a = _st(torch.bmm(w, v))
     a = a.transpose(0, 1).contiguous().view(tq, bsz, c)
     return linear(a, p[pre + "out_proj.weight"], p[pre + "out_proj.bias"])
 
@@ -129,6 +165,8 @@ def conv_feature_extractor(p: P, pre: str, wav: torch.Tensor, conv_layers: List[
     x = wav.unsqueeze(1)
     for i, (dim, k, s) in enumerate(conv_layers):
         x = F.conv1d(x, p["%sconv_layers.%d.0.weight" % (pre, i)], None, stride=s)
+        if i > 0:
+            x = _st(x)  # layer 0 keeps conv -> GroupNorm -> GELU in fp32 registers (cst_conv0_gn_gelu_fwd)
         if i == 0:
             # GroupNorm with one channel per group: statistics per (b, c) over time, fp32, eps 1e-5
             mu = x.mean(-1, keepdim=True)
@@ -173,12 +211,12 @@ def w2v2_sentence_layer(p: P, pre: str, x, padding_mask, heads: int):
     """TransformerSentenceEncoderLayer.forward, post-norm branch (wav2vec2.py:937-957)."""
     res = x
     x = mha(p, pre + "self_attn.", x, x, x, heads, key_padding_mask=padding_mask)
-    x = res + x
+    x = _st(res + x)
     x = layer_norm(x, p[pre + "self_attn_layer_norm.weight"], p[pre + "self_attn_layer_norm.bias"])
     res = x
     x = gelu(linear(x, p[pre + "fc1.weight"], p[pre + "fc1.bias"]))
     x = linear(x, p[pre + "fc2.weight"], p[pre + "fc2.bias"])
-    x = res + x
+    x = _st(res + x)
     return layer_norm(x, p[pre + "final_layer_norm.weight"], p[pre + "final_layer_norm.bias"])
 
 
@@ -207,7 +245,7 @@ def w2v2_extract_features(p: P, pre: str, wav, padding_mask, cfg) -> Tuple[torch
                   padding=kpos // 2, groups=cfg["conv_pos_groups"])  # :773-779
     if kpos % 2 == 0:
         xc = xc[:, :, :-1]  # SamePad (modules/same_pad.py)
-    x = x + gelu(xc).transpose(1, 2)  # :823-825
+    x = _st(x + gelu(xc).transpose(1, 2))  # :823-825
     x = layer_norm(x, p[e + "layer_norm.weight"], p[e + "layer_norm.bias"])  # :827-828
     x = x.transpose(0, 1)
     for i in range(cfg["w2v_layers"]):
@@ -226,9 +264,9 @@ def conv1d_subsampler(p: P, pre: str, x, lengths, n_layers=2):
     x = x.transpose(1, 2).contiguous()
     for i in range(n_layers):
         w = p["%sconv_layers.%d.weight" % (pre, i)]
-        x = F.conv1d(x, w, p["%sconv_layers.%d.bias" % (pre, i)], stride=2, padding=w.size(2) // 2)
+        x = _st(F.conv1d(x, w, p["%sconv_layers.%d.bias" % (pre, i)], stride=2, padding=w.size(2) // 2))
         a, g = x.chunk(2, dim=1)
-        x = a * torch.sigmoid(g)  # F.glu(dim=1)
+        x = _st(a * torch.sigmoid(g))  # F.glu(dim=1)
     out = lengths.clone()
     for _ in range(n_layers):
         out = ((out.float() - 1) / 2 + 1).floor().long()
@@ -243,12 +281,12 @@ def encoder_layer(p: P, pre: str, x, padding_mask, heads: int, attn_mask=None, k
     res = x
     h = layer_norm(x, p[pre + "self_attn_layer_norm.weight"], p[pre + "self_attn_layer_norm.bias"])
     h = mha(p, pre + "self_attn.", h, h, h, heads, key_padding_mask=padding_mask, attn_mask=attn_mask)
-    x = res + h
+    x = _st(res + h)
     res = x
     h = layer_norm(x, p[pre + "final_layer_norm.weight"], p[pre + "final_layer_norm.bias"])
     h = torch.relu(linear(h, p[pre + "fc1.weight"], p[pre + "fc1.bias"]))
     h = linear(h, p[pre + "fc2.weight"], p[pre + "fc2.bias"])
-    return res + h
+    return _st(res + h)
 
 
 def audio_frontend(p: P, wav, src_lengths, cfg):
@@ -272,10 +310,10 @@ def chimera_encoder(p: P, src_tokens, src_lengths, cfg):
         lens = src_lengths
     else:
         feat, lens, inter = audio_frontend(p, src_tokens, src_lengths, cfg)
-    x = math.sqrt(d) * feat  # :231
+    x = _st(math.sqrt(d) * feat)  # :231
     pm = lengths_to_padding_mask(lens, max_len=x.size(0))
     if is_text:  # Q3: only text gets positions (:233-236)
-        x = x + positional_embedding(pm, d, 1).transpose(0, 1)
+        x = _st(x + positional_embedding(pm, d, 1).transpose(0, 1))
     for i in range(cfg["enc_layers"]):
         x = encoder_layer(p, "encoder.transformer_layers.%d." % i, x, pm, heads)
     inter["enc_layer_last"] = x
@@ -303,11 +341,27 @@ def s2t_w2v2_encoder(p: P, wav, src_lengths, cfg):
     x, lens, inter = audio_frontend(p, wav, src_lengths, cfg)
     x = math.sqrt(d) * x
     pm = lengths_to_padding_mask(lens, max_len=x.size(0))
-    x = x + positional_embedding(pm, d, 1).transpose(0, 1)
+    x = _st(x + positional_embedding(pm, d, 1).transpose(0, 1))
     for i in range(cfg["enc_layers"]):
         x = encoder_layer(p, "encoder.transformer_layers.%d." % i, x, pm, heads)
     x = layer_norm(x, p["encoder.layer_norm.weight"], p["encoder.layer_norm.bias"])
     return x, (pm if pm.any() else None), inter
+
+
+def s2t_encoder(p: P, feats, src_lengths, cfg):
+    """S2TTransformerEncoder.forward (models/speech_to_text/s2t_transformer.py:313-345): filter-bank input [B,T,F] ->
+    Conv1dSubsampler -> x sqrt(d) + sinusoidal positions -> pre-norm layers -> LayerNorm; the padding mask is dropped
+    when no frame is padded (:335-336)."""
+    d, heads = cfg["d"], cfg["heads"]
+    x, lens = conv1d_subsampler(p, "encoder.subsample.", feats, src_lengths)
+    x = math.sqrt(d) * x
+    pm = lengths_to_padding_mask(lens, max_len=x.size(0))
+    x = _st(x + positional_embedding(pm, d, 1).transpose(0, 1))
+    for i in range(cfg["enc_layers"]):
+        x = encoder_layer(p, "encoder.transformer_layers.%d." % i, x, pm, heads)
+    if "encoder.layer_norm.weight" in p:
+        x = layer_norm(x, p["encoder.layer_norm.weight"], p["encoder.layer_norm.bias"])
+    return x, (pm if pm.any() else None)
 
 
 # --------------------------------------------------------------------------------------------
@@ -318,16 +372,16 @@ def decoder_layer(p: P, pre: str, x, enc, enc_pm, heads, self_mask, self_pm):
     res = x
     h = layer_norm(x, p[pre + "self_attn_layer_norm.weight"], p[pre + "self_attn_layer_norm.bias"])
     h = mha(p, pre + "self_attn.", h, h, h, heads, key_padding_mask=self_pm, attn_mask=self_mask)
-    x = res + h
+    x = _st(res + h)
     res = x
     h = layer_norm(x, p[pre + "encoder_attn_layer_norm.weight"], p[pre + "encoder_attn_layer_norm.bias"])
     h = mha(p, pre + "encoder_attn.", h, enc, enc, heads, key_padding_mask=enc_pm)
-    x = res + h
+    x = _st(res + h)
     res = x
     h = layer_norm(x, p[pre + "final_layer_norm.weight"], p[pre + "final_layer_norm.bias"])
     h = torch.relu(linear(h, p[pre + "fc1.weight"], p[pre + "fc1.bias"]))
     h = linear(h, p[pre + "fc2.weight"], p[pre + "fc2.bias"])
-    return res + h
+    return _st(res + h)
 
 
 def decoder(p: P, prev_output_tokens, enc, enc_pm, cfg, return_features=False):
@@ -336,7 +390,7 @@ def decoder(p: P, prev_output_tokens, enc, enc_pm, cfg, return_features=False):
     d, heads = cfg["d"], cfg["dec_heads"]
     emb = p["decoder.embed_tokens.weight"]
     x = math.sqrt(d) * F.embedding(prev_output_tokens, emb, padding_idx=1)  # Embedding(..., padding_idx) (transformer.py:906-911): pad row gets no grad
-    x = x + positional_embedding(prev_output_tokens, d, 1)
+    x = _st(x + positional_embedding(prev_output_tokens, d, 1))
     x = x.transpose(0, 1)
     self_pm = prev_output_tokens.eq(1) if prev_output_tokens.eq(1).any() else None
     U = x.size(0)
@@ -347,7 +401,7 @@ def decoder(p: P, prev_output_tokens, enc, enc_pm, cfg, return_features=False):
     feats = x
     x = x.transpose(0, 1)
     out_w = p.get("decoder.output_projection.weight", emb)
-    logits = x.matmul(out_w.t())
+    logits = _st(x.matmul(out_w.t()))
     return (logits, feats) if return_features else logits
 
 
@@ -417,6 +471,22 @@ def lsce_criterion(p: P, sample: dict, cfg, eps=0.1):
     """LabelSmoothedCrossEntropyCriterion.forward (criterions/label_smoothed_cross_entropy.py:56-86)."""
     ni = sample["net_input"]
     logits, enc, enc_pm = s2t_w2v2_forward(p, ni["src_tokens"], ni["src_lengths"], ni["prev_output_tokens"], cfg)
+    loss, nll = label_smoothed_nll_loss(logits, sample["target"], eps)
+    return dict(loss=loss, nll_loss=nll, logits=logits, encoder_out=enc, encoder_padding_mask=enc_pm,
+                sample_size=sample["ntokens"])
+
+
+def s2t_forward(p: P, feats, src_lengths, prev_output_tokens, cfg):
+    """S2TTransformerModel.forward (models/speech_to_text/s2t_transformer.py:252-262)."""
+    enc, enc_pm = s2t_encoder(p, feats, src_lengths, cfg)
+    return decoder(p, prev_output_tokens, enc, enc_pm, cfg), enc, enc_pm
+
+
+def lsce_criterion_s2t(p: P, sample: dict, cfg, eps=0.1):
+    """label_smoothed_cross_entropy on the stock s2t_transformer (BASELINE config 1 / 5 model family): the criterion's
+    compute_loss (label_smoothed_cross_entropy.py:87-108) over model(src_tokens, src_lengths, prev_output_tokens)."""
+    ni = sample["net_input"]
+    logits, enc, enc_pm = s2t_forward(p, ni["src_tokens"], ni["src_lengths"], ni["prev_output_tokens"], cfg)
     loss, nll = label_smoothed_nll_loss(logits, sample["target"], eps)
     return dict(loss=loss, nll_loss=nll, logits=logits, encoder_out=enc, encoder_padding_mask=enc_pm,
                 sample_size=sample["ntokens"])

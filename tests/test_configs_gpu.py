@@ -1,0 +1,261 @@
+"""BASELINE.json configs that round 1 left without a GPU test:
+
+  config 1  `s2t_transformer_s`, 8 x 10 s, one training step — (a) the stock filter-bank model at its full `_s` dimensions through
+            the Trainer, (b) its wav-input variant `s2t_transformer_w2v2_s` on 8 x 10 s 16 kHz WAV files through the command-line
+            driver (cli.train_main: manifest -> batches -> one update), both against the oracle on the same batch and parameters;
+  config 5  `s2t_transformer_l` at FULL depth (12 encoder + 6 decoder layers, d 1024, 16 heads, ffn 4096), B = 32 x beam 5:
+            the device-resident engine == the module-by-module host loop on every token id (fp32), and == oracle.beam_search on a
+            2-sentence slice;
+  and the stock-model fixtures of the real reference (tests/golden/s2t_fbank_tiny.npz: forward, loss, every gradient, beam 1 / 5)."""
+import ast
+import json
+import math
+import os
+import struct
+import wave
+from argparse import Namespace
+from importlib import import_module
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden_sample, load_golden, load_pkg
+from parity_util import cpu_sample, max_abs_rel, run_oracle
+from test_model_gpu import assert_close, to_cuda
+
+pytestmark = pytest.mark.gpu
+
+
+def _s2t_cfg(args):
+    return dict(d=args.encoder_embed_dim, heads=args.encoder_attention_heads, dec_heads=args.decoder_attention_heads,
+                enc_layers=args.encoder_layers, dec_layers=args.decoder_layers)
+
+
+def _build_stock(arch, V, dtype=torch.float32, seed=1, **over):
+    load_pkg()
+    s2t = import_module("chimera-st_amd.s2t_transformer")
+    reg = import_module("chimera-st_amd.registry")
+    tasks = import_module("chimera-st_amd.tasks")
+    torch.manual_seed(seed)
+    task = tasks.SpeechToTextTask(Namespace(data=None, synthetic_vocab_size=V))
+    args = Namespace(arch=arch, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, share_decoder_input_output_embed=True,
+                     input_feat_per_channel=80, input_channels=1, **over)
+    reg.ARCH_CONFIG_REGISTRY[arch](args)
+    model = s2t.S2TTransformerModel.build_model(args, task)
+    return model.to("cuda", dtype), task, args
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+def test_stock_s2t_golden_forward_backward_and_decode():
+    """tests/golden/s2t_fbank_tiny.npz — produced by the reference's own S2TTransformerModel / SequenceGenerator."""
+    g = load_golden("s2t_fbank_tiny.npz")
+    m = ast.literal_eval(str(g["meta/model_args"]))
+    load_pkg()
+    s2t = import_module("chimera-st_amd.s2t_transformer")
+    tasks = import_module("chimera-st_amd.tasks")
+    V = g["param/decoder.embed_tokens.weight"].shape[0]
+    task = tasks.SpeechToTextTask(Namespace(data=None, synthetic_vocab_size=V))
+    model = s2t.S2TTransformerModel.build_model(Namespace(**m), task)
+    sd = {k[len("param/"):]: torch.from_numpy(np.array(v)) for k, v in g.items() if k.startswith("param/")}
+    assert set(model.state_dict().keys()) == set(sd.keys())
+    model.load_state_dict(sd)
+    model = model.cuda().train()
+    sample = to_cuda(golden_sample(g))
+    crit = import_module("chimera-st_amd.criterions").LabelSmoothedCrossEntropyCriterion(task, False, 0.1)
+    enc = model.encoder(sample["net_input"]["src_tokens"], sample["net_input"]["src_lengths"])
+    assert_close(enc.encoder_out, g["out/encoder_out"], 1e-3, "encoder_out")
+    loss, sample_size, log = crit(model, sample)  # the collater's `mask` kwarg is accepted and ignored (quirk Q6)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss/loss"])) <= 1e-4 * abs(float(g["loss/loss"]))
+    logits, _ = model(**sample["net_input"])
+    assert_close(logits, g["out/logits"], 1e-3, "logits")
+    n = 0
+    for name, p in model.named_parameters():
+        assert_close(p.grad if p.grad is not None else torch.zeros_like(p), g["grad/" + name], 1e-3, "grad " + name)
+        n += 1
+    assert n > 60
+    # decode: the fitted parameters, greedy and beam 5, device engine and host loop — bit-exact token ids
+    model.load_state_dict({k[len("fit_param/"):]: torch.from_numpy(np.array(v)) for k, v in g.items() if k.startswith("fit_param/")})
+    model.eval()
+    SG = import_module("chimera-st_amd.sequence_generator").SequenceGenerator
+    s = {"net_input": {"src_tokens": sample["net_input"]["src_tokens"], "src_lengths": sample["net_input"]["src_lengths"]}}
+    for beam in (1, 5):
+        for fused in (True, False):
+            hyps = SG([model], task.target_dictionary, beam_size=beam, max_len_a=0, max_len_b=14, min_len=1, fused=fused).generate([model], s)
+            for b in range(len(hyps)):
+                for r in range(min(beam, 3)):
+                    key = "gen/beam%d/b%d/r%d/" % (beam, b, r)
+                    assert hyps[b][r]["tokens"].tolist() == g[key + "tokens"].tolist(), (key, fused)
+                    assert abs(float(hyps[b][r]["score"]) - float(g[key + "score"])) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+def test_config1_s2t_transformer_s_one_step_against_oracle():
+    """BASELINE configs[0] at the model's real dimensions (d 256, 4 heads, ffn 2048, 12 + 6 layers, V = 10 000): 8 utterances x
+    10 s of 80-dim filter banks (1000 frames), ONE Trainer.train_step (forward, backward, clip, Adam) — loss and every gradient
+    against oracle.lsce_criterion_s2t on the same parameters, and the parameters after the step against oracle.adam_step."""
+    from oracle import chimera_oracle as O
+    model, task, args = _build_stock("s2t_transformer_s", 10000)
+    targs = Namespace(**vars(args))
+    for k, v in dict(bf16=False, lr=[2e-3], adam_betas="(0.9, 0.98)", adam_eps=1e-8, weight_decay=0.0, clip_norm=10.0, warmup_updates=0,
+                     warmup_init_lr=-1, seed=1, label_smoothing=0.1, criterion="label_smoothed_cross_entropy", bucket_cap_mb=64).items():
+        setattr(targs, k, v)
+    crit = import_module("chimera-st_amd.criterions").LabelSmoothedCrossEntropyCriterion(task, False, 0.1)
+    tr = import_module("chimera-st_amd.trainer").Trainer(targs, task, model, crit, device="cuda")
+    g = torch.Generator().manual_seed(7)
+    B, T = 8, 1000
+    feats = torch.randn(B, T, 80, generator=g)
+    lens = [1000, 1000, 930, 871, 800, 640, 512, 333]
+    for b, l in enumerate(lens):
+        feats[b, l:] = 0
+    tasks = import_module("chimera-st_amd.tasks")
+    sample = tasks.synthetic_sample(task.target_dictionary, B, lens, [40, 33, 61, 17, 25, 48, 30, 22], None, seed=7, sort=False)
+    sample["net_input"]["src_tokens"] = feats
+    sd0 = {k: v.detach().cpu().clone() for k, v in tr.get_model().state_dict().items()}
+    out = tr.train_step([sample])
+    ref, rgrads = run_oracle(O.lsce_criterion_s2t, sd0, cpu_sample(sample), _s2t_cfg(args))
+    rl = float(ref["loss"])
+    assert abs(out["loss"] - rl) <= 1e-4 * abs(rl), (out["loss"], rl)
+    assert out["sample_size"] == sample["ntokens"]
+    names = [n for n, _ in tr.get_model().named_parameters()]
+    flat = tr.buffers.flat_grad
+    worst = 0.0
+    for p, o, n in zip(tr.buffers.params, tr.buffers.offsets, names):
+        e = max_abs_rel(flat[o:o + p.numel()].view(p.shape), rgrads[n] if rgrads[n] is not None else torch.zeros(p.shape))
+        worst = max(worst, e)
+        assert e <= 1e-3, "grad %s: %.3e" % (n, e)
+    # the update itself: multiply_grads(1 / sample_size), clip 10, Adam, lr 2e-3 (no warm-up)
+    grads = [(rgrads[n] if rgrads[n] is not None else torch.zeros_like(sd0[n])) / float(sample["ntokens"]) for n in names]
+    gnorm = O.clip_grad_norm_(grads, 10.0)
+    assert out["gnorm"] == pytest.approx(float(gnorm), rel=1e-3)
+    with torch.no_grad():
+        for n, gr, (_, p) in zip(names, grads, tr.get_model().named_parameters()):
+            want = sd0[n].clone().float()
+            O.adam_step(want, gr, torch.zeros_like(want), torch.zeros_like(want), 1, 2e-3, 0.9, 0.98, 1e-8, 0.0)
+            # Adam's first step moves every touched weight by ~lr * sign(g): compare where the gradient is not rounding noise
+            big = gr.abs() > 1e-3 * gr.abs().max()
+            if big.any():
+                assert float((p.detach().float().cpu() - want)[big].abs().max()) <= 2e-4, n
+    print("config 1 (s2t_transformer_s, 8 x 10 s fbank): loss %.4f vs oracle %.4f, worst gradient error %.2e" % (out["loss"], rl, worst))
+
+
+def _write_wav(path, x):
+    pcm = (np.clip(x, -1, 1) * 32767.0).astype("<i2")
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+        w.writeframes(pcm.tobytes())
+
+
+def test_config1_wav_input_one_step_through_the_driver(tmp_path, capsys):
+    """BASELINE configs[0] as written: 8 synthetic 10 s @ 16 kHz WAV files, the fairseq-train flag set, 1 update — through
+    cli.train_main (manifest -> SpeechToText dataset -> batch -> Trainer).  The stock s2t_transformer_s cannot read raw audio
+    (it takes 80-dim filter banks); `s2t_transformer_w2v2_s` is the reference's s-sized model for wav input
+    (models/chimera/w2v2_transformer.py:482-491).  The driver's logged loss must equal the oracle's loss on the same batch and
+    parameters; lr = 0 keeps the parameters at their initial values so the oracle can be run on them after the fact."""
+    from oracle import chimera_oracle as O
+    load_pkg()
+    cli = import_module("chimera-st_amd.cli")
+    w2t = import_module("chimera-st_amd.w2v2_transformer")
+    w2v = import_module("chimera-st_amd.wav2vec2")
+    w2t.SYNTHETIC_W2V["wav2vec_small_nodrop"] = w2v.wav2vec_small_args(dropout=0.0, attention_dropout=0.0, activation_dropout=0.0,
+                                                                         encoder_layerdrop=0.0, dropout_input=0.0, dropout_features=0.0)
+    root = tmp_path / "data"
+    root.mkdir()
+    rng = np.random.RandomState(3)
+    words = ["▁a", "▁cat", "▁sat", "▁on", "▁mat", "▁und", "▁die", "▁der", "en", "▁zu", "▁run"]
+    (root / "dict.txt").write_text("".join("%s 1\n" % w for w in words))
+    rows = ["id\taudio\tn_frames\ttgt_text\tsrc_text\tspeaker"]
+    for i in range(8):
+        _write_wav(str(root / ("utt%d.wav" % i)), 0.1 * rng.randn(160000))
+        tgt = " ".join(rng.choice(words, size=int(rng.randint(5, 30))))
+        rows.append("u%d\tutt%d.wav:0:160000\t160000\t%s\t%s\tspk" % (i, i, tgt, tgt))
+    (root / "train_st.tsv").write_text("\n".join(rows) + "\n")
+    (root / "config_wave.yaml").write_text("audio_root: %s\nbpe_tokenizer:\n  bpe: null\nsrc_bpe_tokenizer:\n  bpe: null\ninput_channels: 1\n"
+                                           "input_feat_per_channel: 80\nsampling_alpha: 1.0\nsrc_vocab_filename: dict.txt\n"
+                                           "use_audio_input: true\nvocab_filename: dict.txt\n" % root)
+    argv = [str(root), "--task", "speech_to_text", "--train-subset", "train_st", "--valid-subset", "train_st", "--config-yaml", "config_wave.yaml",
+            "--max-tokens", "2000000", "--max-source-positions", "2000000", "--save-dir", str(tmp_path / "ckpt"), "--no-save", "--disable-validation",
+            "--criterion", "label_smoothed_cross_entropy", "--label-smoothing", "0.1", "--arch", "s2t_transformer_w2v2_s",
+            "--share-decoder-input-output-embed", "--w2v2-model-path", "synthetic:wav2vec_small_nodrop", "--dropout", "0.0",
+            "--attention-dropout", "0.0", "--activation-dropout", "0.0", "--optimizer", "adam", "--adam-betas", "(0.9, 0.98)",
+            "--clip-norm", "10.0", "--lr", "0.0", "--lr-scheduler", "inverse_sqrt", "--warmup-updates", "0", "--max-update", "1",
+            "--seed", "1", "--log-interval", "1"]
+    tr = cli.train_main(argv)
+    ev = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    inner = [e for e in ev if e["event"] == "train_inner"]
+    assert ev[0]["event"] == "start" and ev[0]["arch"] == "s2t_transformer_w2v2_s" and ev[0]["train_examples"] == 8
+    assert tr.num_updates == 1 and len(inner) == 1
+    # the batch the driver trained on: all 8 utterances (8 x 160 000 samples <= --max-tokens), rebuilt through the same task code
+    task = tr.task
+    itr = task.get_batch_iterator(task.dataset("train_st"), max_tokens=2000000, max_positions=(2000000, 1024), ignore_invalid_inputs=True,
+                                  required_batch_size_multiple=8, seed=1)
+    batches = list(itr.next_epoch_itr(shuffle=True))
+    assert len(batches) == 1 and batches[0]["net_input"]["src_tokens"].shape == (8, 160000)
+    sample = batches[0]
+    wa = w2t.SYNTHETIC_W2V["wav2vec_small_nodrop"]
+    a = tr.args
+    cfg = dict(conv_layers=eval(wa.conv_feature_layers), conv_pos=wa.conv_pos, conv_pos_groups=wa.conv_pos_groups, w2v_layers=wa.encoder_layers,
+               w2v_heads=wa.encoder_attention_heads, feature_grad_mult=wa.feature_grad_mult, d=a.encoder_embed_dim, heads=a.encoder_attention_heads,
+               dec_heads=a.decoder_attention_heads, enc_layers=a.encoder_layers, dec_layers=a.decoder_layers)
+    assert (a.encoder_embed_dim, a.encoder_attention_heads, a.encoder_ffn_embed_dim) == (256, 4, 2048)
+    sd = {k: v.detach().cpu() for k, v in tr.get_model().state_dict().items()}
+    ref, rgrads = run_oracle(O.lsce_criterion, sd, cpu_sample(sample), cfg)
+    rl = float(ref["loss"]) / sample["ntokens"] / math.log(2)  # the driver logs loss / sample_size in base 2
+    assert inner[0]["loss"] == pytest.approx(rl, rel=1e-4), (inner[0]["loss"], rl)
+    names = [n for n, _ in tr.get_model().named_parameters()]
+    worst = 0.0
+    for p, o, n in zip(tr.buffers.params, tr.buffers.offsets, names):
+        r = rgrads.get(n)
+        e = max_abs_rel(tr.buffers.flat_grad[o:o + p.numel()].view(p.shape), r if r is not None else torch.zeros(p.shape))
+        worst = max(worst, e)
+        assert e <= 1e-3, "grad %s: %.3e" % (n, e)
+    print("config 1 (wav input through the driver): loss/token %.5f vs oracle %.5f, worst gradient error %.2e" % (inner[0]["loss"], rl, worst))
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+def test_config5_s2t_transformer_l_full_depth_beam5():
+    """s2t_transformer_l as the reference defines it (12 + 6 layers, d 1024, 16 heads, ffn 4096; s2t_transformer.py:433-478), V = 10 000,
+    fp32, 32 utterances x up to 30 s of filter banks, beam 5: device engine == host mirror loop on EVERY token id of every
+    hypothesis; on a 2-sentence slice both == oracle.beam_search (CPU) on the same parameters."""
+    from oracle import chimera_oracle as O
+    model, task, args = _build_stock("s2t_transformer_l", 10000, seed=5)
+    assert (args.encoder_layers, args.decoder_layers, args.encoder_embed_dim, args.encoder_attention_heads) == (12, 6, 1024, 16)
+    with torch.no_grad():  # sharpen the output distribution (a tied random-init model otherwise repeats one token)
+        model.decoder.embed_tokens.weight.mul_(3.0)
+        model.decoder.embed_tokens.weight[1].zero_()
+    model.eval()
+    SG = import_module("chimera-st_amd.sequence_generator").SequenceGenerator
+    g = torch.Generator().manual_seed(9)
+    B, T = 32, 3000
+    lens = sorted([int(torch.randint(1000, T + 1, (1,), generator=g)) for _ in range(B)], reverse=True)
+    lens[0] = T
+    src = torch.randn(B, T, 80, generator=g)
+    for b, l in enumerate(lens):
+        src[b, l:] = 0
+    sample = {"net_input": {"src_tokens": src.cuda(), "src_lengths": torch.tensor(lens).cuda()}}
+    max_len = 24
+    h1 = SG([model], task.target_dictionary, beam_size=5, max_len_a=0, max_len_b=max_len).generate([model], sample)
+    h2 = SG([model], task.target_dictionary, beam_size=5, max_len_a=0, max_len_b=max_len, fused=False).generate([model], sample)
+    seen = set()
+    for b in range(B):
+        assert len(h1[b]) == len(h2[b]) == 5
+        for r in range(5):
+            assert h1[b][r]["tokens"].tolist() == h2[b][r]["tokens"].tolist(), (b, r)
+            assert abs(float(h1[b][r]["score"]) - float(h2[b][r]["score"])) < 1e-3
+            seen.update(h1[b][r]["tokens"].tolist())
+    assert len(seen) > 12, "degenerate test: the hypotheses repeat a handful of tokens"
+    # oracle on the last two sentences (the shortest: least CPU time), same parameters
+    sl = [B - 2, B - 1]
+    p = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    p["decoder.output_projection.weight"] = p["decoder.embed_tokens.weight"]
+    with torch.no_grad():
+        tmax = lens[sl[0]]
+        enc, pm = O.s2t_encoder(p, src[sl, :tmax], torch.tensor([lens[i] for i in sl]), _s2t_cfg(args))
+        ref = O.beam_search(p, enc, pm, _s2t_cfg(args), beam=5, max_len=max_len)
+    s2 = {"net_input": {"src_tokens": src[sl, :tmax].cuda(), "src_lengths": torch.tensor([lens[i] for i in sl]).cuda()}}
+    h3 = SG([model], task.target_dictionary, beam_size=5, max_len_a=0, max_len_b=max_len).generate([model], s2)
+    for j in range(2):
+        for r in range(5):
+            assert h3[j][r]["tokens"].tolist() == ref[j][r]["tokens"].tolist(), (j, r)
+            assert abs(float(h3[j][r]["score"]) - float(ref[j][r]["score"])) < 1e-3

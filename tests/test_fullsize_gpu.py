@@ -59,3 +59,113 @@ def test_full_size_update_properties():
     # fitting the batch: 6 updates reduce the loss
     losses = [trainer.train_step([sample])["loss"] for _ in range(6)]
     assert all(l == l for l in losses) and losses[-1] < losses[0]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Full-dimension parity against the oracle (CPU fp32 restatement pinned to the reference): the BASELINE model dimensions
+# (wav2vec2-small front end: 7-layer CNN + 12 x 768 / 12 heads / hd 64; d 512 / 8 heads / ffn 2048; V = 10 000; M = 64), two
+# ragged utterances (10 s and 6 s) so that every exact-skipping path of the HIP kernels is live (padded key tiles, dead query
+# tiles, dead token blocks of the weight-gradient GEMMs, the CNN frame bound), the SAME parameters on both sides.
+# ---------------------------------------------------------------------------------------------------------------------
+def _build_full(model, dtype):
+    sys.path.insert(0, ROOT)
+    import bench
+    load_pkg()
+    args = Namespace(batch=2, seconds=10.0, lengths="uniform", dtype=dtype, model=model, dropout=0.0, layerdrop=0.0)
+    trainer, task, tasks, ns = bench.build(args, torch.device("cuda", 0))
+    sample = tasks.synthetic_sample(task.target_dictionary, 2, [160000, 96000], [37, 21], [20, 33], seed=3)
+    return trainer, task, ns, sample, bench.oracle_cfg(ns)
+
+
+def _hip_forward_backward(trainer, sample, chimera):
+    from importlib import import_module
+    K = import_module("chimera-st_amd.kernels")
+    model = trainer.get_model()
+    model.train()
+    s = trainer._prepare_sample(sample)
+    with torch.no_grad():
+        if chimera:
+            (logits, _), memory = model.forward_with_internal(**s["net_input"])
+        else:
+            (logits, _), memory = model(**s["net_input"]), None
+    trainer.optimizer.zero_grad()
+    K.STATS.clear()
+    loss, sample_size, log = trainer.criterion(model, s)
+    loss.backward()
+    stats = dict(K.STATS)
+    grads = {n: (p.grad.detach().float().cpu() if p.grad is not None else None) for n, p in model.named_parameters()}
+    return float(loss), log, logits.float().cpu(), (memory.float().cpu() if memory is not None else None), grads, stats
+
+
+@pytest.mark.parametrize("model", ["s2t_w2v2", "chimera"])
+def test_full_dimension_fp32_parity_with_oracle(model):
+    """fp32 storage: loss <= 1e-4 relative, logits / memory / EVERY parameter gradient <= 1e-3 * max(1, |ref|max)
+    (BASELINE north_star: 'logits/grads within 1e-3')."""
+    from oracle import chimera_oracle as O
+    from parity_util import cpu_sample, max_abs_rel, run_oracle
+    chimera = model == "chimera"
+    trainer, task, ns, sample, cfg = _build_full(model, "f32")
+    loss, log, logits, memory, grads, stats = _hip_forward_backward(trainer, sample, chimera)
+    # every exact-skipping path must have been live in this run (DESIGN §5.2b-d)
+    assert stats.get("attn_kv_len", 0) > 0 and stats.get("attn_q_flags", 0) > 0 and stats.get("gemm_k_len", 0) > 0, stats
+    if not chimera:  # the Chimera memory attends every padded frame (quirk Q1): no dead token blocks inside wav2vec2 there
+        assert stats.get("gemm_k_live", 0) > 0 and stats.get("gemm_m_live", 0) > 0, stats
+    sd = {k: v.detach().cpu() for k, v in trainer.get_model().state_dict().items()}
+    fn = O.triplet_criterion if chimera else O.lsce_criterion
+    ref, rgrads = run_oracle(fn, sd, cpu_sample(sample), cfg)
+    rl = float(ref["loss"])
+    assert abs(loss - rl) <= 1e-4 * abs(rl), "loss %.6f vs oracle %.6f" % (loss, rl)
+    if chimera:
+        for k in ("st_loss", "mt_loss", "contrastive_loss"):
+            assert abs(float(log[k]) - float(ref[k])) <= 1e-4 * abs(float(ref[k])) + 1e-3, k
+        assert max_abs_rel(memory, ref["memory_audio"]) <= 1e-3
+    e = max_abs_rel(logits, ref["st_logits"] if chimera else ref["logits"])
+    assert e <= 1e-3, "logits: %.3e" % e
+    worst = ("", 0.0)
+    n = 0
+    for name, r in rgrads.items():
+        if name not in grads:
+            continue
+        if grads[name] is None and r is None:
+            continue
+        got = grads[name] if grads[name] is not None else torch.zeros_like(r)
+        r = r if r is not None else torch.zeros_like(got)
+        e = max_abs_rel(got, r)
+        worst = max(worst, (name, e), key=lambda t: t[1])
+        assert e <= 1e-3, "grad %s: %.3e" % (name, e)
+        n += 1
+    print("%s fp32 full-dim: loss %.4f (oracle %.4f), %d gradients, worst %s %.2e, skip stats %s" % (model, loss, rl, n, worst[0], worst[1], stats))
+    assert n > 300
+
+
+@pytest.mark.parametrize("model", ["s2t_w2v2", "chimera"])
+def test_full_dimension_bf16_gap_is_storage_rounding(model):
+    """bf16 storage (what bench.py measures).  bf16 keeps 8 mantissa bits, so the distance to the fp32 oracle is not 1e-3; what
+    must hold is that the distance is ROUNDING and nothing else: the oracle re-run with every stored tensor rounded to bf16 at
+    the storage points of the HIP path (oracle.STORAGE) lands at some distance from the fp32 oracle, and the HIP path must not
+    be farther away than 1.5x that — globally, and for every tensor that carries >= 1 % of the gradient norm (2x + 1e-2)."""
+    from oracle import chimera_oracle as O
+    from parity_util import cpu_sample, grad_errors, max_abs_rel, run_oracle
+    chimera = model == "chimera"
+    trainer, task, ns, sample, cfg = _build_full(model, "bf16")
+    loss, log, logits, memory, grads, stats = _hip_forward_backward(trainer, sample, chimera)
+    sd = {k: v.detach().cpu() for k, v in trainer.get_model().state_dict().items()}  # bf16 values: exactly representable in fp32
+    fn = O.triplet_criterion if chimera else O.lsce_criterion
+    cs = cpu_sample(sample)
+    ref, rgrads = run_oracle(fn, sd, cs, cfg)
+    emu, egrads = run_oracle(fn, sd, cs, cfg, storage=torch.bfloat16)
+    key = "st_logits" if chimera else "logits"
+    rl, el = float(ref["loss"]), float(emu["loss"])
+    emu_loss_gap = abs(el - rl) / abs(rl)
+    assert abs(loss - rl) / abs(rl) <= max(2 * emu_loss_gap, 5e-4), "loss %.5f, oracle %.5f, emulated %.5f" % (loss, rl, el)
+    e_logit_emu = max_abs_rel(emu[key], ref[key])
+    e_logit = max_abs_rel(logits, ref[key])
+    assert e_logit <= 2 * e_logit_emu + 1e-3, "logits: hip %.3e vs emulated rounding %.3e" % (e_logit, e_logit_emu)
+    g_emu, per_emu = grad_errors(egrads, rgrads)
+    g_hip, per_hip = grad_errors({k: grads.get(k) for k in rgrads}, rgrads)
+    print("%s bf16 full-dim: loss hip %.4f / oracle %.4f / emulated %.4f; logits err hip %.3e / emulated %.3e; "
+          "gradient rel-L2 hip %.3e / emulated %.3e" % (model, loss, rl, el, e_logit, e_logit_emu, g_hip, g_emu))
+    assert g_hip <= 1.5 * g_emu + 1e-3, "global gradient error %.3e vs %.3e from storage rounding alone" % (g_hip, g_emu)
+    for k, (e, share) in per_hip.items():
+        if share >= 1e-2:
+            assert e <= 2 * per_emu[k][0] + 1e-2, "grad %s: %.3e vs emulated %.3e (share %.3f)" % (k, e, per_emu[k][0], share)

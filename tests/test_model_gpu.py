@@ -4,10 +4,13 @@ reference and (b) the oracle on the same inputs.  The product runs through the f
 
 Tolerances (stated where applied):
   fp32 storage: logits / memory / every gradient within 1e-3 * max(1, |ref|max)  (BASELINE north_star: "within 1e-3").
-  bf16 storage: outputs within 5e-2 * max(1,|ref|max); losses within 2e-3 relative; gradients judged in norm —
-    the concatenation of all gradients within 3e-2 relative L2 error, and every tensor that carries >= 3e-3 of the
-    total gradient norm within 0.15 relative L2 error (8 mantissa bits through ~25 stacked layers of a tiny model;
-    tensors whose true gradient is ~0, e.g. k_proj.bias, are pure rounding noise and only bound by the global check)."""
+  bf16 storage: bf16 keeps 8 mantissa bits, so the fp32 fixtures are not reached to 1e-3 by ANY bf16 computation; the bound is
+    set by what storage rounding alone does: the oracle is re-run with every stored tensor rounded to bf16 at the HIP path's
+    storage points (oracle.STORAGE; CPU, same fixture) and its distance to the fp32 fixture is the yardstick — outputs within
+    2x that distance + 1e-3, losses within 3x (the largest gap of any loss term) + 5e-4 relative, the concatenation of all gradients within 1.5x its relative
+    L2 error + 1e-3, every tensor carrying >= 1 % of the gradient norm within 2x its own + 1e-2 (tensors whose true gradient
+    is ~0, e.g. k_proj.bias, are pure rounding noise and only bound by the global check).  Measured on the tiny fixtures:
+    emulated 1.8e-2 global, HIP 1.8e-2."""
 import ast
 from argparse import Namespace
 from importlib import import_module
@@ -59,21 +62,31 @@ def to_cuda(sample):
     return mv(sample)
 
 
-def assert_grads_close_bf16(model, g):
-    num = den = 0.0
-    per = []
-    for name, p in model.named_parameters():
-        ref = np.asarray(g["grad/" + name], dtype=np.float64)
-        got = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().double().cpu().numpy()
-        assert np.isfinite(got).all(), name
-        e, r = float(((got - ref) ** 2).sum()), float((ref ** 2).sum())
-        num += e
-        den += r
-        per.append((name, e, r))
-    assert (num / den) ** 0.5 <= 3e-2, "global gradient rel-L2 error %.3e" % ((num / den) ** 0.5)
-    for name, e, r in per:
-        if r >= 1e-5 * den:  # >= 3e-3 of the total norm (a tensor at 1e-3 of the norm sits at the global noise floor of 1.8e-2)
-            assert (e / r) ** 0.5 <= 0.15, "grad %s rel-L2 error %.3e" % (name, (e / r) ** 0.5)
+def emulated_bf16(g, kind):
+    """The oracle with bf16 storage rounding on the fixture's parameters and inputs (CPU): (outputs, gradients)."""
+    from oracle import chimera_oracle as O
+    from parity_util import run_oracle
+    sd = {k[len("param/"):]: torch.from_numpy(np.array(v)) for k, v in g.items() if k.startswith("param/")}
+    fn = O.triplet_criterion if kind == "chimera" else O.lsce_criterion
+    return run_oracle(fn, sd, golden_sample(g), golden_cfg(g), storage=torch.bfloat16)
+
+
+def assert_grads_close_bf16(model, g, egrads):
+    from parity_util import grad_errors
+    ref = {n: torch.from_numpy(np.asarray(g["grad/" + n])) for n, _ in model.named_parameters()}
+    g_emu, per_emu = grad_errors(egrads, ref)
+    g_hip, per_hip = grad_errors({n: p.grad for n, p in model.named_parameters()}, ref)
+    print("gradient rel-L2 vs fp32 fixture: hip %.3e, storage rounding alone %.3e" % (g_hip, g_emu))
+    assert g_hip <= 1.5 * g_emu + 1e-3, "global gradient rel-L2 error %.3e vs %.3e from storage rounding alone" % (g_hip, g_emu)
+    for name, (e, share) in per_hip.items():
+        if share >= 1e-2:
+            assert e <= 2 * per_emu[name][0] + 1e-2, "grad %s rel-L2 error %.3e vs emulated %.3e" % (name, e, per_emu[name][0])
+
+
+def emulated_tol(emu_out, ref):
+    """Output tolerance in bf16 = 2x what storage rounding alone does to this output + 1e-3 (in units of max(1, |ref|max))."""
+    from parity_util import max_abs_rel
+    return 2 * max_abs_rel(emu_out, ref) + 1e-3
 
 
 def assert_close(got, ref, tol, what):
@@ -86,31 +99,40 @@ def assert_close(got, ref, tol, what):
     assert err <= tol * scale, "%s: max abs err %.3e > %.1e * %.3g" % (what, err, tol, scale)
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
-def test_chimera_golden_forward_backward(dtype, tol):
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_chimera_golden_forward_backward(dtype):
     g = load_golden("chimera_tiny.npz")
     model, task, args = build_from_golden(g, "chimera", dtype)
     crit_mod = import_module("chimera-st_amd.criterions")
     crit = crit_mod.TripletSTMTContrastiveCriterion(task, False, 0.1, [1.0, 1.0, 1.0], 0.1)
     sample = to_cuda(golden_sample(g))
     model.train()
+    tol = 1e-3
+    if dtype == torch.bfloat16:
+        emu, egrads = emulated_bf16(g, "chimera")
+        tols = {k: emulated_tol(emu[k], g["out/" + k]) for k in ("memory_audio", "st_logits", "memory_text", "mt_logits")}
+    else:
+        tols = {k: tol for k in ("memory_audio", "st_logits", "memory_text", "mt_logits")}
     (st_logits, _), mem_a = model.forward_with_internal(**sample["net_input"])
-    assert_close(mem_a, g["out/memory_audio"], tol, "memory(audio)")
-    assert_close(st_logits, g["out/st_logits"], tol, "st logits")
+    assert_close(mem_a, g["out/memory_audio"], tols["memory_audio"], "memory(audio)")
+    assert_close(st_logits, g["out/st_logits"], tols["st_logits"], "st logits")
     (mt_logits, _), mem_t = model.forward_with_internal(src_tokens=sample["src_text"], src_lengths=sample["src_text_lengths"],
                                                         prev_output_tokens=sample["net_input"]["prev_output_tokens"])
-    assert_close(mem_t, g["out/memory_text"], tol, "memory(text)")
-    assert_close(mt_logits, g["out/mt_logits"], tol, "mt logits")
+    assert_close(mem_t, g["out/memory_text"], tols["memory_text"], "memory(text)")
+    assert_close(mt_logits, g["out/mt_logits"], tols["mt_logits"], "mt logits")
     model.zero_grad()
     loss, sample_size, log = crit(model, sample)
     loss.backward()
-    ltol = 1e-4 if dtype == torch.float32 else 2e-3
-    for k in ("loss", "nll_loss", "st_loss", "st_nll_loss", "mt_loss", "mt_nll_loss", "contrastive_loss"):
+    terms = ("loss", "nll_loss", "st_loss", "st_nll_loss", "mt_loss", "mt_nll_loss", "contrastive_loss")
+    if dtype == torch.bfloat16:  # one rounding-noise sample per term: the largest relative gap of any term is the yardstick for all
+        emu_gap = max(abs(float(emu[k]) - float(g["loss/" + k])) / abs(float(g["loss/" + k])) for k in terms)
+    for k in terms:
         ref = float(g["loss/" + k])
+        ltol = 1e-4 if dtype == torch.float32 else 3 * emu_gap + 5e-4
         assert abs(float(log[k]) - ref) <= ltol * abs(ref) + 1e-3, "%s: %.6f vs %.6f" % (k, float(log[k]), ref)
     assert sample_size == int(g["loss/sample_size"])
     if dtype == torch.bfloat16:
-        assert_grads_close_bf16(model, g)
+        assert_grads_close_bf16(model, g, egrads)
         return
     n = 0
     for name, p in model.named_parameters():
@@ -121,14 +143,18 @@ def test_chimera_golden_forward_backward(dtype, tol):
     assert n > 80
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
-def test_s2t_w2v2_golden_forward_backward(dtype, tol):
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_s2t_w2v2_golden_forward_backward(dtype):
     g = load_golden("s2t_w2v2_tiny.npz")
     model, task, args = build_from_golden(g, "s2t", dtype)
     crit_mod = import_module("chimera-st_amd.criterions")
     crit = crit_mod.LabelSmoothedCrossEntropyCriterion(task, False, 0.1)
     sample = to_cuda(golden_sample(g))
     model.train()
+    tol = 1e-3
+    if dtype == torch.bfloat16:
+        emu, egrads = emulated_bf16(g, "s2t")
+        tol = emulated_tol(emu["encoder_out"], g["out/encoder_out"])
     enc = model.encoder(sample["net_input"]["src_tokens"], sample["net_input"]["src_lengths"])
     assert_close(enc.encoder_out, g["out/encoder_out"], tol, "encoder_out")
     assert (enc.encoder_padding_mask.cpu().numpy() == g["out/encoder_padding_mask"]).all()
@@ -136,9 +162,10 @@ def test_s2t_w2v2_golden_forward_backward(dtype, tol):
     loss, sample_size, log = crit(model, sample)  # passes the collater's `mask` kwarg through (Q6)
     loss.backward()
     ref = float(g["loss/loss"])
-    assert abs(float(loss.detach()) - ref) <= (1e-4 if dtype == torch.float32 else 2e-3) * abs(ref)
+    ltol = 1e-4 if dtype == torch.float32 else 2 * abs(float(emu["loss"]) - ref) / abs(ref) + 5e-4
+    assert abs(float(loss.detach()) - ref) <= ltol * abs(ref)
     if dtype == torch.bfloat16:
-        assert_grads_close_bf16(model, g)
+        assert_grads_close_bf16(model, g, egrads)
         return
     for name, p in model.named_parameters():
         got = p.grad if p.grad is not None else torch.zeros_like(p)
