@@ -50,10 +50,17 @@ def validate(trainer, task, args, subset, rank, world):
         log = trainer.valid_step(sample)
         for k, v in (log or {}).items():
             totals[k] = totals.get(k, 0.0) + torch.as_tensor(v, dtype=torch.float64, device=trainer.device)
+    # every rank takes part in the SAME collectives with the SAME vector layout, whatever its shard held: a rank whose shard had
+    # no batch (fewer validation batches than ranks) contributes zeros instead of returning before the all-reduce
     keys = sorted(totals)
+    if world > 1:
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, keys)
+        keys = sorted(set(k for ks in gathered for k in ks))
     if not keys:
         return {}
-    vec = torch.stack([totals[k] for k in keys])
+    zero = torch.zeros((), dtype=torch.float64, device=trainer.device)
+    vec = torch.stack([totals.get(k, zero) for k in keys])
     if world > 1:
         torch.distributed.all_reduce(vec)
     out = dict(zip(keys, vec.tolist()))
@@ -91,7 +98,7 @@ def train_main(argv=None):
                                   ignore_invalid_inputs=True, required_batch_size_multiple=8 if args.batch_size is None else 1,
                                   seed=args.seed, num_shards=world, shard_id=rank, epoch=start_epoch)
     itr.pin_memory = True
-    best = None
+    best = extra_state.get("best") if extra_state is not None else None  # checkpoint_utils.py:47-55: save_checkpoint.best survives a restart
     max_update = args.max_update or math.inf
     max_epoch = args.max_epoch or math.inf
     epoch = start_epoch
@@ -118,6 +125,9 @@ def train_main(argv=None):
                 continue
             out = trainer.train_step(group)
             group = []
+            if out is None:  # a rank ran out of memory: every rank dropped this update (trainer.py:564-570)
+                _log(rank, event="oom_skipped_update", epoch=epoch, num_updates=trainer.num_updates)
+                continue
             for k, v in out.items():
                 agg[k] = agg.get(k, 0.0) + (v if k not in ("lr", "gnorm") else 0.0)
             if trainer.num_updates % max(args.log_interval, 1) == 0:
@@ -130,7 +140,7 @@ def train_main(argv=None):
                 break
         if group and trainer.num_updates < max_update:  # the epoch's tail group is a (smaller) update of its own (iterators.py GroupedIterator)
             out = trainer.train_step(group)
-            for k, v in out.items():
+            for k, v in (out or {}).items():
                 agg[k] = agg.get(k, 0.0) + (v if k not in ("lr", "gnorm") else 0.0)
         ss = max(agg.get("sample_size", 1.0), 1.0)
         _log(rank, event="train", epoch=epoch, num_updates=trainer.num_updates, loss=agg.get("loss", 0.0) / ss / math.log(2),
@@ -229,8 +239,11 @@ def generate_main(argv=None):
     for sample in itr.next_epoch_itr(shuffle=False):
         if not sample:
             continue
-        s = {"net_input": {"src_tokens": sample["net_input"]["src_tokens"].to("cuda", dtype),
-                           "src_lengths": sample["net_input"]["src_lengths"].cuda()}}
+        src = sample["net_input"]["src_tokens"]
+        # raw waveforms [B, S] stay fp32 as in training (Trainer._prepare_sample: conv0 reads fp32 samples); only feature
+        # inputs [B, T, F] take the model's storage dtype
+        src = src.to("cuda", dtype) if (src.dim() == 3 and src.is_floating_point()) else src.cuda()
+        s = {"net_input": {"src_tokens": src, "src_lengths": sample["net_input"]["src_lengths"].cuda()}}
         results = task.inference_step(gen, [model], s)
         for i, sid in enumerate(sample["id"].tolist()):
             ref = tgt_dict.string(sample["target"][i]) if sample.get("target") is not None else None

@@ -105,13 +105,21 @@ class BucketedGradAllReduce:
         self._works = []
         self._skipped = set()
         self._fired = set()
+        self._late = set()  # buckets whose all-reduce went out before one of their gradients existed (re-reduced in finish)
 
     def _make_hook(self, idx):
         def hook(param):
             if not self.enabled or not self.active:
                 return
             b = self.param_bucket[idx]
+            again = idx in self._fired  # a second backward pass through the same parameter accumulates into its gradient
             self._fired.add(idx)
+            if idx in self._skipped or again:
+                # reported unused by one forward pass (layerdrop) but used by another pass of the same update, or hit twice: it was
+                # already counted.  If its bucket has left, that all-reduce carried a stale gradient: reduce the bucket again.
+                if b < self._next:
+                    self._late.add(b)
+                return
             self._pending[b] -= 1
             if self._pending[b] == 0:
                 self._ready[b] = True
@@ -143,6 +151,14 @@ class BucketedGradAllReduce:
                 self._next += 1
             for w in self._works:
                 w.wait()
+            if self._late:
+                # every rank runs the same forward passes in the same order, so `_late` is the same set everywhere.  The stale
+                # reduction is discarded: the bucket is re-gathered from the (now complete) local gradients and reduced again.
+                self._works = []
+                for b in sorted(self._late):
+                    self._launch(b)
+                for w in self._works:
+                    w.wait()
         self.reset()
 
 

@@ -107,22 +107,34 @@ class FusedAdam:
     def get_lr(self):
         return self.lr
 
-    def grad_norm(self, multiply=1.0):
-        """|| multiply * grad ||_2 as a device tensor (what clip_grad_norm_ returns after multiply_grads)."""
+    def grad_sumsq(self):
+        """sum(grad^2) over the flat gradient buffer as a 1-element fp32 device tensor (fixed-order two-stage sum: replicas that hold
+        the same all-reduced gradients get the same bits)."""
         self._sumsq.zero_()
         K.sumsq(self.buf.flat_grad, self._sumsq)
-        return self._sumsq.sqrt() * multiply
+        return self._sumsq
 
-    def step(self, multiply=1.0):
-        """One update.  `multiply` = world_size / sample_size (trainer.py:606).  Returns the pre-clip grad norm (device)."""
-        gnorm = self.grad_norm(multiply)  # `multiply` may be a python float or a 1-element device tensor
-        if self.clip_norm > 0:
-            coef = (self.clip_norm / (gnorm + 1e-6)).clamp(max=1.0)
-            self._scale.copy_((coef * multiply).reshape(1))
-        elif torch.is_tensor(multiply):
-            self._scale.copy_(multiply.reshape(1))
+    def grad_norm(self, multiply=1.0):
+        """|| multiply * grad ||_2 as a device tensor (what clip_grad_norm_ returns after multiply_grads)."""
+        return self.grad_sumsq().sqrt() * multiply
+
+    def step(self, multiply=1.0, gnorm=None):
+        """One update.  `multiply` = world_size / sample_size (trainer.py:606).  Returns the pre-clip grad norm.
+        gnorm: the norm of multiply * grad if the caller already has it on the HOST (the trainer reads the raw sum of squares back
+        together with the logging vector); then the clip coefficient is computed there and no device scalar math is queued."""
+        if gnorm is not None:
+            multiply = float(multiply)
+            coef = min(1.0, self.clip_norm / (gnorm + 1e-6)) if self.clip_norm > 0 else 1.0
+            self._scale.fill_(coef * multiply)
         else:
-            self._scale.fill_(multiply)
+            gnorm = self.grad_norm(multiply)  # `multiply` may be a python float or a 1-element device tensor
+            if self.clip_norm > 0:
+                coef = (self.clip_norm / (gnorm + 1e-6)).clamp(max=1.0)
+                self._scale.copy_((coef * multiply).reshape(1))
+            elif torch.is_tensor(multiply):
+                self._scale.copy_(multiply.reshape(1))
+            else:
+                self._scale.fill_(multiply)
         self.num_updates += 1
         K.adam_step(self.master, self.exp_avg, self.exp_avg_sq, self.buf.flat_grad, self.buf.flat_param, self.lr,
                     self.betas[0], self.betas[1], self.eps, self.weight_decay, self.num_updates, self._scale)

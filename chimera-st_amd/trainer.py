@@ -3,6 +3,7 @@
 (world/sample_size, :601-606), clip (:615), optimizer step (:627), lr schedule — with the MI355X pieces swapped in:
 flat bf16 parameter/gradient buffers, bucketed RCCL all-reduce overlapped with backward, one fused Adam pass."""
 import contextlib
+import math
 import os
 import random
 
@@ -36,6 +37,7 @@ class Trainer:
         self.num_updates = 0
         self.dtype = dtype
         self._dummy_batch = None
+        self._log_keys = None
 
     def get_model(self):
         return self._model
@@ -61,12 +63,18 @@ class Trainer:
 
         return mv(sample)
 
-    def train_step(self, samples):
-        """One update over a list of micro-batches.  Returns the summed logging output (loss terms as device tensors
-        converted to floats only here, once per update)."""
+    def train_step(self, samples, raise_oom=False):
+        """One update over a list of micro-batches.  Returns the summed logging output (device scalars converted to floats in the
+        step's single host read), or None when the update was skipped because a rank ran out of memory (trainer.py:524-544, 564-570).
+
+        The cross-rank guards of the reference ride in the ONE fp64 vector that already carries the logging scalars (C3-C5):
+          * `distributed_cuda_oom` (trainer.py:564-570): a rank that ran out of memory in forward/backward still issues every
+            bucket all-reduce (finish()) and the stat all-reduce, with the flag set; every rank then drops the update;
+          * `_check_grad_norms` (trainer.py:1045-1077): each rank writes the sum of squares of ITS copy of the reduced gradient
+            into its own slot; after the all-reduce every rank sees all of them and raises if they disagree beyond 1e-6."""
         self._set_seed()
         self.optimizer.zero_grad()
-        logs, sample_size = [], 0
+        logs, sample_size, ooms = [], 0, 0
         for i, sample in enumerate(samples):
             # an empty batch (this rank's shard ran out: ShardedIterator pads with []) runs the dummy batch with its loss zeroed
             # so that every rank issues the same collectives (trainer.py:469-477, 552-556)
@@ -76,12 +84,23 @@ class Trainer:
                 sample = self._dummy_batch
             elif self._dummy_batch is None:
                 self._dummy_batch = sample
-            sample = self._prepare_sample(sample)
             last = i == len(samples) - 1
             ctx = self.model.no_sync() if (self.ddp and not last) else contextlib.nullcontext()
-            with ctx:
-                loss, ss, log = self.task.train_step(sample, self.model, self.criterion, self.optimizer, self.num_updates,
-                                                     ignore_grad=ignore)
+            try:
+                sample = self._prepare_sample(sample)
+                with ctx:
+                    loss, ss, log = self.task.train_step(sample, self.model, self.criterion, self.optimizer, self.num_updates,
+                                                         ignore_grad=ignore)
+                del loss
+            except RuntimeError as e:
+                if "out of memory" not in str(e) or raise_oom:
+                    raise
+                ooms += 1
+                self.optimizer.zero_grad()
+                torch.cuda.empty_cache()
+                if not self.ddp:
+                    return None
+                continue
             if ignore:
                 log, ss = {k: v * 0 for k, v in log.items()}, 0
             logs.append(log)
@@ -90,19 +109,43 @@ class Trainer:
             self.model.all_reduce()  # waits for the overlapped bucket reductions; launches the stragglers
         else:
             self.buffers.gather_grads()  # one multi-tensor copy of every autograd-owned gradient into the flat buffer
-        # logging scalars + sample_size: ONE fp64 device vector, one small all-reduce (C3-C5 folded), no host sync
-        # before the optimizer kernels are queued.
-        keys = sorted(k for k in logs[0].keys())
-        vec = torch.stack([sum(torch.as_tensor(l[k], dtype=torch.float64, device=self.device) for l in logs) for k in keys])
+        # logging scalars + sample_size + OOM flag + one gradient-norm slot per rank: ONE fp64 device vector, one small
+        # all-reduce, one host read
+        if logs:
+            self._log_keys = sorted(logs[0].keys())
+        keys = self._log_keys
+        assert keys is not None, "out of memory before any update completed: no logging layout to all-reduce"
+        zero = torch.zeros((), dtype=torch.float64, device=self.device)
+        stats = [sum((torch.as_tensor(l[k], dtype=torch.float64, device=self.device) for l in logs), zero) for k in keys]
+        slots = torch.zeros(self.world, dtype=torch.float64, device=self.device)
+        slots[self.rank] = self.optimizer.grad_sumsq()[0].double()
+        vec = torch.cat([torch.stack(stats), torch.tensor([float(ooms)], dtype=torch.float64, device=self.device), slots])
         if self.ddp:
             dist.all_reduce(vec)
-        total_ss = vec[keys.index("sample_size")]
-        gnorm = self.optimizer.step(multiply=(self.world / total_ss).float())
+        vals = vec.tolist()  # the step's only host sync
+        out = dict(zip(keys, vals[:len(keys)]))
+        if vals[len(keys)] != 0:  # some rank lost this update's gradients: nobody steps (trainer.py:564-570)
+            self.optimizer.zero_grad()
+            return None
+        sumsq = vals[len(keys) + 1:]
+        self._check_grad_norms(sumsq)
+        multiply = self.world / out["sample_size"] if out["sample_size"] > 0 else 0.0
+        out["gnorm"] = self.optimizer.step(multiply=multiply, gnorm=math.sqrt(sumsq[self.rank]) * multiply)
         self.num_updates += 1
-        out = dict(zip(keys, vec.tolist()))  # the step's only host sync
-        out["gnorm"] = float(gnorm)
         out["lr"] = self.optimizer.get_lr()
         return out
+
+    def _check_grad_norms(self, sumsq):
+        """trainer.py:1045-1077 — replicas all-reduce the same buckets in the same order, so their gradient norms must agree to
+        rounding; anything else (a rank that skipped a bucket, mixed hardware, a corrupted buffer) is fatal."""
+        norms = [math.sqrt(v) if v >= 0 and math.isfinite(v) else float("nan") for v in sumsq]
+        if len(norms) < 2 or not all(math.isfinite(n) for n in norms):
+            return  # a non-finite norm is the overflow / NaN path's business (every rank sees the same vector)
+        if max(abs(n - norms[0]) for n in norms) / (norms[0] + 1e-6) < 1e-6:
+            return
+        detail = "\n".join("rank {:3d} = {:.8f}".format(r, n) for r, n in enumerate(norms))
+        raise RuntimeError("Fatal error: gradients are inconsistent between workers.\n" + "-" * 80 +
+                           "\ngrad_norm across the workers:\n{}\n".format(detail) + "-" * 80)
 
     @torch.no_grad()
     def valid_step(self, sample):

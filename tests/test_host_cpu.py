@@ -199,3 +199,100 @@ def test_bucketed_all_reduce_gloo_world2():
     np.testing.assert_allclose(res[0][2], want2.numpy(), rtol=1e-5, atol=1e-6)
     tail = buf.offsets[-2]
     assert np.abs(res[0][1][tail:]).sum() == 0  # the unused layer stayed exactly zero in step 1
+
+
+# ---- Trainer-level cross-rank guards (fairseq/trainer.py:564-570 OOM flag, :1045-1077 _check_grad_norms), world 2 over gloo ----
+class _ToyCriterion(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.fail_next = False
+
+    def forward(self, model, sample):
+        if self.fail_next:
+            self.fail_next = False
+            raise RuntimeError("HIP out of memory. Tried to allocate 20.00 GiB (injected by the test)")
+        loss = model(sample["x"]).pow(2).sum()
+        n = sample["x"].shape[0]
+        return loss, n, {"loss": loss.detach(), "sample_size": n, "ntokens": n, "nsentences": n}
+
+
+def _cpu_trainer(rank):
+    """A Trainer on CPU tensors: the two optimizer KERNELS (cst_sumsq, cst_adam_step) are replaced by torch arithmetic — the
+    guards under test live in the host logic around them."""
+    Trainer = import_module("chimera-st_amd.trainer").Trainer
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 40), torch.nn.ReLU(), torch.nn.Linear(40, 4))
+    args = Namespace(bf16=False, lr=[1e-2], adam_betas="(0.9, 0.98)", adam_eps=1e-8, weight_decay=0.0, clip_norm=0.0, seed=1,
+                     bucket_cap_mb=0.0005)
+    tr = Trainer(args, tasks.FairseqTask(args), net, _ToyCriterion(), device="cpu")
+    opt = tr.optimizer
+    opt.grad_sumsq = lambda: opt.buf.flat_grad.double().pow(2).sum().float().reshape(1)
+
+    def step(multiply=1.0, gnorm=None):
+        opt.num_updates += 1
+        opt.buf.flat_param.sub_(opt.lr * float(multiply) * opt.buf.flat_grad)  # plain SGD stands in for the Adam kernel
+        return gnorm
+
+    opt.step = step
+    return tr
+
+
+def _guard_worker(rank, world, port, q, mode):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tr = _cpu_trainer(rank)
+    g = torch.Generator().manual_seed(100 + rank)
+    batch = lambda: {"x": torch.randn(5, 6, generator=g)}
+    out = {"rank": rank}
+    o1 = tr.train_step([batch()])
+    out["step1"] = (o1["sample_size"], o1["gnorm"], tr.buffers.flat_param.clone().numpy())
+    if mode == "oom":
+        before = tr.buffers.flat_param.clone()
+        if rank == 1:
+            tr.criterion.fail_next = True  # rank 1 loses its forward pass; rank 0 completes a normal backward
+        o2 = tr.train_step([batch()])
+        out["step2_none"] = o2 is None
+        out["unchanged"] = bool(torch.equal(before, tr.buffers.flat_param)) and tr.num_updates == 1
+        o3 = tr.train_step([batch()])  # the job carries on, replicas still identical
+        out["step3"] = (o3["sample_size"], tr.buffers.flat_param.clone().numpy(), tr.num_updates)
+    else:  # a replica whose reduced gradient differs (a skipped bucket, a corrupted buffer)
+        orig = tr.model.all_reduce
+
+        def bad():
+            orig()
+            if rank == 1:
+                tr.buffers.flat_grad[3] += 0.5
+
+        tr.model.all_reduce = bad
+        try:
+            tr.train_step([batch()])
+            out["raised"] = None
+        except RuntimeError as e:
+            out["raised"] = str(e)
+    q.put(out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["oom", "diverge"])
+def test_trainer_oom_flag_and_grad_norm_check_gloo_world2(mode):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_guard_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t["rank"])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0]["step1"][0] == res[1]["step1"][0] == 10.0  # sample sizes were summed over the ranks
+    assert res[0]["step1"][1] == res[1]["step1"][1]
+    np.testing.assert_array_equal(res[0]["step1"][2], res[1]["step1"][2])
+    if mode == "oom":
+        for r in res:
+            assert r["step2_none"] and r["unchanged"], r  # BOTH ranks dropped the update although only rank 1 failed
+            assert r["step3"][0] == 10.0 and r["step3"][2] == 2
+        np.testing.assert_array_equal(res[0]["step3"][1], res[1]["step3"][1])
+    else:
+        for r in res:  # every rank sees every rank's norm in the all-reduced vector: all of them stop
+            assert r["raised"] is not None and "gradients are inconsistent between workers" in r["raised"] and "rank   1" in r["raised"]
