@@ -701,6 +701,43 @@ def dropout(x, p, key=None):
     return _DropoutFn.apply(x, float(p), rng.next_key() if key is None else key)
 
 
+class _EmbedPosFn(torch.autograd.Function):
+    """dropout(scale * (E[tokens] | x) + sinusoidal_positions): one kernel forward (cst_embed_pos_fwd); backward = the
+    deterministic table gradient cst_embed_bwd (embedding) or cst_dropout_scale (dense features).  The positional table
+    is data (no gradient), make_positions is evaluated inside the kernel."""
+
+    @staticmethod
+    def forward(ctx, tokens, pad_mask, embed, x, pos_table, scale, pad_idx, p, key):
+        out = K.embed_pos_fwd(tokens, pad_mask, embed, x, pos_table, scale, pad_idx, p, key)
+        ctx.save_for_backward(tokens)
+        ctx.cfg = (scale, pad_idx, p, key, embed.shape[0] if embed is not None else 0, embed.dtype if embed is not None else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (tokens,) = ctx.saved_tensors
+        scale, pad_idx, p, key, V, gdt = ctx.cfg
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        if V:
+            dE = K.embed_bwd(dy, tokens, V, scale, pad_idx, p, key, gdt) if ctx.needs_input_grad[2] else None
+            return None, None, dE, None, None, None, None, None, None
+        dx = K.dropout_scale(dy, scale, p, key) if ctx.needs_input_grad[3] else None
+        return None, None, None, dx, None, None, None, None, None
+
+
+def embed_positions(tokens=None, pad_mask=None, embed=None, x=None, pos_table=None, scale=1.0, pad_idx=1, dropout_p=0.0):
+    """[B, T, C] = dropout(scale * (embed[tokens] or x) + pos_table[make_positions(pad_mask or tokens, pad_idx)]).
+    tokens int64 [B, T]; pad_mask bool/uint8 [B, T] (True = pad; takes precedence as the position source); pos_table fp32
+    [>= pad_idx + 1 + T, C] or None."""
+    if pad_mask is not None:
+        pad_mask = pad_mask.to(torch.uint8).contiguous()
+    if tokens is not None:
+        tokens = tokens.contiguous()
+    if x is not None and not x.is_contiguous():
+        x = x.contiguous()
+    return _EmbedPosFn.apply(tokens, pad_mask, embed, x, pos_table, float(scale), int(pad_idx), *_drop_args(dropout_p))
+
+
 class _LsCeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target, eps, pad):

@@ -343,6 +343,42 @@ def dropout(x, p, key):
     return y
 
 
+def dropout_scale(x, alpha, p, key):
+    """y = alpha * x * keep(key, idx) / (1 - p); x contiguous, numel % 8 == 0."""
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    L.check(L.load().cst_dropout_scale(L.ptr(x), L.ptr(y), x.numel(), float(alpha), float(p), int(key) & 0xFFFFFFFF, L.dtype_code(x.dtype),
+                                       L.stream_ptr()), "cst_dropout_scale")
+    return y
+
+
+def embed_pos_fwd(tokens, pad_mask, embed, x, pos_table, scale, pad_idx, p, key):
+    """dropout(scale * (embed[tokens] | x) + pos_table[make_positions(pad_mask | tokens)]) -> [B, T, C] (include/cst.h)."""
+    ref = tokens if tokens is not None else pad_mask
+    B, T = ref.shape
+    src = embed if embed is not None else x
+    C = src.shape[-1]
+    V = embed.shape[0] if embed is not None else 0
+    assert src.is_contiguous() and (tokens is None or (tokens.dtype == torch.int64 and tokens.is_contiguous()))
+    assert pad_mask is None or (pad_mask.dtype == torch.uint8 and pad_mask.is_contiguous() and pad_mask.shape == (B, T))
+    assert pos_table is None or (pos_table.dtype == torch.float32 and pos_table.is_contiguous() and pos_table.shape[1] == C)
+    out = torch.empty(B, T, C, dtype=src.dtype, device=src.device)
+    L.check(L.load().cst_embed_pos_fwd(L.ptr(tokens), L.ptr(pad_mask), L.ptr(embed), L.ptr(x), L.ptr(pos_table), float(scale), int(pad_idx),
+                                       L.ptr(out), B, T, C, V, 0 if pos_table is None else pos_table.shape[0], float(p), int(key) & 0xFFFFFFFF,
+                                       L.dtype_code(src.dtype), L.stream_ptr()), "cst_embed_pos_fwd")
+    return out
+
+
+def embed_bwd(dy, tokens, V, scale, pad_idx, p, key, grad_dtype):
+    """Deterministic embedding-table gradient [V, C] of embed_pos_fwd (include/cst.h)."""
+    dy = dy.reshape(-1, dy.shape[-1])
+    assert dy.is_contiguous() and tokens.is_contiguous() and tokens.numel() == dy.shape[0]
+    dE = torch.empty(V, dy.shape[1], dtype=grad_dtype, device=dy.device)
+    L.check(L.load().cst_embed_bwd(L.ptr(dy), L.ptr(tokens), L.ptr(dE), float(scale), int(pad_idx), dy.shape[0], dy.shape[1], V, float(p),
+                                   int(key) & 0xFFFFFFFF, L.dtype_code(dy.dtype), L.dtype_code(grad_dtype), L.stream_ptr()), "cst_embed_bwd")
+    return dE
+
+
 def ls_ce_fwd(logits, target, eps, pad):
     logits = _2d(logits)
     rows, V = logits.shape

@@ -138,6 +138,18 @@ class SinusoidalPositionalEmbedding(nn.Module):
             emb[padding_idx, :] = 0
         return emb
 
+    def table(self, seq_len, device):
+        """The fp32 sin || cos table on `device` with at least padding_idx + 1 + seq_len rows (row padding_idx is zero) — the
+        operand of cst_embed_pos_fwd, which evaluates make_positions itself and gathers the rows in-kernel."""
+        need = self.padding_idx + 1 + seq_len
+        t = getattr(self, "_dev_table", None)
+        if t is None or t.shape[0] < need or t.device != device:
+            rows = max(need, 256)
+            rows = 1 << (rows - 1).bit_length()  # grow geometrically: one H2D copy per doubling, not per batch shape
+            t = SinusoidalPositionalEmbedding.get_embedding(rows, self.embedding_dim, self.padding_idx).to(device=device, dtype=torch.float32).contiguous()
+            self._dev_table = t
+        return t
+
     def forward(self, input, incremental_state=None, timestep=None, positions=None):
         bsz, seq_len = input.shape[:2]
         max_pos = self.padding_idx + 1 + seq_len

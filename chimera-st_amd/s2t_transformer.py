@@ -106,16 +106,25 @@ class TransformerDecoder(FairseqIncrementalDecoder):
     def extract_features_scriptable(self, prev_output_tokens, encoder_out=None, incremental_state=None,
                                     full_context_alignment=False, alignment_layer=None, alignment_heads=None):
         """transformer.py:720-828."""
-        positions = (self.embed_positions(prev_output_tokens, incremental_state=incremental_state)
-                     if self.embed_positions is not None else None)
-        if incremental_state is not None:
-            prev_output_tokens = prev_output_tokens[:, -1:]
+        if incremental_state is None and prev_output_tokens.is_cuda:
+            # training / full-sequence path: embed_scale * E[tokens] + sinusoidal positions + dropout in ONE kernel
+            # (cst_embed_pos_fwd: make_positions evaluated in-kernel; deterministic table gradient cst_embed_bwd)
+            x = CF.embed_positions(tokens=prev_output_tokens, embed=self.embed_tokens.weight,
+                                   pos_table=(self.embed_positions.table(prev_output_tokens.size(1), prev_output_tokens.device)
+                                              if self.embed_positions is not None else None),
+                                   scale=self.embed_scale, pad_idx=self.padding_idx,
+                                   dropout_p=self.dropout_module.p if self.training else 0.0)
+        else:
+            positions = (self.embed_positions(prev_output_tokens, incremental_state=incremental_state)
+                         if self.embed_positions is not None else None)
+            if incremental_state is not None:
+                prev_output_tokens = prev_output_tokens[:, -1:]
+                if positions is not None:
+                    positions = positions[:, -1:]
+            x = self.embed_scale * self.embed_tokens(prev_output_tokens)  # B x T x C, batch-major
             if positions is not None:
-                positions = positions[:, -1:]
-        x = self.embed_scale * self.embed_tokens(prev_output_tokens)  # B x T x C, batch-major
-        if positions is not None:
-            x = x + positions.to(x.dtype)
-        x = self.dropout_module(x)
+                x = x + positions.to(x.dtype)
+            x = self.dropout_module(x)
         x = to_time_major_view(x.contiguous())
         # transformer.py:768-770 builds this mask only `if prev_output_tokens.eq(pad).any()` — a host sync between encoder and
         # decoder; the mask of a pad-free batch is all-False and changes nothing, so the full-sequence (training) path always
@@ -228,9 +237,11 @@ class S2TTransformerEncoder(FairseqEncoder):
     def forward(self, src_tokens, src_lengths, **extra_args):
         x, input_lengths = self.subsample(src_tokens, src_lengths)
         encoder_padding_mask = lengths_to_padding_mask(input_lengths, max_len=x.size(0))
-        positions = self.embed_positions(encoder_padding_mask)  # B x T x C
-        x = to_time_major_view(self.embed_scale * to_batch_major(x) + positions.to(x.dtype))
-        x = self.dropout_module(x)
+        # embed_scale * x + sinusoidal positions (from the padding mask) + dropout: one kernel (cst_embed_pos_fwd)
+        x = to_time_major_view(CF.embed_positions(pad_mask=encoder_padding_mask, x=to_batch_major(x),
+                                                  pos_table=self.embed_positions.table(encoder_padding_mask.size(1), x.device),
+                                                  scale=self.embed_scale, pad_idx=self.padding_idx,
+                                                  dropout_p=self.dropout_module.p if self.training else 0.0))
         for layer in self.transformer_layers:
             x = layer(x, encoder_padding_mask)
         if self.layer_norm is not None:

@@ -8,6 +8,7 @@ import math
 import torch
 import torch.nn as nn
 
+from . import functional as CF
 from .fairseq_model import EncoderOut, FairseqEncoder, FairseqEncoderDecoderModel, lengths_to_padding_mask
 from .modules import FairseqDropout, LayerNorm, PositionalEmbedding, TransformerEncoderLayer, to_batch_major, to_time_major_view
 from .registry import register_model, register_model_architecture
@@ -107,9 +108,11 @@ class S2T_W2V2_TransformerEncoder(FairseqEncoder):
         w2v_feature, _, input_lengths = self._get_w2v_feature(src_tokens, src_lengths)
         x, input_lengths = self.subsample(w2v_feature, input_lengths)
         encoder_padding_mask = lengths_to_padding_mask(input_lengths, max_len=x.size(0))
-        positions = self.embed_positions(encoder_padding_mask)  # B x T x C (audio DOES get positions here, :356-358)
-        x = to_time_major_view(self.embed_scale * to_batch_major(x) + positions.to(x.dtype))
-        x = self.dropout_module(x)
+        # embed_scale * x + sinusoidal positions (audio DOES get positions here, :356-358) + dropout: one kernel
+        x = to_time_major_view(CF.embed_positions(pad_mask=encoder_padding_mask, x=to_batch_major(x),
+                                                  pos_table=self.embed_positions.table(encoder_padding_mask.size(1), x.device),
+                                                  scale=self.embed_scale, pad_idx=self.padding_idx,
+                                                  dropout_p=self.dropout_module.p if self.training else 0.0))
         for layer in self.transformer_layers:
             x = layer(x, encoder_padding_mask)
         # (the reference drops an all-False mask here, w2v2_transformer.py:377-378: `.any()` is a host sync in the middle of the

@@ -12,6 +12,7 @@ import logging
 import torch
 import torch.nn as nn
 
+from . import functional as CF
 from .fairseq_model import EncoderOut, lengths_to_padding_mask
 from .modules import Embedding, TransformerEncoderLayer, to_batch_major, to_time_major_view
 from .registry import register_model, register_model_architecture
@@ -115,18 +116,21 @@ class S2T_W2V2_TransformerInterlinguaEncoder(S2T_W2V2_TransformerEncoder):
     def forward(self, src_tokens, src_lengths, **extra_args):
         """:207-312."""
         is_text = not src_tokens.dtype.is_floating_point
+        drop_p = self.dropout_module.p if self.training else 0.0
         if is_text:
-            feature = self.text_embed_tokens(src_tokens)  # B x T x C batch-major
+            # text: embed_scale * E[tokens] + sinusoidal positions (Q3: only text gets them, :233-236; the position source is the
+            # LENGTH-derived padding mask, as the reference passes it) + dropout — one kernel (cst_embed_pos_fwd)
             input_lengths = src_lengths
-            feature_tm = to_time_major_view(feature)
+            encoder_padding_mask = lengths_to_padding_mask(input_lengths, max_len=src_tokens.size(1))
+            xb = CF.embed_positions(tokens=src_tokens, pad_mask=encoder_padding_mask, embed=self.text_embed_tokens.weight,
+                                    pos_table=self.embed_positions.table(src_tokens.size(1), src_tokens.device),
+                                    scale=self.embed_scale, pad_idx=self.padding_idx, dropout_p=drop_p)
         else:
             w2v_feature, _, input_lengths = self._get_w2v_feature(src_tokens, src_lengths)
             feature_tm, input_lengths = self.subsample(w2v_feature, input_lengths)
-        xb = self.embed_scale * to_batch_major(feature_tm)
-        encoder_padding_mask = lengths_to_padding_mask(input_lengths, max_len=xb.size(1))
-        if is_text:  # Q3: only text gets sinusoidal positions (:233-236)
-            xb = xb + self.embed_positions(encoder_padding_mask).to(xb.dtype)
-        x = to_time_major_view(self.dropout_module(xb))
+            encoder_padding_mask = lengths_to_padding_mask(input_lengths, max_len=feature_tm.size(0))
+            xb = CF.embed_positions(x=to_batch_major(feature_tm), scale=self.embed_scale, pad_idx=self.padding_idx, dropout_p=drop_p)  # no positions (Q3)
+        x = to_time_major_view(xb)
         for layer in self.transformer_layers:
             x = layer(x, encoder_padding_mask)
         if self.layer_norm is not None:

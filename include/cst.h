@@ -244,6 +244,33 @@ int cst_mask_rows(const void* x, const uint8_t* mask, void* y, int64_t rows, int
  * The mask is counter-based — keep(key, element index), csrc/cst_common.h — so nothing is stored between the two calls and
  * fused epilogues (cst_gemm / cst_attn_*) regenerate the identical mask from the same key.  n elements, contiguous. */
 int cst_dropout(const void* x, void* y, int64_t n, float p, uint32_t key, int dtype, cst_stream stream);
+/* y = alpha * x * keep / (1 - p)   (n % 8 == 0): the gradient of `dropout(alpha * x + const)` — the dense-feature branch of
+ * cst_embed_pos_fwd below. */
+int cst_dropout_scale(const void* x, void* y, int64_t n, float alpha, float p, uint32_t key, int dtype, cst_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Token embedding + sinusoidal positions of the TRAINING path — replaces, in one kernel,
+ *   embed_scale * nn.Embedding(tokens)            models/transformer.py:744-760 (decoder), w2v2_transformer_interlingua.py:216, :231
+ *   + SinusoidalPositionalEmbedding.forward       modules/sinusoidal_positional_embedding.py:60-105: weights.index_select(make_positions(input))
+ *     with utils.make_positions                   utils.py:235-245: pad_idx + cumsum(non-pad) for non-pad symbols, pad_idx for pads
+ *   + FairseqDropout                              modules/fairseq_dropout.py:20-37 (counter-based mask, see cst_dropout)
+ *   out[b,t,:] = dropout(scale * src[b,t,:] + pos_table[position(b,t),:])
+ * src: exactly one of `embed` [V, C] (row tokens[b,t]; ids outside [0, V) read the pad row) or `x` [B, T, C] (dense features: the
+ *   audio branch of S2T_W2V2_TransformerEncoder, w2v2_transformer.py:352-358).
+ * position source: `pad_mask` uint8 [B, T] when given (the encoders pass their padding mask: non-pad <=> mask != pad_idx, as
+ *   `tensor.ne(padding_idx)` reads a 0/1 mask), else `tokens` (non-pad <=> tokens != pad_idx).
+ * pos_table: fp32 [pos_rows, C], the reference's sin || cos table with row pad_idx zero; pos_rows >= pad_idx + 1 + T; NULL = no
+ *   positional term.  C % 8 == 0.  tokens int64 [B, T]. */
+int cst_embed_pos_fwd(const int64_t* tokens, const uint8_t* pad_mask, const void* embed, const void* x, const float* pos_table,
+                      float scale, int64_t pad_idx, void* out, int64_t B, int64_t T, int64_t C, int64_t V, int64_t pos_rows,
+                      float drop_p, uint32_t drop_key, int dtype, cst_stream stream);
+/* Gradient of the embedding table of cst_embed_pos_fwd — replaces ATen's embedding_dense_backward (sort by key + segmented
+ * reduce, 5 kernels; F.embedding with padding_idx: the pad row receives no gradient):
+ *   dE[v,:] = scale * sum over occurrences (b,t) of v != pad_idx, in (b,t) order, of keep(b,t,:) * dy[b,t,:];  all other rows 0.
+ * Deterministic (fixed summation order, no atomics).  dy [n, C] (n = B*T), tokens int64 [n], dE [V, C] in grad_dtype (fp32 or
+ * dtype; fully overwritten).  C % 8 == 0, C <= 8192. */
+int cst_embed_bwd(const void* dy, const int64_t* tokens, void* dE, float scale, int64_t pad_idx, int64_t n, int64_t C, int64_t V,
+                  float drop_p, uint32_t drop_key, int dtype, int grad_dtype, cst_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Label-smoothed cross entropy over vocabulary logits — replaces fp32 log_softmax

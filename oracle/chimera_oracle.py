@@ -62,6 +62,20 @@ def _st(x):
     return x if STORAGE is None else _RoundStored.apply(x)
 
 
+# ReLU is not differentiable at 0: two correct fp32 evaluations of the same pre-activation can land on either side of it (their
+# last bits depend on summation order) and then disagree on that neuron's weight-gradient row by a whole dh * x term.  With
+# RELU_TAPS = {} the oracle records, per fc1 (tag = parameter prefix), the smallest |pre-activation| each neuron saw over all
+# tokens, so that a parity test can tell such ties from errors (tests/parity_util.py::assert_grads_close_fp32).
+RELU_TAPS = None
+
+
+def _relu(x, tag):
+    if RELU_TAPS is not None:
+        m = x.detach().abs().reshape(-1, x.shape[-1]).amin(dim=0)
+        RELU_TAPS[tag] = torch.minimum(RELU_TAPS[tag], m) if tag in RELU_TAPS else m
+    return torch.relu(x)
+
+
 def _st_fwd(x):
     """Rounded where it is consumed (MFMA operand), but its gradient never leaves fp32 registers (attention's dP)."""
     return x if STORAGE is None else _RoundFwd.apply(x)
@@ -284,7 +298,7 @@ def encoder_layer(p: P, pre: str, x, padding_mask, heads: int, attn_mask=None, k
     x = _st(res + h)
     res = x
     h = layer_norm(x, p[pre + "final_layer_norm.weight"], p[pre + "final_layer_norm.bias"])
-    h = torch.relu(linear(h, p[pre + "fc1.weight"], p[pre + "fc1.bias"]))
+    h = _relu(linear(h, p[pre + "fc1.weight"], p[pre + "fc1.bias"]), pre + "fc1")
     h = linear(h, p[pre + "fc2.weight"], p[pre + "fc2.bias"])
     return _st(res + h)
 
@@ -379,7 +393,7 @@ def decoder_layer(p: P, pre: str, x, enc, enc_pm, heads, self_mask, self_pm):
     x = _st(res + h)
     res = x
     h = layer_norm(x, p[pre + "final_layer_norm.weight"], p[pre + "final_layer_norm.bias"])
-    h = torch.relu(linear(h, p[pre + "fc1.weight"], p[pre + "fc1.bias"]))
+    h = _relu(linear(h, p[pre + "fc1.weight"], p[pre + "fc1.bias"]), pre + "fc1")
     h = linear(h, p[pre + "fc2.weight"], p[pre + "fc2.bias"])
     return _st(res + h)
 

@@ -24,17 +24,50 @@ def oracle_leaves(state_dict, storage=None):
 
 
 def run_oracle(fn, state_dict, sample, cfg, storage=None, **kw):
-    """fn = O.triplet_criterion / O.lsce_criterion; returns (outputs, {name: grad}) of one forward + backward."""
+    """fn = O.triplet_criterion / O.lsce_criterion; returns (outputs, {name: grad}) of one forward + backward.
+    outputs["relu_min_abs"] = {fc1 prefix: per-neuron smallest |pre-activation|} (oracle.RELU_TAPS)."""
     prev = O.STORAGE
     O.STORAGE = storage
+    O.RELU_TAPS = {}
     try:
         p = oracle_leaves(state_dict, storage)
         out = fn(p, sample, cfg, **kw)
         out["loss"].backward()
+        out["relu_min_abs"] = O.RELU_TAPS
     finally:
         O.STORAGE = prev
+        O.RELU_TAPS = None
     grads = {k: v.grad for k, v in p.items() if k != "decoder.output_projection.weight" and v.requires_grad}
     return out, grads
+
+
+def detie(fn, state_dict, sample, cfg, margin=1e-4, bump=2e-2, rounds=8):
+    """ReLU is not differentiable at 0; two correct fp32 evaluations of a pre-activation that lies within rounding of 0 can fall
+    on different sides of the kink and then differ by a whole term in every gradient behind it.  To compare gradients at 1e-3
+    WITHOUT exemptions the parity tests pick their (random) parameters away from that measure-zero set: the oracle's forward
+    pass records the smallest |pre-activation| of every fc1 neuron (oracle.RELU_TAPS); neurons that come within `margin` of
+    zero for some token get their bias moved by `bump`.  Returns (state dict — same tensors for both sides —, neurons moved)."""
+    sd = {k: v.clone() for k, v in state_dict.items()}
+    moved = 0
+    for _ in range(rounds):
+        O.RELU_TAPS = {}
+        try:
+            with torch.no_grad():
+                fn(oracle_leaves(sd), sample, cfg)
+            taps = O.RELU_TAPS
+        finally:
+            O.RELU_TAPS = None
+        n = 0
+        for tag, m in taps.items():
+            idx = torch.nonzero(m < margin).flatten()
+            if idx.numel():
+                b = sd[tag + ".bias"]
+                b[idx] = b[idx] + torch.tensor(bump, dtype=b.dtype)
+                n += idx.numel()
+        moved += n
+        if n == 0:
+            return sd, moved
+    raise AssertionError("could not move the ReLU pre-activations away from zero in %d rounds" % rounds)
 
 
 def cpu_sample(sample):
@@ -70,3 +103,36 @@ def max_abs_rel(got, ref):
     assert got.shape == ref.shape, (got.shape, ref.shape)
     assert torch.isfinite(got).all()
     return float((got - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+
+
+def assert_grads_close_fp32(got, ref, relu_min_abs, tol=1e-3, tie=1e-4, max_tie_rows=0.01):
+    """Every gradient within tol * max(1, |ref|max) — except the rows of a ReLU fc1 weight / bias whose neuron is a TIE: its
+    pre-activation came within `tie` of zero for some token (oracle.RELU_TAPS), where ReLU' is discontinuous and two correct fp32
+    evaluations may pick different sides.  Such rows are exempt from the max-abs bound (at most `max_tie_rows` of a tensor's
+    rows, and the tensor must still agree to 1e-2 in relative L2); any other entry beyond the bound fails.
+    Returns (number of tensors compared, worst error outside ties, number of tie rows excused)."""
+    n, worst, excused = 0, ("", 0.0), 0
+    for name, r in ref.items():
+        g = got.get(name)
+        if g is None and r is None:
+            continue
+        r = r.detach().float().cpu() if r is not None else torch.zeros_like(g.detach().float().cpu())
+        g = g.detach().float().cpu() if g is not None else torch.zeros_like(r)
+        assert g.shape == r.shape and torch.isfinite(g).all(), name
+        scale = max(1.0, float(r.abs().max()))
+        err = (g - r).abs() / scale
+        tag = name.rsplit(".", 1)[0]
+        if tag in relu_min_abs and float(err.max()) > tol:
+            ties = relu_min_abs[tag] < tie
+            bad_rows = err.reshape(err.shape[0], -1).amax(dim=1) > tol
+            assert not bool((bad_rows & ~ties).any()), "grad %s: %.3e on a neuron that is no ReLU tie" % (name, float(err[bad_rows & ~ties].max()))
+            assert int(bad_rows.sum()) <= max(1, int(max_tie_rows * err.shape[0])), "grad %s: %d rows beyond %.0e" % (name, int(bad_rows.sum()), tol)
+            rel = float((g - r).norm() / r.norm())
+            assert rel <= 1e-2, "grad %s: relative L2 error %.3e" % (name, rel)
+            excused += int(bad_rows.sum())
+            err = err[~bad_rows]
+        e = float(err.max()) if err.numel() else 0.0
+        worst = max(worst, (name, e), key=lambda t: t[1])
+        assert e <= tol, "grad %s: %.3e" % (name, e)
+        n += 1
+    return n, worst, excused

@@ -21,7 +21,7 @@ import pytest
 import torch
 
 from conftest import GOLDEN, golden_sample, load_golden, load_pkg
-from parity_util import cpu_sample, max_abs_rel, run_oracle
+from parity_util import assert_grads_close_fp32, cpu_sample, detie, max_abs_rel, run_oracle
 from test_model_gpu import assert_close, to_cuda
 
 pytestmark = pytest.mark.gpu
@@ -39,7 +39,8 @@ def _build_stock(arch, V, dtype=torch.float32, seed=1, **over):
     tasks = import_module("chimera-st_amd.tasks")
     torch.manual_seed(seed)
     task = tasks.SpeechToTextTask(Namespace(data=None, synthetic_vocab_size=V))
-    args = Namespace(arch=arch, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, share_decoder_input_output_embed=True,
+    untied = over.pop("untied", False)
+    args = Namespace(arch=arch, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, share_decoder_input_output_embed=not untied,
                      input_feat_per_channel=80, input_channels=1, **over)
     reg.ARCH_CONFIG_REGISTRY[arch](args)
     model = s2t.S2TTransformerModel.build_model(args, task)
@@ -112,7 +113,9 @@ def test_config1_s2t_transformer_s_one_step_against_oracle():
     tasks = import_module("chimera-st_amd.tasks")
     sample = tasks.synthetic_sample(task.target_dictionary, B, lens, [40, 33, 61, 17, 25, 48, 30, 22], None, seed=7, sort=False)
     sample["net_input"]["src_tokens"] = feats
-    sd0 = {k: v.detach().cpu().clone() for k, v in tr.get_model().state_dict().items()}
+    sd0, moved = detie(O.lsce_criterion_s2t, {k: v.detach().cpu() for k, v in tr.get_model().state_dict().items()}, cpu_sample(sample), _s2t_cfg(args))
+    tr.get_model().load_state_dict(sd0)  # same tensors on both sides, no ReLU pre-activation within 1e-4 of the kink
+    tr.optimizer.master.copy_(tr.buffers.flat_param.float())
     out = tr.train_step([sample])
     ref, rgrads = run_oracle(O.lsce_criterion_s2t, sd0, cpu_sample(sample), _s2t_cfg(args))
     rl = float(ref["loss"])
@@ -120,11 +123,9 @@ def test_config1_s2t_transformer_s_one_step_against_oracle():
     assert out["sample_size"] == sample["ntokens"]
     names = [n for n, _ in tr.get_model().named_parameters()]
     flat = tr.buffers.flat_grad
-    worst = 0.0
-    for p, o, n in zip(tr.buffers.params, tr.buffers.offsets, names):
-        e = max_abs_rel(flat[o:o + p.numel()].view(p.shape), rgrads[n] if rgrads[n] is not None else torch.zeros(p.shape))
-        worst = max(worst, e)
-        assert e <= 1e-3, "grad %s: %.3e" % (n, e)
+    got = {n: flat[o:o + p.numel()].view(p.shape) for p, o, n in zip(tr.buffers.params, tr.buffers.offsets, names)}
+    _, (wname, worst), excused = assert_grads_close_fp32(got, {n: rgrads[n] for n in names}, ref["relu_min_abs"])
+    assert excused == 0
     # the update itself: multiply_grads(1 / sample_size), clip 10, Adam, lr 2e-3 (no warm-up)
     grads = [(rgrads[n] if rgrads[n] is not None else torch.zeros_like(sd0[n])) / float(sample["ntokens"]) for n in names]
     gnorm = O.clip_grad_norm_(grads, 10.0)
@@ -137,7 +138,8 @@ def test_config1_s2t_transformer_s_one_step_against_oracle():
             big = gr.abs() > 1e-3 * gr.abs().max()
             if big.any():
                 assert float((p.detach().float().cpu() - want)[big].abs().max()) <= 2e-4, n
-    print("config 1 (s2t_transformer_s, 8 x 10 s fbank): loss %.4f vs oracle %.4f, worst gradient error %.2e" % (out["loss"], rl, worst))
+    print("config 1 (s2t_transformer_s, 8 x 10 s fbank): loss %.4f vs oracle %.4f, worst gradient error %.2e (%s), %d fc1 biases moved off the ReLU kink"
+          % (out["loss"], rl, worst, wname, moved))
 
 
 def _write_wav(path, x):
@@ -204,13 +206,21 @@ def test_config1_wav_input_one_step_through_the_driver(tmp_path, capsys):
     rl = float(ref["loss"]) / sample["ntokens"] / math.log(2)  # the driver logs loss / sample_size in base 2
     assert inner[0]["loss"] == pytest.approx(rl, rel=1e-4), (inner[0]["loss"], rl)
     names = [n for n, _ in tr.get_model().named_parameters()]
-    worst = 0.0
-    for p, o, n in zip(tr.buffers.params, tr.buffers.offsets, names):
-        r = rgrads.get(n)
-        e = max_abs_rel(tr.buffers.flat_grad[o:o + p.numel()].view(p.shape), r if r is not None else torch.zeros(p.shape))
-        worst = max(worst, e)
-        assert e <= 1e-3, "grad %s: %.3e" % (n, e)
-    print("config 1 (wav input through the driver): loss/token %.5f vs oracle %.5f, worst gradient error %.2e" % (inner[0]["loss"], rl, worst))
+    got = {n: tr.buffers.flat_grad[o:o + p.numel()].view(p.shape) for p, o, n in zip(tr.buffers.params, tr.buffers.offsets, names)}
+    _, (wname, worst), excused = assert_grads_close_fp32(got, {n: rgrads.get(n) for n in names}, ref["relu_min_abs"])
+    print("config 1 (wav input through the driver): loss/token %.5f vs oracle %.5f, worst gradient error %.2e (%s), %d ReLU-tie rows excused"
+          % (inner[0]["loss"], rl, worst, wname, excused))
+    # the driver's own random parameters may sit on a ReLU kink (rows excused above); the SAME trainer, batch and code path once
+    # more with the parameters moved off it: every gradient entry within 1e-3, nothing excused
+    sd2, moved = detie(O.lsce_criterion, sd, cpu_sample(sample), cfg)
+    tr.get_model().load_state_dict(sd2)
+    out2 = tr.train_step([sample])
+    ref2, rgrads2 = run_oracle(O.lsce_criterion, sd2, cpu_sample(sample), cfg)
+    assert out2["loss"] == pytest.approx(float(ref2["loss"]), rel=1e-4)
+    got2 = {n: tr.buffers.flat_grad[o:o + p.numel()].view(p.shape) for p, o, n in zip(tr.buffers.params, tr.buffers.offsets, names)}
+    _, (wname2, worst2), excused2 = assert_grads_close_fp32(got2, {n: rgrads2.get(n) for n in names}, ref2["relu_min_abs"])
+    assert excused2 == 0
+    print("config 1 (wav input, %d fc1 biases moved off the kink): worst gradient error %.2e (%s)" % (moved, worst2, wname2))
 
 
 # ------------------------------------------------------------------------------------------------------------------------
@@ -219,11 +229,10 @@ def test_config5_s2t_transformer_l_full_depth_beam5():
     fp32, 32 utterances x up to 30 s of filter banks, beam 5: device engine == host mirror loop on EVERY token id of every
     hypothesis; on a 2-sentence slice both == oracle.beam_search (CPU) on the same parameters."""
     from oracle import chimera_oracle as O
-    model, task, args = _build_stock("s2t_transformer_l", 10000, seed=5)
+    model, task, args = _build_stock("s2t_transformer_l", 10000, seed=5, untied=True)
     assert (args.encoder_layers, args.decoder_layers, args.encoder_embed_dim, args.encoder_attention_heads) == (12, 6, 1024, 16)
-    with torch.no_grad():  # sharpen the output distribution (a tied random-init model otherwise repeats one token)
-        model.decoder.embed_tokens.weight.mul_(3.0)
-        model.decoder.embed_tokens.weight[1].zero_()
+    with torch.no_grad():  # sharpen the output distribution (a tied random-init model repeats one token; an untied one wanders)
+        model.decoder.output_projection.weight.mul_(4.0)
     model.eval()
     SG = import_module("chimera-st_amd.sequence_generator").SequenceGenerator
     g = torch.Generator().manual_seed(9)
@@ -248,7 +257,6 @@ def test_config5_s2t_transformer_l_full_depth_beam5():
     # oracle on the last two sentences (the shortest: least CPU time), same parameters
     sl = [B - 2, B - 1]
     p = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-    p["decoder.output_projection.weight"] = p["decoder.embed_tokens.weight"]
     with torch.no_grad():
         tmax = lens[sl[0]]
         enc, pm = O.s2t_encoder(p, src[sl, :tmax], torch.tensor([lens[i] for i in sl]), _s2t_cfg(args))

@@ -100,18 +100,21 @@ def _hip_forward_backward(trainer, sample, chimera):
 @pytest.mark.parametrize("model", ["s2t_w2v2", "chimera"])
 def test_full_dimension_fp32_parity_with_oracle(model):
     """fp32 storage: loss <= 1e-4 relative, logits / memory / EVERY parameter gradient <= 1e-3 * max(1, |ref|max)
-    (BASELINE north_star: 'logits/grads within 1e-3')."""
+    (BASELINE north_star: 'logits/grads within 1e-3'), no exemptions.  The random parameters are first moved off the ReLU
+    kink (parity_util.detie: a pre-activation within rounding of 0 makes the gradient itself ill-defined)."""
     from oracle import chimera_oracle as O
-    from parity_util import cpu_sample, max_abs_rel, run_oracle
+    from parity_util import assert_grads_close_fp32, cpu_sample, max_abs_rel, run_oracle
+    from parity_util import detie
     chimera = model == "chimera"
     trainer, task, ns, sample, cfg = _build_full(model, "f32")
+    fn = O.triplet_criterion if chimera else O.lsce_criterion
+    sd, moved = detie(fn, {k: v.detach().cpu() for k, v in trainer.get_model().state_dict().items()}, cpu_sample(sample), cfg)
+    trainer.get_model().load_state_dict(sd)  # the same tensors on both sides; no ReLU pre-activation within 1e-4 of the kink
     loss, log, logits, memory, grads, stats = _hip_forward_backward(trainer, sample, chimera)
     # every exact-skipping path must have been live in this run (DESIGN §5.2b-d)
     assert stats.get("attn_kv_len", 0) > 0 and stats.get("attn_q_flags", 0) > 0 and stats.get("gemm_k_len", 0) > 0, stats
     if not chimera:  # the Chimera memory attends every padded frame (quirk Q1): no dead token blocks inside wav2vec2 there
         assert stats.get("gemm_k_live", 0) > 0 and stats.get("gemm_m_live", 0) > 0, stats
-    sd = {k: v.detach().cpu() for k, v in trainer.get_model().state_dict().items()}
-    fn = O.triplet_criterion if chimera else O.lsce_criterion
     ref, rgrads = run_oracle(fn, sd, cpu_sample(sample), cfg)
     rl = float(ref["loss"])
     assert abs(loss - rl) <= 1e-4 * abs(rl), "loss %.6f vs oracle %.6f" % (loss, rl)
@@ -121,21 +124,11 @@ def test_full_dimension_fp32_parity_with_oracle(model):
         assert max_abs_rel(memory, ref["memory_audio"]) <= 1e-3
     e = max_abs_rel(logits, ref["st_logits"] if chimera else ref["logits"])
     assert e <= 1e-3, "logits: %.3e" % e
-    worst = ("", 0.0)
-    n = 0
-    for name, r in rgrads.items():
-        if name not in grads:
-            continue
-        if grads[name] is None and r is None:
-            continue
-        got = grads[name] if grads[name] is not None else torch.zeros_like(r)
-        r = r if r is not None else torch.zeros_like(got)
-        e = max_abs_rel(got, r)
-        worst = max(worst, (name, e), key=lambda t: t[1])
-        assert e <= 1e-3, "grad %s: %.3e" % (name, e)
-        n += 1
-    print("%s fp32 full-dim: loss %.4f (oracle %.4f), %d gradients, worst %s %.2e, skip stats %s" % (model, loss, rl, n, worst[0], worst[1], stats))
-    assert n > 300
+    n, worst, excused = assert_grads_close_fp32({k: grads.get(k) for k in rgrads if k in grads}, {k: v for k, v in rgrads.items() if k in grads},
+                                                ref["relu_min_abs"])
+    print("%s fp32 full-dim: loss %.4f (oracle %.4f), %d gradients, worst %s %.2e, %d fc1 biases moved off the ReLU kink, skip stats %s"
+          % (model, loss, rl, n, worst[0], worst[1], moved, stats))
+    assert n > 300 and excused == 0  # every gradient entry within 1e-3, no exemption used
 
 
 @pytest.mark.parametrize("model", ["s2t_w2v2", "chimera"])

@@ -748,3 +748,79 @@ def test_live_tile_stamps_are_dropped_when_the_gradient_is_rewritten():
     assert F_._tiles_of(t, rows + 64) is None
     t.add_(1.0)                                                                   # in-place accumulation
     assert F_._tiles_of(t, rows) is None and F_._tiles_of(t.transpose(0, 1).transpose(0, 1), rows) is None
+
+
+# --------------------------------------------------------------------------------------------
+# cst_embed_pos_fwd / cst_embed_bwd / cst_dropout_scale against the oracle's make_positions / sinusoidal table
+# (restated from modules/sinusoidal_positional_embedding.py:36-105, utils.py:235-245) and F.embedding's gradient
+# --------------------------------------------------------------------------------------------
+def _tokens(B, T, V, pad, seed, lens):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.randint(4, V, (B, T), generator=g)
+    for b, l in enumerate(lens):
+        t[b, l:] = pad
+    t[0, 3] = pad  # a pad INSIDE a sequence: make_positions does not count it and gives it the pad position
+    t[:, 1] = t[:, 0]  # repeated symbols: several occurrences feed one row of the table gradient
+    return t
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,T,C,V", [(3, 7, 64, 60), (32, 128, 512, 10000), (5, 300, 1024, 997)])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_embed_positions_token_path(K, dt, B, T, C, V, p):
+    from oracle import chimera_oracle as O
+    k, L = K
+    pad, scale, key = 1, math.sqrt(C), 0xBEEF01
+    lens = [T - (3 * b) % (T - 5) for b in range(B)]
+    tok = _tokens(B, T, V, pad, 5, lens)
+    E = rnd(V, C, dt=dt, seed=6, scale=C ** -0.5)
+    E[pad].zero_()
+    table = O.sinusoidal_table(pad + 1 + T + 9, C, pad).cuda()
+    out = k.embed_pos_fwd(tok.cuda(), None, E, None, table, scale, pad, p, key)
+    ref = scale * E.float()[tok.cuda()] + O.positional_embedding(tok, C, pad).cuda()
+    keep = _keep(key, B * T * C, p).view(B, T, C).cuda() if p > 0 else torch.ones(B, T, C, dtype=torch.bool, device="cuda")
+    ref = torch.where(keep, ref / (1 - p), torch.zeros_like(ref))
+    check(out, ref, dt, "embed_pos fwd")
+    assert float(out[0, 3].float().abs().max()) == 0.0  # pad symbol: zero embedding row + the zero pad row of the table
+    # table gradient: deterministic, pad row untouched, equals scale * index_add of the (masked) upstream gradient
+    dy = rnd(B, T, C, dt=dt, seed=7)
+    dE = k.embed_bwd(dy, tok.cuda().view(-1), V, scale, pad, p, key, dt)
+    dE2 = k.embed_bwd(dy, tok.cuda().view(-1), V, scale, pad, p, key, dt)
+    assert torch.equal(dE, dE2)
+    g = torch.where(keep, dy.float() / (1 - p), torch.zeros_like(dy.float())) * scale
+    want = torch.zeros(V, C, device="cuda").index_add_(0, tok.cuda().view(-1), g.view(-1, C))
+    want[pad].zero_()
+    check(dE, want, dt, "embed bwd")
+    assert float(dE[pad].float().abs().max()) == 0.0
+    unused = torch.ones(V, dtype=torch.bool)
+    unused[tok.view(-1)] = False
+    assert float(dE[unused.cuda()].float().abs().max() if unused.any() else 0.0) == 0.0
+    dE32 = k.embed_bwd(dy, tok.cuda().view(-1), V, scale, pad, p, key, torch.float32)  # fp32 accumulation buffer variant
+    check(dE32, want, torch.float32 if dt == torch.float32 else dt, "embed bwd fp32 out")
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("with_pos", [True, False])
+def test_embed_positions_dense_path_and_mask_source(K, dt, with_pos):
+    """The encoders' form: dense features scaled by sqrt(d), positions from the 0/1 padding mask (`mask.ne(padding_idx)`)."""
+    from oracle import chimera_oracle as O
+    k, L = K
+    B, T, C, pad, p, key = 4, 93, 512, 1, 0.2, 4242
+    lens = torch.tensor([93, 80, 41, 7])
+    mask = torch.arange(T)[None, :] >= lens[:, None]
+    x = rnd(B, T, C, dt=dt, seed=2)
+    table = O.sinusoidal_table(pad + 1 + T, C, pad).cuda() if with_pos else None
+    scale = math.sqrt(C)
+    out = k.embed_pos_fwd(None, mask.to(torch.uint8).cuda() if with_pos else None, None, x, table, scale, pad, p, key)
+    ref = scale * x.float() + (O.positional_embedding(mask, C, pad).cuda() if with_pos else 0.0)
+    keep = _keep(key, B * T * C, p).view(B, T, C).cuda()
+    check(out, torch.where(keep, ref / (1 - p), torch.zeros_like(ref)), dt, "embed_pos dense fwd")
+    dy = rnd(B, T, C, dt=dt, seed=3)
+    dx = k.dropout_scale(dy, scale, p, key)
+    check(dx, torch.where(keep, dy.float() * scale / (1 - p), torch.zeros_like(dy.float())), dt, "dropout_scale")
+    # token ids with a mask as the position source (the Chimera text encoder): embedding from the ids, positions from the mask
+    if with_pos:
+        tok = torch.randint(4, 50, (B, T), generator=torch.Generator().manual_seed(1))
+        E = rnd(50, C, dt=dt, seed=9)
+        out = k.embed_pos_fwd(tok.cuda(), mask.to(torch.uint8).cuda(), E, None, table, scale, pad, 0.0, 0)
+        check(out, scale * E.float()[tok.cuda()] + O.positional_embedding(mask, C, pad).cuda(), dt, "embed_pos ids + mask")
