@@ -19,15 +19,14 @@ namespace {
 
 constexpr int KMAX = 16;
 
-// ---- pass A: per-utterance moments m[k], G[k][k] (fp32 atomics of block partials) -------------
-__global__ void conv0_gram_kernel(const float* wav, float* gram, int64_t S, int64_t L, int k, int stride) {
+// ---- pass A: per-utterance moments m[k], G[k][k]: per-block partials in a fixed layout [B][gridDim.x][k*k+k] (no atomics:
+//      the statistics — and with them every activation of the network — are bit-reproducible run to run) ----------------
+__global__ void conv0_gram_kernel(const float* wav, float* part, int64_t S, int64_t L, int k, int stride) {
   const int64_t b = blockIdx.y;
   const float* x = wav + b * S;
-  float* g = gram + b * (k * k + k);
   const int nacc = k * k + k;
-  __shared__ float red[KMAX * KMAX + KMAX];
-  for (int i = threadIdx.x; i < nacc; i += blockDim.x) red[i] = 0.0f;
-  __syncthreads();
+  float* g = part + (b * gridDim.x + blockIdx.x) * nacc;
+  __shared__ float red[4][KMAX * KMAX + KMAX];
   float m[KMAX], G[KMAX * (KMAX + 1) / 2];
 #pragma unroll
   for (int j = 0; j < KMAX; ++j) m[j] = 0.0f;
@@ -45,31 +44,43 @@ __global__ void conv0_gram_kernel(const float* wav, float* gram, int64_t S, int6
       for (int j2 = j; j2 < KMAX; ++j2) G[idx++] += xv[j] * xv[j2];
     }
   }
+  const int wave = threadIdx.x >> 6;
   int idx = 0;
 #pragma unroll
   for (int j = 0; j < KMAX; ++j) {
     const float mj = wave_sum(m[j]);
-    if ((threadIdx.x & 63) == 0 && j < k) atomicAdd(&red[k * k + j], mj);
+    if ((threadIdx.x & 63) == 0 && j < k) red[wave][k * k + j] = mj;
 #pragma unroll
     for (int j2 = j; j2 < KMAX; ++j2) {
       const float gj = wave_sum(G[idx++]);
       if ((threadIdx.x & 63) == 0 && j < k && j2 < k) {
-        atomicAdd(&red[j * k + j2], gj);
-        if (j2 != j) atomicAdd(&red[j2 * k + j], gj);
+        red[wave][j * k + j2] = gj;
+        red[wave][j2 * k + j] = gj;
       }
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < nacc; i += blockDim.x) atomicAdd(&g[i], red[i]);
+  for (int i = threadIdx.x; i < nacc; i += blockDim.x) g[i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);  // blockDim.x == 256
 }
 
 // ---- pass B: mean/rstd per (b,c) from the moments --------------------------------------------
 template <typename T>
-__global__ void conv0_stats_kernel(const T* w, const float* gram, float* mean, float* rstd, int64_t C, int64_t L, int k, float eps) {
+__global__ void conv0_stats_kernel(const T* w, const float* part, int nparts, float* gram, float* mean, float* rstd, int64_t C, int64_t L, int k,
+                                   float eps) {
+  // fixed-order sum of the block partials (every block of an utterance redoes it: nparts * 110 floats out of L2), kept in LDS;
+  // block 0 also publishes it as gram[b] for the backward pass
+  __shared__ float g[KMAX * KMAX + KMAX];
   const int64_t b = blockIdx.y;
+  const int nacc = k * k + k;
+  for (int i = threadIdx.x; i < nacc; i += blockDim.x) {
+    double a = 0.0;
+    for (int q = 0; q < nparts; ++q) a += (double)part[(b * nparts + q) * nacc + i];
+    g[i] = (float)a;
+    if (blockIdx.x == 0) gram[b * nacc + i] = (float)a;
+  }
+  __syncthreads();
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const float* g = gram + b * (k * k + k);
   double wm = 0.0, wgw = 0.0;
   for (int j = 0; j < k; ++j) {
     const double wj = (double)DT<T>::ld(w + c * k + j);
@@ -128,8 +139,9 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* wav, const 
 }
 
 // ---- backward pass over dy: per (b,c) accumulate s1, s2, r[0..k) --------------------------------
-// acc layout in ws: [B][k+2][C]  (row 0 = s1, row 1 = s2, rows 2.. = r[j])
-constexpr int C0_BWD_TB = 1024;  // frames per block (fewer, larger blocks: the per-block result goes out as fp32 atomics)
+// partial layout in ws: [B][gridDim.x][k+2][C]  (row 0 = s1, row 1 = s2, rows 2.. = r[j]); conv0_bwd_reduce_kernel adds the blocks of
+// an utterance in a fixed order into [B][k+2][C] (no atomics: bit-reproducible gradients)
+constexpr int C0_BWD_TB = 2048;  // frames per block (fewer, larger blocks: the per-block result goes out as one partial row set)
 
 template <typename T>
 __global__ __launch_bounds__(256) void conv0_bwd_kernel(const T* dy, const float* wav, const T* w, const T* gamma,
@@ -192,8 +204,8 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(const T* dy, const float
       }
     }
     // combine the frame-lanes that share this channel vector through LDS (one 8-float row of the accumulator set at a
-    // time, so the staging area is 8 KiB), then ONE atomic per value per block instead of one per thread.
-    float* o = ws + b * (k + 2) * (int64_t)C + ccv * 8;
+    // time, so the staging area is 8 KiB), then ONE store per value per block.
+    float* o = ws + (b * gridDim.x + blockIdx.x) * (k + 2) * (int64_t)C + ccv * 8;
 #pragma unroll
     for (int row = 0; row < KMAX + 2; ++row) {
       if (row < k + 2) {  // wave-uniform
@@ -207,7 +219,7 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(const T* dy, const float
           for (int e = 0; e < 8; ++e) {
             float v = 0.0f;
             for (int t2 = 0; t2 < tpc; ++t2) v += sm[(size_t)(t2 * cvecs + ccv) * 8 + e];
-            atomicAdd(o + (int64_t)row * C + e, v);
+            o[(int64_t)row * C + e] = v;
           }
         }
       }
@@ -284,7 +296,7 @@ __global__ __launch_bounds__(256) void conv0_fwd_reg_kernel(const float* wav, co
   }
 }
 
-constexpr int C0R_BWD_TB = 1024;  // frames per block (backward)
+constexpr int C0R_BWD_TB = 2048;  // frames per block (backward)
 
 template <typename T, int KC>
 __global__ __launch_bounds__(256) void conv0_bwd_reg_kernel(const T* dy, const float* wav, const T* w, const T* gamma,
@@ -335,8 +347,8 @@ __global__ __launch_bounds__(256) void conv0_bwd_reg_kernel(const T* dy, const f
       for (int j = 0; j < KC; ++j) r[j][e] = fmaf(dz, xv[j], r[j][e]);
     }
   }
-  // combine the `fp` frame-lanes of each channel quad through LDS (4 floats per thread per round), one atomic per value
-  float* o = ws + b * (KC + 2) * (int64_t)C + c0;
+  // combine the `fp` frame-lanes of each channel quad through LDS (4 floats per thread per round), one store per value
+  float* o = ws + (b * gridDim.x + blockIdx.x) * (KC + 2) * (int64_t)C + c0;
 #pragma unroll
   for (int row = 0; row < KC + 2; ++row) {
     __syncthreads();
@@ -349,9 +361,20 @@ __global__ __launch_bounds__(256) void conv0_bwd_reg_kernel(const T* dy, const f
       for (int e = 0; e < 4; ++e) {
         float v = 0.0f;
         for (int t2 = 0; t2 < fp; ++t2) v += sm[(size_t)(t2 * tpf + cq) * 4 + e];
-        atomicAdd(o + (int64_t)row * C + e, v);
+        o[(int64_t)row * C + e] = v;
       }
     }
+  }
+}
+
+// fixed-order sum of an utterance's block partials: part [B][nblk][rows][C] -> acc [B][rows][C]; grid (B, rows), one thread per channel
+__global__ void conv0_bwd_reduce_kernel(const float* part, float* acc, int nblk, int rows, int C) {
+  const int64_t b = blockIdx.x;
+  const int row = blockIdx.y;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float a = 0.0f;
+    for (int q = 0; q < nblk; ++q) a += part[((b * nblk + q) * rows + row) * (int64_t)C + c];
+    acc[(b * rows + row) * (int64_t)C + c] = a;
   }
 }
 
@@ -387,10 +410,17 @@ __global__ void conv0_bwd_finish_kernel(const float* ws, const float* gram, cons
 
 }  // namespace
 
+static int conv0_gram_blocks(int64_t L) { return (int)(cst_ceil_div(L, 256 * 8) < 64 ? cst_ceil_div(L, 256 * 8) : 64); }
+
+extern "C" int64_t cst_conv0_fwd_workspace(int64_t B, int64_t S, int k, int stride) {
+  const int64_t L = S >= k ? (S - k) / stride + 1 : 0;
+  return B * (int64_t)conv0_gram_blocks(L) * (k * k + k) * (int64_t)sizeof(float);
+}
+
 extern "C" int cst_conv0_gn_gelu_fwd(const float* wav, const void* w, const void* gamma, const void* beta, void* y,
-                                     float* mean, float* rstd, float* gram, int64_t B, int64_t S, int64_t C, int k,
+                                     float* mean, float* rstd, float* gram, float* workspace, int64_t B, int64_t S, int64_t C, int k,
                                      int stride, float eps, int dtype, cst_stream stream) {
-  CST_REQUIRE(wav && w && gamma && beta && y && mean && rstd && gram, "cst_conv0_gn_gelu_fwd: null tensor");
+  CST_REQUIRE(wav && w && gamma && beta && y && mean && rstd && gram && workspace, "cst_conv0_gn_gelu_fwd: null tensor");
   CST_REQUIRE(k >= 1 && k <= KMAX && stride >= 1 && S >= k, "cst_conv0_gn_gelu_fwd: unsupported k=%d stride=%d S=%lld", k, stride, (long long)S);
   CST_REQUIRE(C % 8 == 0 && C >= 8 && C / 8 <= 256, "cst_conv0_gn_gelu_fwd: C=%lld must be a multiple of 8 and <= 2048", (long long)C);
   CST_REQUIRE(dtype == CST_F32 || dtype == CST_BF16, "cst_conv0_gn_gelu_fwd: bad dtype %d", dtype);
@@ -398,27 +428,35 @@ extern "C" int cst_conv0_gn_gelu_fwd(const float* wav, const void* w, const void
   hipStream_t s = (hipStream_t)stream;
   const double bytes = (double)B * S * 4.0 * 2.0 + (double)B * L * C * cst_dtype_size(dtype);
   CstProfScope prof(CST_K_CONV0, s, 2.0 * (double)B * L * C * k, bytes);
-  if (hipMemsetAsync(gram, 0, sizeof(float) * B * (k * k + k), s) != hipSuccess) { cst_set_error("conv0: memset failed"); return CST_ERR_LAUNCH; }
-  int gb = (int)(cst_ceil_div(L, 256 * 8) < 64 ? cst_ceil_div(L, 256 * 8) : 64);
-  hipLaunchKernelGGL(conv0_gram_kernel, dim3(gb, (unsigned)B), dim3(256), 0, s, wav, gram, S, L, k, stride);
+  const int gb = conv0_gram_blocks(L);
+  hipLaunchKernelGGL(conv0_gram_kernel, dim3(gb, (unsigned)B), dim3(256), 0, s, wav, workspace, S, L, k, stride);
   const size_t lds = sizeof(float) * ((size_t)k * C + C + (size_t)C0_TB * stride + k);
   dim3 sg((unsigned)cst_ceil_div(C, 128), (unsigned)B), fg((unsigned)cst_ceil_div(L, C0_TB), (unsigned)B);
   const bool reg_path = k == 10 && C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0;
   const size_t lds_r = sizeof(float) * ((size_t)C0R_TB * stride + k);
   dim3 fgr((unsigned)cst_ceil_div(L, C0R_TB), (unsigned)B);
   if (dtype == CST_BF16) {
-    hipLaunchKernelGGL(conv0_stats_kernel<bf16_t>, sg, dim3(128), 0, s, (const bf16_t*)w, gram, mean, rstd, C, L, k, eps);
+    hipLaunchKernelGGL(conv0_stats_kernel<bf16_t>, sg, dim3(128), 0, s, (const bf16_t*)w, workspace, gb, gram, mean, rstd, C, L, k, eps);
     if (reg_path) hipLaunchKernelGGL((conv0_fwd_reg_kernel<bf16_t, 10>), fgr, dim3(256), lds_r, s, wav, (const bf16_t*)w, (const bf16_t*)gamma, (const bf16_t*)beta, mean, rstd, (bf16_t*)y, S, L, (int)C, stride);
     else hipLaunchKernelGGL(conv0_fwd_kernel<bf16_t>, fg, dim3(256), lds, s, wav, (const bf16_t*)w, (const bf16_t*)gamma, (const bf16_t*)beta, mean, rstd, (bf16_t*)y, S, L, (int)C, k, stride);
   } else {
-    hipLaunchKernelGGL(conv0_stats_kernel<float>, sg, dim3(128), 0, s, (const float*)w, gram, mean, rstd, C, L, k, eps);
+    hipLaunchKernelGGL(conv0_stats_kernel<float>, sg, dim3(128), 0, s, (const float*)w, workspace, gb, gram, mean, rstd, C, L, k, eps);
     if (reg_path) hipLaunchKernelGGL((conv0_fwd_reg_kernel<float, 10>), fgr, dim3(256), lds_r, s, wav, (const float*)w, (const float*)gamma, (const float*)beta, mean, rstd, (float*)y, S, L, (int)C, stride);
     else hipLaunchKernelGGL(conv0_fwd_kernel<float>, fg, dim3(256), lds, s, wav, (const float*)w, (const float*)gamma, (const float*)beta, mean, rstd, (float*)y, S, L, (int)C, k, stride);
   }
   return cst_check_launch("cst_conv0_gn_gelu_fwd");
 }
 
-extern "C" int64_t cst_conv0_bwd_workspace(int64_t B, int64_t C, int k) { return B * (int64_t)(k + 2) * C * (int64_t)sizeof(float); }
+static int conv0_bwd_blocks(int64_t L, int k, int64_t C) {
+  const bool reg_path = k == 10 && C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0;
+  return (int)cst_ceil_div(L, reg_path ? C0R_BWD_TB : C0_BWD_TB);
+}
+
+/* [B][nblk][k+2][C] block partials followed by the reduced [B][k+2][C] */
+extern "C" int64_t cst_conv0_bwd_workspace(int64_t B, int64_t S, int64_t C, int k, int stride) {
+  const int64_t L = S >= k ? (S - k) / stride + 1 : 0;
+  return B * (int64_t)(conv0_bwd_blocks(L, k, C) + 1) * (k + 2) * C * (int64_t)sizeof(float);
+}
 
 extern "C" int cst_conv0_gn_gelu_bwd(const void* dy, const float* wav, const void* w, const void* gamma, const void* beta,
                                      const float* mean, const float* rstd, const float* gram, float* dw, float* dgamma,
@@ -432,7 +470,9 @@ extern "C" int cst_conv0_gn_gelu_bwd(const void* dy, const float* wav, const voi
   hipStream_t s = (hipStream_t)stream;
   const double bytes = (double)B * S * 4.0 + (double)B * L * C * cst_dtype_size(dtype);
   CstProfScope prof(CST_K_CONV0, s, 4.0 * (double)B * L * C * k, bytes);
-  if (hipMemsetAsync(workspace, 0, (size_t)cst_conv0_bwd_workspace(B, C, k), s) != hipSuccess) { cst_set_error("conv0 bwd: memset failed"); return CST_ERR_LAUNCH; }
+  const int nblk = conv0_bwd_blocks(L, k, C);
+  float* acc = workspace + (size_t)B * nblk * (k + 2) * C;  // the reduced [B][k+2][C] behind the partials
+  const dim3 rg((unsigned)B, (unsigned)(k + 2));
   size_t lds = sizeof(float) * ((size_t)k * C + 4 * C + (size_t)C0_BWD_TB * stride + k);
   dim3 grid((unsigned)cst_ceil_div(L, C0_BWD_TB), (unsigned)B), fg((unsigned)cst_ceil_div(C, 128));
   const bool reg_path = k == 10 && C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0;
@@ -442,19 +482,23 @@ extern "C" int cst_conv0_gn_gelu_bwd(const void* dy, const float* wav, const voi
     dim3 gr((unsigned)cst_ceil_div(L, C0R_BWD_TB), (unsigned)B);
     if (dtype == CST_BF16) {
       hipLaunchKernelGGL((conv0_bwd_reg_kernel<bf16_t, 10>), gr, dim3(256), lds_r, s, (const bf16_t*)dy, wav, (const bf16_t*)w, (const bf16_t*)gamma, (const bf16_t*)beta, mean, rstd, workspace, S, L, (int)C, stride);
-      hipLaunchKernelGGL(conv0_bwd_finish_kernel<bf16_t>, fg, dim3(128), 0, s, workspace, gram, (const bf16_t*)w, (const bf16_t*)gamma, mean, rstd, dw, dgamma, dbeta, B, C, L, k);
+      hipLaunchKernelGGL(conv0_bwd_reduce_kernel, rg, dim3(256), 0, s, workspace, acc, nblk, k + 2, (int)C);
+      hipLaunchKernelGGL(conv0_bwd_finish_kernel<bf16_t>, fg, dim3(128), 0, s, acc, gram, (const bf16_t*)w, (const bf16_t*)gamma, mean, rstd, dw, dgamma, dbeta, B, C, L, k);
     } else {
       hipLaunchKernelGGL((conv0_bwd_reg_kernel<float, 10>), gr, dim3(256), lds_r, s, (const float*)dy, wav, (const float*)w, (const float*)gamma, (const float*)beta, mean, rstd, workspace, S, L, (int)C, stride);
-      hipLaunchKernelGGL(conv0_bwd_finish_kernel<float>, fg, dim3(128), 0, s, workspace, gram, (const float*)w, (const float*)gamma, mean, rstd, dw, dgamma, dbeta, B, C, L, k);
+      hipLaunchKernelGGL(conv0_bwd_reduce_kernel, rg, dim3(256), 0, s, workspace, acc, nblk, k + 2, (int)C);
+      hipLaunchKernelGGL(conv0_bwd_finish_kernel<float>, fg, dim3(128), 0, s, acc, gram, (const float*)w, (const float*)gamma, mean, rstd, dw, dgamma, dbeta, B, C, L, k);
     }
     return cst_check_launch("cst_conv0_gn_gelu_bwd");
   }
   if (dtype == CST_BF16) {
     hipLaunchKernelGGL(conv0_bwd_kernel<bf16_t>, grid, dim3(256), lds, s, (const bf16_t*)dy, wav, (const bf16_t*)w, (const bf16_t*)gamma, (const bf16_t*)beta, mean, rstd, workspace, S, L, (int)C, k, stride);
-    hipLaunchKernelGGL(conv0_bwd_finish_kernel<bf16_t>, fg, dim3(128), 0, s, workspace, gram, (const bf16_t*)w, (const bf16_t*)gamma, mean, rstd, dw, dgamma, dbeta, B, C, L, k);
+    hipLaunchKernelGGL(conv0_bwd_reduce_kernel, rg, dim3(256), 0, s, workspace, acc, nblk, k + 2, (int)C);
+    hipLaunchKernelGGL(conv0_bwd_finish_kernel<bf16_t>, fg, dim3(128), 0, s, acc, gram, (const bf16_t*)w, (const bf16_t*)gamma, mean, rstd, dw, dgamma, dbeta, B, C, L, k);
   } else {
     hipLaunchKernelGGL(conv0_bwd_kernel<float>, grid, dim3(256), lds, s, (const float*)dy, wav, (const float*)w, (const float*)gamma, (const float*)beta, mean, rstd, workspace, S, L, (int)C, k, stride);
-    hipLaunchKernelGGL(conv0_bwd_finish_kernel<float>, fg, dim3(128), 0, s, workspace, gram, (const float*)w, (const float*)gamma, mean, rstd, dw, dgamma, dbeta, B, C, L, k);
+    hipLaunchKernelGGL(conv0_bwd_reduce_kernel, rg, dim3(256), 0, s, workspace, acc, nblk, k + 2, (int)C);
+    hipLaunchKernelGGL(conv0_bwd_finish_kernel<float>, fg, dim3(128), 0, s, acc, gram, (const float*)w, (const float*)gamma, mean, rstd, dw, dgamma, dbeta, B, C, L, k);
   }
   return cst_check_launch("cst_conv0_gn_gelu_bwd");
 }

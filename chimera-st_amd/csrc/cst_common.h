@@ -6,7 +6,7 @@
 #include <math.h>
 #include "../../include/cst.h"
 
-#define CST_ABI_VERSION 1
+#define CST_ABI_VERSION 2
 #define CST_WAVE 64
 
 // ---------------------------------------------------------------------------------------

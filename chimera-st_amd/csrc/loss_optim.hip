@@ -32,7 +32,7 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 
 // loss_row = (1-eps) * (lse - x_t) + (eps/V) * (V*lse - sum_v x_v);   nll_row = lse - x_t
 template <typename T>
-__global__ __launch_bounds__(256) void ls_ce_fwd_kernel(const T* logits, const int64_t* target, float* out2, float* lse_out,
+__global__ __launch_bounds__(256) void ls_ce_fwd_kernel(const T* logits, const int64_t* target, float* rows2, float* lse_out,
                                                         int64_t V, float eps, int64_t pad) {
   __shared__ float red[4];
   const int64_t row = blockIdx.x;
@@ -52,12 +52,32 @@ __global__ __launch_bounds__(256) void ls_ce_fwd_kernel(const T* logits, const i
     const float lse = mx + __logf(se);
     lse_out[row] = lse;
     const int64_t t = target[row];
+    float l = 0.0f, nll = 0.0f;
     if (t != pad) {
-      const float nll = lse - DT<T>::ld(x + t);
+      nll = lse - DT<T>::ld(x + t);
       const float smooth = (float)V * lse - sx;
-      atomicAdd(out2, (1.0f - eps) * nll + (eps / (float)V) * smooth);
-      atomicAdd(out2 + 1, nll);
+      l = (1.0f - eps) * nll + (eps / (float)V) * smooth;
     }
+    rows2[2 * row] = l;  // per-row terms; sum_pairs_kernel adds them in a fixed order (bit-reproducible loss, no atomics)
+    rows2[2 * row + 1] = nll;
+  }
+}
+
+// out[j] = sum_i v[i * stride + j], j < stride <= 2: ONE block, fixed order (strided per-thread partial sums in double, then a
+// fixed LDS tree) — the run-to-run reproducible replacement of "atomicAdd a per-row term into a scalar"
+__global__ __launch_bounds__(256) void sum_pairs_kernel(const float* v, int64_t n, int stride, float* out) {
+  __shared__ double red[256];
+  for (int j = 0; j < stride; ++j) {
+    double a = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) a += (double)v[i * stride + j];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[j] = (float)red[0];
+    __syncthreads();
   }
 }
 
@@ -133,7 +153,7 @@ __global__ void adam_kernel(float* master, float* m, float* v, const TG* grad, T
 constexpr int CM = 64, CK = 32;
 
 template <typename T>
-__global__ __launch_bounds__(256) void contrastive_fwd_kernel(const T* a, const T* t, float* loss, float* sim, float* na, float* nt,
+__global__ __launch_bounds__(256) void contrastive_fwd_kernel(const T* a, const T* t, float* loss_rows, float* sim, float* na, float* nt,
                                                               int M, int C, float inv_temp) {
   __shared__ float sA[CM][CK + 1], sT[CM][CK + 1], sS[CM][CM + 1], red[4];
   const int b = blockIdx.x, tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
@@ -186,7 +206,7 @@ __global__ __launch_bounds__(256) void contrastive_fwd_kernel(const T* a, const 
     l = mx + __logf(se) - sS[tid][tid] * inv_temp;
   }
   l = block_sum(l, red);
-  if (tid == 0) atomicAdd(loss, l);
+  if (tid == 0) loss_rows[b] = l;  // per-utterance term; summed in a fixed order by sum_pairs_kernel
 }
 
 template <typename T>
@@ -265,14 +285,15 @@ __global__ __launch_bounds__(256) void contrastive_bwd_kernel(const T* a, const 
 
 }  // namespace
 
-extern "C" int cst_ls_ce_fwd(const void* logits, const int64_t* target, float* out2, float* lse, int64_t rows, int64_t V,
+extern "C" int cst_ls_ce_fwd(const void* logits, const int64_t* target, float* out2, float* lse, float* row_ws, int64_t rows, int64_t V,
                              float eps, int64_t pad_idx, int dtype, cst_stream stream) {
-  CST_REQUIRE(logits && target && out2 && lse && rows > 0 && V > 0, "cst_ls_ce_fwd: bad args");
+  CST_REQUIRE(logits && target && out2 && lse && row_ws && rows > 0 && V > 0, "cst_ls_ce_fwd: bad args");
   CST_REQUIRE(dtype == CST_F32 || dtype == CST_BF16, "cst_ls_ce_fwd: bad dtype");
   hipStream_t s = (hipStream_t)stream;
   CstProfScope prof(CST_K_LOSS, s, 0.0, (double)rows * V * cst_dtype_size(dtype));
-  if (dtype == CST_BF16) hipLaunchKernelGGL(ls_ce_fwd_kernel<bf16_t>, dim3((unsigned)rows), dim3(256), 0, s, (const bf16_t*)logits, target, out2, lse, V, eps, pad_idx);
-  else hipLaunchKernelGGL(ls_ce_fwd_kernel<float>, dim3((unsigned)rows), dim3(256), 0, s, (const float*)logits, target, out2, lse, V, eps, pad_idx);
+  if (dtype == CST_BF16) hipLaunchKernelGGL(ls_ce_fwd_kernel<bf16_t>, dim3((unsigned)rows), dim3(256), 0, s, (const bf16_t*)logits, target, row_ws, lse, V, eps, pad_idx);
+  else hipLaunchKernelGGL(ls_ce_fwd_kernel<float>, dim3((unsigned)rows), dim3(256), 0, s, (const float*)logits, target, row_ws, lse, V, eps, pad_idx);
+  hipLaunchKernelGGL(sum_pairs_kernel, dim3(1), dim3(256), 0, s, row_ws, rows, 2, out2);
   return cst_check_launch("cst_ls_ce_fwd");
 }
 
@@ -321,14 +342,15 @@ extern "C" int cst_adam_step(float* master, float* exp_avg, float* exp_avg_sq, c
   return cst_check_launch("cst_adam_step");
 }
 
-extern "C" int cst_contrastive_fwd(const void* a, const void* t, float* loss, float* sim, float* na, float* nt, int64_t B, int64_t M,
+extern "C" int cst_contrastive_fwd(const void* a, const void* t, float* loss, float* loss_rows, float* sim, float* na, float* nt, int64_t B, int64_t M,
                                    int64_t C, float temp, int dtype, cst_stream stream) {
-  CST_REQUIRE(a && t && loss && sim && na && nt && B > 0 && M > 0 && M <= 64 && C > 0 && temp > 0.0f, "cst_contrastive_fwd: bad args (M <= 64)");
+  CST_REQUIRE(a && t && loss && loss_rows && sim && na && nt && B > 0 && M > 0 && M <= 64 && C > 0 && temp > 0.0f, "cst_contrastive_fwd: bad args (M <= 64)");
   CST_REQUIRE(dtype == CST_F32 || dtype == CST_BF16, "cst_contrastive_fwd: bad dtype");
   hipStream_t s = (hipStream_t)stream;
   CstProfScope prof(CST_K_LOSS, s, 2.0 * B * M * M * C, 2.0 * B * M * C * cst_dtype_size(dtype));
-  if (dtype == CST_BF16) hipLaunchKernelGGL(contrastive_fwd_kernel<bf16_t>, dim3((unsigned)B), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)t, loss, sim, na, nt, (int)M, (int)C, 1.0f / temp);
-  else hipLaunchKernelGGL(contrastive_fwd_kernel<float>, dim3((unsigned)B), dim3(256), 0, s, (const float*)a, (const float*)t, loss, sim, na, nt, (int)M, (int)C, 1.0f / temp);
+  if (dtype == CST_BF16) hipLaunchKernelGGL(contrastive_fwd_kernel<bf16_t>, dim3((unsigned)B), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)t, loss_rows, sim, na, nt, (int)M, (int)C, 1.0f / temp);
+  else hipLaunchKernelGGL(contrastive_fwd_kernel<float>, dim3((unsigned)B), dim3(256), 0, s, (const float*)a, (const float*)t, loss_rows, sim, na, nt, (int)M, (int)C, 1.0f / temp);
+  hipLaunchKernelGGL(sum_pairs_kernel, dim3(1), dim3(256), 0, s, loss_rows, B, 1, loss);
   return cst_check_launch("cst_contrastive_fwd");
 }
 

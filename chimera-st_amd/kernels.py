@@ -240,8 +240,10 @@ def conv0_fwd(wav, w, gamma, beta, k, stride, eps=1e-5):
     mean = torch.empty(B, C, dtype=torch.float32, device=wav.device)
     rstd = torch.empty(B, C, dtype=torch.float32, device=wav.device)
     gram = torch.empty(B, k * k + k, dtype=torch.float32, device=wav.device)
-    L.check(L.load().cst_conv0_gn_gelu_fwd(L.ptr(wav), L.ptr(w), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(mean), L.ptr(rstd),
-                                           L.ptr(gram), B, S, C, k, stride, eps, L.dtype_code(w.dtype), L.stream_ptr()),
+    lib = L.load()
+    ws = workspace(lib.cst_conv0_fwd_workspace(B, S, k, stride), wav.device)
+    L.check(lib.cst_conv0_gn_gelu_fwd(L.ptr(wav), L.ptr(w), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(mean), L.ptr(rstd),
+                                      L.ptr(gram), L.ptr(ws), B, S, C, k, stride, eps, L.dtype_code(w.dtype), L.stream_ptr()),
             "cst_conv0_gn_gelu_fwd")
     return y, mean, rstd, gram
 
@@ -253,7 +255,7 @@ def conv0_bwd(dy, wav, w, gamma, beta, mean, rstd, gram, k, stride):
     dw = torch.empty(C, k, dtype=torch.float32, device=wav.device)
     dg = torch.empty(C, dtype=torch.float32, device=wav.device)
     db = torch.empty(C, dtype=torch.float32, device=wav.device)
-    ws = workspace(lib.cst_conv0_bwd_workspace(B, C, k), wav.device)
+    ws = workspace(lib.cst_conv0_bwd_workspace(B, S, C, k, stride), wav.device)
     L.check(lib.cst_conv0_gn_gelu_bwd(L.ptr(dy), L.ptr(wav), L.ptr(w), L.ptr(gamma), L.ptr(beta), L.ptr(mean), L.ptr(rstd),
                                       L.ptr(gram), L.ptr(dw), L.ptr(dg), L.ptr(db), L.ptr(ws), B, S, C, k, stride,
                                       L.dtype_code(w.dtype), L.stream_ptr()), "cst_conv0_gn_gelu_bwd")
@@ -354,8 +356,8 @@ def dropout_scale(x, alpha, p, key):
 
 def embed_pos_fwd(tokens, pad_mask, embed, x, pos_table, scale, pad_idx, p, key):
     """dropout(scale * (embed[tokens] | x) + pos_table[make_positions(pad_mask | tokens)]) -> [B, T, C] (include/cst.h)."""
-    ref = tokens if tokens is not None else pad_mask
-    B, T = ref.shape
+    ref = tokens if tokens is not None else (pad_mask if pad_mask is not None else x)
+    B, T = ref.shape[0], ref.shape[1]
     src = embed if embed is not None else x
     C = src.shape[-1]
     V = embed.shape[0] if embed is not None else 0
@@ -382,9 +384,10 @@ def embed_bwd(dy, tokens, V, scale, pad_idx, p, key, grad_dtype):
 def ls_ce_fwd(logits, target, eps, pad):
     logits = _2d(logits)
     rows, V = logits.shape
-    out2 = torch.zeros(2, dtype=torch.float32, device=logits.device)
+    out2 = torch.empty(2, dtype=torch.float32, device=logits.device)
     lse = torch.empty(rows, dtype=torch.float32, device=logits.device)
-    L.check(L.load().cst_ls_ce_fwd(L.ptr(logits), L.ptr(target), L.ptr(out2), L.ptr(lse), rows, V, eps, pad,
+    ws = workspace(2 * rows * 4, logits.device)
+    L.check(L.load().cst_ls_ce_fwd(L.ptr(logits), L.ptr(target), L.ptr(out2), L.ptr(lse), L.ptr(ws), rows, V, eps, pad,
                                    L.dtype_code(logits.dtype), L.stream_ptr()), "cst_ls_ce_fwd")
     return out2, lse
 
@@ -407,11 +410,12 @@ def sumsq(x, out):
 def contrastive_fwd(a, t, temp):
     """a, t [B, M, C] contiguous -> (loss fp32[1], sim, na, nt)."""
     B, M, C = a.shape
-    loss = torch.zeros(1, dtype=torch.float32, device=a.device)
+    loss = torch.empty(1, dtype=torch.float32, device=a.device)
     sim = torch.empty(B, M, M, dtype=torch.float32, device=a.device)
     na = torch.empty(B, M, dtype=torch.float32, device=a.device)
     nt = torch.empty_like(na)
-    L.check(L.load().cst_contrastive_fwd(L.ptr(a), L.ptr(t), L.ptr(loss), L.ptr(sim), L.ptr(na), L.ptr(nt), B, M, C, float(temp),
+    ws = workspace(B * 4, a.device)
+    L.check(L.load().cst_contrastive_fwd(L.ptr(a), L.ptr(t), L.ptr(loss), L.ptr(ws), L.ptr(sim), L.ptr(na), L.ptr(nt), B, M, C, float(temp),
                                          L.dtype_code(a.dtype), L.stream_ptr()), "cst_contrastive_fwd")
     return loss, sim, na, nt
 

@@ -97,8 +97,9 @@ SYMBOLS = [
     ("cst_gemm", c_int, [ctypes.POINTER(GemmDesc), c_p]),
     ("cst_attn_fwd", c_int, [ctypes.POINTER(AttnDesc), c_p]),
     ("cst_attn_bwd", c_int, [ctypes.POINTER(AttnDesc), c_p]),
-    ("cst_conv0_gn_gelu_fwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_int, c_int, c_f, c_int, c_p]),
-    ("cst_conv0_bwd_workspace", c_i64, [c_i64, c_i64, c_int]),
+    ("cst_conv0_fwd_workspace", c_i64, [c_i64, c_i64, c_int, c_int]),
+    ("cst_conv0_gn_gelu_fwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_int, c_int, c_f, c_int, c_p]),
+    ("cst_conv0_bwd_workspace", c_i64, [c_i64, c_i64, c_i64, c_int, c_int]),
     ("cst_conv0_gn_gelu_bwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_p]),
     ("cst_glu_fwd", c_int, [c_p, c_p, c_i64, c_i64, c_int, c_p]),
     ("cst_glu_bwd", c_int, [c_p, c_p, c_p, c_i64, c_i64, c_int, c_p]),
@@ -114,9 +115,9 @@ SYMBOLS = [
     ("cst_dropout_scale", c_int, [c_p, c_p, c_i64, c_f, c_f, ctypes.c_uint32, c_int, c_p]),
     ("cst_embed_pos_fwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_f, c_i64, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_f, ctypes.c_uint32, c_int, c_p]),
     ("cst_embed_bwd", c_int, [c_p, c_p, c_p, c_f, c_i64, c_i64, c_i64, c_i64, c_f, ctypes.c_uint32, c_int, c_int, c_p]),
-    ("cst_ls_ce_fwd", c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_f, c_i64, c_int, c_p]),
+    ("cst_ls_ce_fwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_f, c_i64, c_int, c_p]),
     ("cst_ls_ce_bwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_f, c_i64, c_int, c_p]),
-    ("cst_contrastive_fwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_int, c_p]),
+    ("cst_contrastive_fwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_int, c_p]),
     ("cst_contrastive_bwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_int, c_p]),
     ("cst_sumsq_workspace", c_i64, []),
     ("cst_sumsq", c_int, [c_p, c_i64, c_p, c_p, c_int, c_p]),

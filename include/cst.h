@@ -200,12 +200,16 @@ int cst_attn_bwd(const cst_attn_desc* d, cst_stream stream);
  *   mean,rstd fp32 [B,C];  gram fp32 [B, k*k + k] (per-utterance lag moments, saved for backward);
  *   L = (S-k)/stride + 1;  k <= 16;  C % 8 == 0.
  * ------------------------------------------------------------------------------------------ */
+/* workspace: cst_conv0_fwd_workspace() bytes — per-block partial moments, added up in a fixed order (no atomics: the statistics,
+ * and with them the whole forward pass, are bit-reproducible run to run). */
+int64_t cst_conv0_fwd_workspace(int64_t B, int64_t S, int k, int stride);
 int cst_conv0_gn_gelu_fwd(const float* wav, const void* w, const void* gamma, const void* beta,
-                          void* y, float* mean, float* rstd, float* gram, int64_t B, int64_t S,
+                          void* y, float* mean, float* rstd, float* gram, float* workspace, int64_t B, int64_t S,
                           int64_t C, int k, int stride, float eps, int dtype, cst_stream stream);
 /* dw [C,k], dgamma [C], dbeta [C] are fp32 and overwritten.
- * workspace: cst_conv0_bwd_workspace() bytes (zeroed by the call). */
-int64_t cst_conv0_bwd_workspace(int64_t B, int64_t C, int k);
+ * workspace: cst_conv0_bwd_workspace() bytes — per-block partial sums [B][blocks][k+2][C] + their fixed-order reduction
+ * (no atomics: bit-reproducible gradients). */
+int64_t cst_conv0_bwd_workspace(int64_t B, int64_t S, int64_t C, int k, int stride);
 int cst_conv0_gn_gelu_bwd(const void* dy, const float* wav, const void* w, const void* gamma,
                           const void* beta, const float* mean, const float* rstd, const float* gram,
                           float* dw, float* dgamma, float* dbeta, float* workspace,
@@ -276,11 +280,12 @@ int cst_embed_bwd(const void* dy, const int64_t* tokens, void* dE, float scale, 
  * Label-smoothed cross entropy over vocabulary logits — replaces fp32 log_softmax
  * (models/fairseq_decoder.py:75-79 -> utils.py:469-473) + label_smoothed_nll_loss
  * (criterions/label_smoothed_cross_entropy.py:13-30), reduce=True, ignore_index=pad.
- *   logits [rows, V] (dtype), target int64 [rows];  out fp32[2] += {loss_sum, nll_sum} (caller zeroes);
- *   lse fp32 [rows] saved for backward.
+ *   logits [rows, V] (dtype), target int64 [rows];  out2 fp32[2] = {loss_sum, nll_sum} (overwritten);
+ *   lse fp32 [rows] saved for backward;  row_ws fp32 [2 * rows]: the per-row terms, added up in a fixed order by a second
+ *   one-workgroup kernel (no atomics: the loss is bit-reproducible run to run).
  * bwd: dlogits = gscale * d loss / d logits  (gscale = upstream grad of the summed loss).
  * ------------------------------------------------------------------------------------------ */
-int cst_ls_ce_fwd(const void* logits, const int64_t* target, float* out2, float* lse,
+int cst_ls_ce_fwd(const void* logits, const int64_t* target, float* out2, float* lse, float* row_ws,
                   int64_t rows, int64_t V, float eps, int64_t pad_idx, int dtype, cst_stream stream);
 int cst_ls_ce_bwd(const void* logits, const int64_t* target, const float* lse, const float* gscale,
                   void* dlogits, int64_t rows, int64_t V, float eps, int64_t pad_idx, int dtype,
@@ -290,10 +295,11 @@ int cst_ls_ce_bwd(const void* logits, const int64_t* target, const float* lse, c
  * Contrastive term of TripletSTMTContrastiveCriterion.compute_contrastive
  * (criterions/triplet_st_mt_contrastive.py:154-169): a = audio memory, t = text memory, both [B, M, C] batch-major
  * (M <= 64 slots); c[b,i,j] = cosine(a[b,i], t[b,j]) (fp32, eps 1e-8), logits = c / temp with the AUDIO slot as class
- * dim and target(j) = j;  loss[0] += sum_b sum_j ( logsumexp_i - logits[j][j] )  (caller zeroes loss).
+ * dim and target(j) = j;  loss[0] = sum_b sum_j ( logsumexp_i - logits[j][j] )  (overwritten; loss_rows fp32 [B] holds the
+ * per-utterance terms, added up in a fixed order).
  * sim fp32 [B,M,M], na/nt fp32 [B,M] (norms) are saved for backward;  bwd: da, dt = gscale[0] * d loss / d a, t.
  * ------------------------------------------------------------------------------------------ */
-int cst_contrastive_fwd(const void* a, const void* t, float* loss, float* sim, float* na, float* nt,
+int cst_contrastive_fwd(const void* a, const void* t, float* loss, float* loss_rows, float* sim, float* na, float* nt,
                         int64_t B, int64_t M, int64_t C, float temp, int dtype, cst_stream stream);
 int cst_contrastive_bwd(const void* a, const void* t, const float* sim, const float* na, const float* nt,
                         const float* gscale, void* da, void* dt, int64_t B, int64_t M, int64_t C, float temp,
