@@ -779,8 +779,10 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
     p.k_len = no_klive ? nullptr : d->k_len;
   }
   {
-    static const int gm = getenv("CST_GEMM8P_GROUP_M") ? atoi(getenv("CST_GEMM8P_GROUP_M")) : 8;
-    p.group_m = gm > 0 ? gm : 8;
+    // m tiles per group of the XCD-local tile walk: 4 (a 4 x 8 patch of concurrent tiles per XCD) measured 2-8 % faster than 8 on the
+    // N = 768 / 2304 / 3072 Linear shapes at M = 47 968 (same-box sweep over 2 / 4 / 8 / 16 / 32, tools/bench_gemm4w.py)
+    static const int gm = getenv("CST_GEMM8P_GROUP_M") ? atoi(getenv("CST_GEMM8P_GROUP_M")) : 4;
+    p.group_m = gm > 0 ? gm : 4;
   }
   p.splits = choose_splits(d);
   p.ws = nullptr;

@@ -67,12 +67,16 @@ def _st(x):
 # RELU_TAPS = {} the oracle records, per fc1 (tag = parameter prefix), the smallest |pre-activation| each neuron saw over all
 # tokens, so that a parity test can tell such ties from errors (tests/parity_util.py::assert_grads_close_fp32).
 RELU_TAPS = None
+RELU_FULL = None  # {} -> also keep every pre-activation [tokens, neurons] per fc1 (tests/parity_util.py::detie picks bias nudges from them)
 
 
 def _relu(x, tag):
     if RELU_TAPS is not None:
-        m = x.detach().abs().reshape(-1, x.shape[-1]).amin(dim=0)
+        z = x.detach().reshape(-1, x.shape[-1])
+        m = z.abs().amin(dim=0)
         RELU_TAPS[tag] = torch.minimum(RELU_TAPS[tag], m) if tag in RELU_TAPS else m
+        if RELU_FULL is not None:
+            RELU_FULL[tag] = torch.cat((RELU_FULL[tag], z), 0) if tag in RELU_FULL else z
     return torch.relu(x)
 
 

@@ -41,29 +41,41 @@ def run_oracle(fn, state_dict, sample, cfg, storage=None, **kw):
     return out, grads
 
 
-def detie(fn, state_dict, sample, cfg, margin=1e-4, bump=2e-2, rounds=8):
+def detie(fn, state_dict, sample, cfg, margin=1e-4, rounds=12):
     """ReLU is not differentiable at 0; two correct fp32 evaluations of a pre-activation that lies within rounding of 0 can fall
     on different sides of the kink and then differ by a whole term in every gradient behind it.  To compare gradients at 1e-3
     WITHOUT exemptions the parity tests pick their (random) parameters away from that measure-zero set: the oracle's forward
-    pass records the smallest |pre-activation| of every fc1 neuron (oracle.RELU_TAPS); neurons that come within `margin` of
-    zero for some token get their bias moved by `bump`.  Returns (state dict — same tensors for both sides —, neurons moved)."""
+    pass records every fc1 pre-activation (oracle.RELU_FULL); a neuron that comes within `margin` of zero for some token gets
+    its bias moved by the SMALLEST amount (a few margins) that leaves none of its tokens within 2 x margin — small enough not
+    to re-shuffle the layers behind it.  Returns (state dict — the same tensors go to both sides —, number of biases moved)."""
     sd = {k: v.clone() for k, v in state_dict.items()}
     moved = 0
+    cand = [s * k * margin for k in range(2, 60) for s in (1.0, -1.0)]
     for _ in range(rounds):
-        O.RELU_TAPS = {}
+        O.RELU_TAPS, O.RELU_FULL = {}, {}
         try:
             with torch.no_grad():
                 fn(oracle_leaves(sd), sample, cfg)
-            taps = O.RELU_TAPS
+            taps, full = O.RELU_TAPS, O.RELU_FULL
         finally:
-            O.RELU_TAPS = None
+            O.RELU_TAPS, O.RELU_FULL = None, None
         n = 0
         for tag, m in taps.items():
-            idx = torch.nonzero(m < margin).flatten()
-            if idx.numel():
-                b = sd[tag + ".bias"]
-                b[idx] = b[idx] + torch.tensor(bump, dtype=b.dtype)
-                n += idx.numel()
+            idx = torch.nonzero(m < margin).flatten().tolist()
+            if not idx:
+                continue
+            b = sd[tag + ".bias"]
+            z = full[tag]
+            for j in idx:
+                col = z[:, j]
+                near = col[col.abs() < 64 * margin]
+                for c in cand:
+                    if float((near + c).abs().min()) >= 2 * margin:
+                        b[j] = b[j] + torch.tensor(c, dtype=b.dtype)
+                        break
+                else:
+                    raise AssertionError("no bias nudge clears neuron %s[%d]" % (tag, j))
+                n += 1
         moved += n
         if n == 0:
             return sd, moved
