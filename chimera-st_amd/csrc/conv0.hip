@@ -21,37 +21,38 @@ constexpr int KMAX = 16;
 
 // ---- pass A: per-utterance moments m[k], G[k][k]: per-block partials in a fixed layout [B][gridDim.x][k*k+k] (no atomics:
 //      the statistics — and with them every activation of the network — are bit-reproducible run to run) ----------------
+template <int KC>  // KC = k when k is a supported compile-time size (no padded taps: 55 instead of 136 products per frame at k = 10), else KMAX
 __global__ void conv0_gram_kernel(const float* wav, float* part, int64_t S, int64_t L, int k, int stride) {
   const int64_t b = blockIdx.y;
   const float* x = wav + b * S;
   const int nacc = k * k + k;
   float* g = part + (b * gridDim.x + blockIdx.x) * nacc;
   __shared__ float red[4][KMAX * KMAX + KMAX];
-  float m[KMAX], G[KMAX * (KMAX + 1) / 2];
+  float m[KC], G[KC * (KC + 1) / 2];
 #pragma unroll
-  for (int j = 0; j < KMAX; ++j) m[j] = 0.0f;
+  for (int j = 0; j < KC; ++j) m[j] = 0.0f;
 #pragma unroll
-  for (int j = 0; j < KMAX * (KMAX + 1) / 2; ++j) G[j] = 0.0f;
+  for (int j = 0; j < KC * (KC + 1) / 2; ++j) G[j] = 0.0f;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < L; t += (int64_t)gridDim.x * blockDim.x) {
-    float xv[KMAX];
+    float xv[KC];
 #pragma unroll
-    for (int j = 0; j < KMAX; ++j) xv[j] = j < k ? x[t * stride + j] : 0.0f;
+    for (int j = 0; j < KC; ++j) xv[j] = j < k ? x[t * stride + j] : 0.0f;
     int idx = 0;
 #pragma unroll
-    for (int j = 0; j < KMAX; ++j) {
+    for (int j = 0; j < KC; ++j) {
       m[j] += xv[j];
 #pragma unroll
-      for (int j2 = j; j2 < KMAX; ++j2) G[idx++] += xv[j] * xv[j2];
+      for (int j2 = j; j2 < KC; ++j2) G[idx++] += xv[j] * xv[j2];
     }
   }
   const int wave = threadIdx.x >> 6;
   int idx = 0;
 #pragma unroll
-  for (int j = 0; j < KMAX; ++j) {
+  for (int j = 0; j < KC; ++j) {
     const float mj = wave_sum(m[j]);
     if ((threadIdx.x & 63) == 0 && j < k) red[wave][k * k + j] = mj;
 #pragma unroll
-    for (int j2 = j; j2 < KMAX; ++j2) {
+    for (int j2 = j; j2 < KC; ++j2) {
       const float gj = wave_sum(G[idx++]);
       if ((threadIdx.x & 63) == 0 && j < k && j2 < k) {
         red[wave][j * k + j2] = gj;
@@ -381,31 +382,49 @@ __global__ void conv0_bwd_reduce_kernel(const float* part, float* acc, int nblk,
 // closed-form finish: dW[c][j], dgamma[c], dbeta[c] summed over utterances.
 //   du = (gamma rstd) (dz - s1/L - uhat s2/L);  dW[c][j] = sum_t du x[s t + j]
 //   sum_t uhat x_j = rstd (sum_j' w[c][j'] G[j'][j] - mean m[j])
+// One thread per (utterance, channel) evaluates its term in double (the k x k contraction: ~1000 fp64 operations); the utterances of
+// a channel are then added in index order through LDS.  (The first version looped the utterances inside one thread per channel:
+// 512 threads on the whole chip, 465 us per call.)  Block = FB utterances x FC channels.
+constexpr int FB = 32, FC = 8;
 template <typename T>
-__global__ void conv0_bwd_finish_kernel(const float* ws, const float* gram, const T* w, const T* gamma, const float* mean,
-                                        const float* rstd, float* dw, float* dgamma, float* dbeta, int64_t B, int64_t C,
-                                        int64_t L, int k) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double dg = 0.0, db = 0.0, dwj[KMAX];
-  for (int j = 0; j < k; ++j) dwj[j] = 0.0;
-  const double gam = (double)DT<T>::ld(gamma + c);
-  for (int64_t b = 0; b < B; ++b) {
-    const float* a = ws + b * (k + 2) * C;
-    const float* g = gram + b * (k * k + k);
-    const double s1 = a[c], s2 = a[C + c], rs = rstd[b * C + c], mu = mean[b * C + c];
-    dg += s2;
-    db += s1;
-    for (int j = 0; j < k; ++j) {
-      double wg = 0.0;
-      for (int j2 = 0; j2 < k; ++j2) wg += (double)DT<T>::ld(w + c * k + j2) * (double)g[j2 * k + j];
-      const double uhx = rs * (wg - mu * (double)g[k * k + j]);
-      dwj[j] += gam * rs * ((double)a[(2 + j) * C + c] - s1 / (double)L * (double)g[k * k + j] - s2 / (double)L * uhx);
+__global__ __launch_bounds__(FB * FC) void conv0_bwd_finish_kernel(const float* ws, const float* gram, const T* w, const T* gamma, const float* mean,
+                                                                    const float* rstd, float* dw, float* dgamma, float* dbeta, int64_t B, int64_t C,
+                                                                    int64_t L, int k) {
+  __shared__ double red[FB][FC][KMAX + 2];
+  const int cl = threadIdx.x % FC, bl = threadIdx.x / FC;
+  const int64_t c = (int64_t)blockIdx.x * FC + cl;
+  double tot[KMAX + 2];
+  for (int j = 0; j < k + 2; ++j) tot[j] = 0.0;
+  for (int64_t b0 = 0; b0 < B; b0 += FB) {
+    const int64_t b = b0 + bl;
+    double acc[KMAX + 2];
+    for (int j = 0; j < k + 2; ++j) acc[j] = 0.0;
+    if (b < B && c < C) {
+      const double gam = (double)DT<T>::ld(gamma + c);
+      const float* a = ws + b * (k + 2) * C;
+      const float* g = gram + b * (k * k + k);
+      const double s1 = a[c], s2 = a[C + c], rs = rstd[b * C + c], mu = mean[b * C + c];
+      acc[0] = s2;  // dgamma
+      acc[1] = s1;  // dbeta
+      for (int j = 0; j < k; ++j) {
+        double wg = 0.0;
+        for (int j2 = 0; j2 < k; ++j2) wg += (double)DT<T>::ld(w + c * k + j2) * (double)g[j2 * k + j];
+        const double uhx = rs * (wg - mu * (double)g[k * k + j]);
+        acc[2 + j] = gam * rs * ((double)a[(2 + j) * C + c] - s1 / (double)L * (double)g[k * k + j] - s2 / (double)L * uhx);
+      }
     }
+    for (int j = 0; j < k + 2; ++j) red[bl][cl][j] = acc[j];
+    __syncthreads();
+    if (bl == 0)
+      for (int j = 0; j < k + 2; ++j)
+        for (int q = 0; q < FB; ++q) tot[j] += red[q][cl][j];  // utterances in index order: deterministic
+    __syncthreads();
   }
-  dgamma[c] = (float)dg;
-  dbeta[c] = (float)db;
-  for (int j = 0; j < k; ++j) dw[c * k + j] = (float)dwj[j];
+  if (bl == 0 && c < C) {
+    dgamma[c] = (float)tot[0];
+    dbeta[c] = (float)tot[1];
+    for (int j = 0; j < k; ++j) dw[c * k + j] = (float)tot[2 + j];
+  }
 }
 
 }  // namespace
@@ -429,7 +448,8 @@ extern "C" int cst_conv0_gn_gelu_fwd(const float* wav, const void* w, const void
   const double bytes = (double)B * S * 4.0 * 2.0 + (double)B * L * C * cst_dtype_size(dtype);
   CstProfScope prof(CST_K_CONV0, s, 2.0 * (double)B * L * C * k, bytes);
   const int gb = conv0_gram_blocks(L);
-  hipLaunchKernelGGL(conv0_gram_kernel, dim3(gb, (unsigned)B), dim3(256), 0, s, wav, workspace, S, L, k, stride);
+  if (k == 10) hipLaunchKernelGGL(conv0_gram_kernel<10>, dim3(gb, (unsigned)B), dim3(256), 0, s, wav, workspace, S, L, k, stride);
+  else hipLaunchKernelGGL(conv0_gram_kernel<KMAX>, dim3(gb, (unsigned)B), dim3(256), 0, s, wav, workspace, S, L, k, stride);
   const size_t lds = sizeof(float) * ((size_t)k * C + C + (size_t)C0_TB * stride + k);
   dim3 sg((unsigned)cst_ceil_div(C, 128), (unsigned)B), fg((unsigned)cst_ceil_div(L, C0_TB), (unsigned)B);
   const bool reg_path = k == 10 && C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0;
@@ -474,7 +494,7 @@ extern "C" int cst_conv0_gn_gelu_bwd(const void* dy, const float* wav, const voi
   float* acc = workspace + (size_t)B * nblk * (k + 2) * C;  // the reduced [B][k+2][C] behind the partials
   const dim3 rg((unsigned)B, (unsigned)(k + 2));
   size_t lds = sizeof(float) * ((size_t)k * C + 4 * C + (size_t)C0_BWD_TB * stride + k);
-  dim3 grid((unsigned)cst_ceil_div(L, C0_BWD_TB), (unsigned)B), fg((unsigned)cst_ceil_div(C, 128));
+  dim3 grid((unsigned)cst_ceil_div(L, C0_BWD_TB), (unsigned)B), fg((unsigned)cst_ceil_div(C, FC));
   const bool reg_path = k == 10 && C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0;
   if (reg_path) {
     size_t lds_r = sizeof(float) * ((size_t)C0R_BWD_TB * stride + k);
@@ -483,22 +503,22 @@ extern "C" int cst_conv0_gn_gelu_bwd(const void* dy, const float* wav, const voi
     if (dtype == CST_BF16) {
       hipLaunchKernelGGL((conv0_bwd_reg_kernel<bf16_t, 10>), gr, dim3(256), lds_r, s, (const bf16_t*)dy, wav, (const bf16_t*)w, (const bf16_t*)gamma, (const bf16_t*)beta, mean, rstd, workspace, S, L, (int)C, stride);
       hipLaunchKernelGGL(conv0_bwd_reduce_kernel, rg, dim3(256), 0, s, workspace, acc, nblk, k + 2, (int)C);
-      hipLaunchKernelGGL(conv0_bwd_finish_kernel<bf16_t>, fg, dim3(128), 0, s, acc, gram, (const bf16_t*)w, (const bf16_t*)gamma, mean, rstd, dw, dgamma, dbeta, B, C, L, k);
+      hipLaunchKernelGGL(conv0_bwd_finish_kernel<bf16_t>, fg, dim3(FB * FC), 0, s, acc, gram, (const bf16_t*)w, (const bf16_t*)gamma, mean, rstd, dw, dgamma, dbeta, B, C, L, k);
     } else {
       hipLaunchKernelGGL((conv0_bwd_reg_kernel<float, 10>), gr, dim3(256), lds_r, s, (const float*)dy, wav, (const float*)w, (const float*)gamma, (const float*)beta, mean, rstd, workspace, S, L, (int)C, stride);
       hipLaunchKernelGGL(conv0_bwd_reduce_kernel, rg, dim3(256), 0, s, workspace, acc, nblk, k + 2, (int)C);
-      hipLaunchKernelGGL(conv0_bwd_finish_kernel<float>, fg, dim3(128), 0, s, acc, gram, (const float*)w, (const float*)gamma, mean, rstd, dw, dgamma, dbeta, B, C, L, k);
+      hipLaunchKernelGGL(conv0_bwd_finish_kernel<float>, fg, dim3(FB * FC), 0, s, acc, gram, (const float*)w, (const float*)gamma, mean, rstd, dw, dgamma, dbeta, B, C, L, k);
     }
     return cst_check_launch("cst_conv0_gn_gelu_bwd");
   }
   if (dtype == CST_BF16) {
     hipLaunchKernelGGL(conv0_bwd_kernel<bf16_t>, grid, dim3(256), lds, s, (const bf16_t*)dy, wav, (const bf16_t*)w, (const bf16_t*)gamma, (const bf16_t*)beta, mean, rstd, workspace, S, L, (int)C, k, stride);
     hipLaunchKernelGGL(conv0_bwd_reduce_kernel, rg, dim3(256), 0, s, workspace, acc, nblk, k + 2, (int)C);
-    hipLaunchKernelGGL(conv0_bwd_finish_kernel<bf16_t>, fg, dim3(128), 0, s, acc, gram, (const bf16_t*)w, (const bf16_t*)gamma, mean, rstd, dw, dgamma, dbeta, B, C, L, k);
+    hipLaunchKernelGGL(conv0_bwd_finish_kernel<bf16_t>, fg, dim3(FB * FC), 0, s, acc, gram, (const bf16_t*)w, (const bf16_t*)gamma, mean, rstd, dw, dgamma, dbeta, B, C, L, k);
   } else {
     hipLaunchKernelGGL(conv0_bwd_kernel<float>, grid, dim3(256), lds, s, (const float*)dy, wav, (const float*)w, (const float*)gamma, (const float*)beta, mean, rstd, workspace, S, L, (int)C, k, stride);
     hipLaunchKernelGGL(conv0_bwd_reduce_kernel, rg, dim3(256), 0, s, workspace, acc, nblk, k + 2, (int)C);
-    hipLaunchKernelGGL(conv0_bwd_finish_kernel<float>, fg, dim3(128), 0, s, acc, gram, (const float*)w, (const float*)gamma, mean, rstd, dw, dgamma, dbeta, B, C, L, k);
+    hipLaunchKernelGGL(conv0_bwd_finish_kernel<float>, fg, dim3(FB * FC), 0, s, acc, gram, (const float*)w, (const float*)gamma, mean, rstd, dw, dgamma, dbeta, B, C, L, k);
   }
   return cst_check_launch("cst_conv0_gn_gelu_bwd");
 }

@@ -10,18 +10,21 @@ namespace {
 
 constexpr int LN_MAXV = 4;       // 8-element vectors per lane -> cols <= 2048
 constexpr int LN_WAVES = 4;      // rows per block iteration
+// The kernels are instantiated per NV = vectors per lane actually needed (cols <= 512: 1, <= 1024: 2, else 4): with the generic 4 the
+// backward kernel allocates 160 VGPRs (3 waves per SIMD) for the 768-column rows of wav2vec2 that need 2 vectors (100 VGPRs, 5 waves
+// per SIMD) — a row is only 1.5 KB, so the bytes in flight, i.e. the HBM rate, scale with the resident waves.
 
-template <typename T>
+template <typename T, int NV>
 __global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(const T* x, const T* res, const T* gamma, const T* beta,
                                                               T* y, T* sum_out, float* mean, float* rstd,
                                                               int64_t rows, int cols, float eps) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = cols / 8;
   for (int64_t row = (int64_t)blockIdx.x * LN_WAVES + wave; row < rows; row += (int64_t)gridDim.x * LN_WAVES) {
-    float v[LN_MAXV][8];
+    float v[NV][8];
     float s = 0.0f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int vi = lane + 64 * i;
       if (vi < nvec) {
         load8(x + row * cols + vi * 8, v[i]);
@@ -39,14 +42,14 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(const T* x, const
     const float mu = wave_sum(s) / (float)cols;
     float q = 0.0f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i)
+    for (int i = 0; i < NV; ++i)
       if (lane + 64 * i < nvec) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mu; q += d * d; }
       }
     const float rs = rsqrtf(wave_sum(q) / (float)cols + eps);
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int vi = lane + 64 * i;
       if (vi < nvec) {
         float g[8], b[8], o[8];
@@ -61,39 +64,62 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(const T* x, const
   }
 }
 
+// 8 elements of a row in storage form
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> {
+  u32x4 r;
+  __device__ __forceinline__ void load(const bf16_t* p) { r = *reinterpret_cast<const u32x4*>(p); }
+  __device__ __forceinline__ void unpack(float (&v)[8]) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(r[i] << 16); v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
+  }
+};
+template <> struct Raw8<float> {
+  float f[8];
+  __device__ __forceinline__ void load(const float* p) { load8(p, f); }
+  __device__ __forceinline__ void unpack(float (&v)[8]) const {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = f[i];
+  }
+};
+
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma;  partial dgamma/dbeta per block.
-template <typename T>
-__global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(const T* dy, const T* s, const T* gamma, const float* mean,
+template <typename T, int NV>
+__global__ __launch_bounds__(LN_WAVES * 64, (NV <= 2 ? 4 : 2)) void ln_bwd_kernel(const T* dy, const T* s, const T* gamma, const float* mean,
                                                               const float* rstd, const T* dres, T* dx, float* part,
                                                               int64_t rows, int cols, uint32_t* tile_live, uint32_t epoch) {
   __shared__ float red[LN_WAVES][64 * 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = cols / 8;
-  float dg[LN_MAXV][8], db[LN_MAXV][8], gm[LN_MAXV][8];
+  float dg[NV][8], db[NV][8], gm[NV][8];
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { dg[i][e] = 0.0f; db[i][e] = 0.0f; gm[i][e] = 0.0f; }
     if (lane + 64 * i < nvec) load8(gamma + (lane + 64 * i) * 8, gm[i]);
   }
   for (int64_t row = (int64_t)blockIdx.x * LN_WAVES + wave; row < rows; row += (int64_t)gridDim.x * LN_WAVES) {
     const float mu = mean[row], rs = rstd[row];
-    float g[LN_MAXV][8], xh[LN_MAXV][8];
+    // the row is kept in its STORAGE form between the two passes (4 VGPRs per 8 bf16 elements instead of 8 + 8 floats of g and
+    // xhat) and unpacked twice: 16-32 fewer live registers buy a fourth wave per SIMD
+    Raw8<T> rd[NV], rx[NV];
     float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int vi = lane + 64 * i;
       if (vi < nvec) {
+        rd[i].load(dy + row * cols + vi * 8);
+        rx[i].load(s + row * cols + vi * 8);
         float d[8], xs[8];
-        load8(dy + row * cols + vi * 8, d);
-        load8(s + row * cols + vi * 8, xs);
+        rd[i].unpack(d);
+        rx[i].unpack(xs);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          xh[i][e] = (xs[e] - mu) * rs;
-          g[i][e] = d[e] * gm[i][e];
-          s1 += g[i][e];
-          s2 += g[i][e] * xh[i][e];
-          dg[i][e] += d[e] * xh[i][e];
+          const float xh = (xs[e] - mu) * rs;
+          const float g = d[e] * gm[i][e];
+          s1 += g;
+          s2 += g * xh;
+          dg[i][e] += d[e] * xh;
           db[i][e] += d[e];
         }
       }
@@ -102,12 +128,14 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(const T* dy, cons
     s2 = wave_sum(s2) / (float)cols;
     bool nz = false;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int vi = lane + 64 * i;
       if (vi < nvec) {
-        float o[8];
+        float d[8], xs[8], o[8];
+        rd[i].unpack(d);
+        rx[i].unpack(xs);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = rs * (g[i][e] - s1 - xh[i][e] * s2);
+        for (int e = 0; e < 8; ++e) o[e] = rs * (d[e] * gm[i][e] - s1 - (xs[e] - mu) * rs * s2);
         if (dres) {
           float r[8];
           load8(dres + row * cols + vi * 8, r);
@@ -127,7 +155,7 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(const T* dy, cons
   float* pg = part + (int64_t)blockIdx.x * 2 * cols;
   float* pb = pg + cols;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     for (int pass = 0; pass < 2; ++pass) {
       __syncthreads();
 #pragma unroll
@@ -170,10 +198,11 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* part, 
   }
 }
 
-int ln_blocks(int64_t rows) {
+int ln_blocks(int64_t rows, int cap = 1024) {
   int64_t b = cst_ceil_div(rows, LN_WAVES);
-  return (int)(b < 1024 ? b : 1024);
+  return (int)(b < cap ? b : cap);
 }
+inline int ln_nv(int64_t cols) { return cols <= 512 ? 1 : (cols <= 1024 ? 2 : 4); }
 
 }  // namespace
 
@@ -185,17 +214,20 @@ extern "C" int cst_layernorm_fwd(const void* x, const void* res, const void* gam
   hipStream_t s = (hipStream_t)stream;
   const double bytes = (double)rows * cols * cst_dtype_size(dtype) * (2.0 + (res ? 1.0 : 0.0) + (sum_out ? 1.0 : 0.0));
   CstProfScope prof(CST_K_LAYERNORM, s, 0.0, bytes);
-  dim3 grid(ln_blocks(rows));
-  if (dtype == CST_BF16)
-    hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, dim3(LN_WAVES * 64), 0, s, (const bf16_t*)x, (const bf16_t*)res, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y, (bf16_t*)sum_out, mean, rstd, rows, (int)cols, eps);
-  else if (dtype == CST_F32)
-    hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, dim3(LN_WAVES * 64), 0, s, (const float*)x, (const float*)res, (const float*)gamma, (const float*)beta, (float*)y, (float*)sum_out, mean, rstd, rows, (int)cols, eps);
-  else CST_REQUIRE(false, "cst_layernorm_fwd: bad dtype %d", dtype);
+  dim3 grid(ln_blocks(rows, 2048));  // 8 blocks of 4 waves per CU: the forward kernel needs < 64 VGPRs
+  CST_REQUIRE(dtype == CST_BF16 || dtype == CST_F32, "cst_layernorm_fwd: bad dtype %d", dtype);
+#define CST_LNF(T, NVV) hipLaunchKernelGGL((ln_fwd_kernel<T, NVV>), grid, dim3(LN_WAVES * 64), 0, s, (const T*)x, (const T*)res, (const T*)gamma, (const T*)beta, (T*)y, (T*)sum_out, mean, rstd, rows, (int)cols, eps)
+#define CST_LNF_NV(T) do { const int nv = ln_nv(cols); if (nv == 1) CST_LNF(T, 1); else if (nv == 2) CST_LNF(T, 2); else CST_LNF(T, 4); } while (0)
+  if (dtype == CST_BF16) CST_LNF_NV(bf16_t);
+  else CST_LNF_NV(float);
+#undef CST_LNF_NV
+#undef CST_LNF
   return cst_check_launch("cst_layernorm_fwd");
 }
 
+constexpr int LN_BWD_BLOCKS = 1024;  // 4 blocks of 4 waves per CU at <= 128 VGPRs (NV <= 2)
 extern "C" int64_t cst_layernorm_bwd_workspace(int64_t rows, int64_t cols) {
-  return (int64_t)ln_blocks(rows) * 2 * cols * (int64_t)sizeof(float);
+  return (int64_t)ln_blocks(rows, LN_BWD_BLOCKS) * 2 * cols * (int64_t)sizeof(float);
 }
 
 static int layernorm_bwd_impl(const void* dy, const void* sx, const void* gamma, const float* mean, const float* rstd,
@@ -206,12 +238,14 @@ static int layernorm_bwd_impl(const void* dy, const void* sx, const void* gamma,
   hipStream_t s = (hipStream_t)stream;
   const double bytes = (double)rows * cols * cst_dtype_size(dtype) * (3.0 + (dres ? 1.0 : 0.0));
   CstProfScope prof(CST_K_LAYERNORM, s, 0.0, bytes);
-  const int nb = ln_blocks(rows);
-  if (dtype == CST_BF16)
-    hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(nb), dim3(LN_WAVES * 64), 0, s, (const bf16_t*)dy, (const bf16_t*)sx, (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, (float*)workspace, rows, (int)cols, tile_live, epoch);
-  else if (dtype == CST_F32)
-    hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(LN_WAVES * 64), 0, s, (const float*)dy, (const float*)sx, (const float*)gamma, mean, rstd, (const float*)dres, (float*)dx, (float*)workspace, rows, (int)cols, tile_live, epoch);
-  else CST_REQUIRE(false, "cst_layernorm_bwd: bad dtype %d", dtype);
+  const int nb = ln_blocks(rows, LN_BWD_BLOCKS);
+  CST_REQUIRE(dtype == CST_BF16 || dtype == CST_F32, "cst_layernorm_bwd: bad dtype %d", dtype);
+#define CST_LNB(T, NVV) hipLaunchKernelGGL((ln_bwd_kernel<T, NVV>), dim3(nb), dim3(LN_WAVES * 64), 0, s, (const T*)dy, (const T*)sx, (const T*)gamma, mean, rstd, (const T*)dres, (T*)dx, (float*)workspace, rows, (int)cols, tile_live, epoch)
+#define CST_LNB_NV(T) do { const int nv = ln_nv(cols); if (nv == 1) CST_LNB(T, 1); else if (nv == 2) CST_LNB(T, 2); else CST_LNB(T, 4); } while (0)
+  if (dtype == CST_BF16) CST_LNB_NV(bf16_t);
+  else CST_LNB_NV(float);
+#undef CST_LNB_NV
+#undef CST_LNB
   int rc = cst_check_launch("cst_layernorm_bwd");
   if (rc != CST_OK) return rc;
   CST_REQUIRE(grad_dtype == CST_F32 || grad_dtype == dtype, "cst_layernorm_bwd: grad_dtype must be f32 or dtype");
