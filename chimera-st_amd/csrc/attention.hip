@@ -39,12 +39,34 @@ struct AttnParams {
   uint32_t drop_thr, drop_key; float drop_scale;  // attention-probability dropout (drop_thr == 0: none)
   const int32_t* kv_len;  // optional [B]: keys >= kv_len[b] are all padding -> their tiles are skipped (they contribute exact zeros)
   uint8_t* q_flags;       // optional [B][H][ceil(Tq/64)] (backward): 1 = the 64-query tile has a non-zero dO row
+  // PACKED (variable-length) self-attention: seq_off != nullptr -> Q/K/V/O and all gradients are [rows, H*D] with the rows of sequence b
+  // at [seq_off[b], seq_off[b+1]); its keys are the first kv_len[b] rows (the rest of the segment are query-only rows: padding frames
+  // kept for their outputs).  Tq / Tk then hold the LONGEST segment: grid size and the strides of lse / delta / q_flags / the dropout
+  // index space — so a packed call regenerates exactly the masks of the padded call it replaces.
+  const int32_t* seq_off;
 };
 
+// per-sequence view of the problem: row offset, number of query rows, number of keys
+struct SeqView { int64_t row0; int tq, tk; };
+__device__ __forceinline__ SeqView seq_view(const AttnParams& p, int64_t b) {
+  SeqView v;
+  if (p.seq_off) {
+    v.row0 = p.seq_off[b];
+    v.tq = p.seq_off[b + 1] - p.seq_off[b];
+    v.tk = p.kv_len ? (p.kv_len[b] < v.tq ? p.kv_len[b] : v.tq) : v.tq;
+    if (v.tk < 0) v.tk = 0;
+  } else {
+    v.row0 = 0;
+    v.tq = (int)p.Tq;
+    v.tk = (int)p.Tk;
+  }
+  return v;
+}
+
 // last query (exclusive, multiple of 64) whose tile carries a non-zero upstream gradient; wave 0 scans the flags
-__device__ __forceinline__ int live_query_end(const AttnParams& p, int64_t b, int64_t h, int* sh, int tid) {
+__device__ __forceinline__ int live_query_end(const AttnParams& p, int64_t b, int64_t h, int* sh, int tid, int tq) {
   const int nqt = (int)((p.Tq + 63) / 64);
-  if (!p.q_flags) return (int)p.Tq;
+  if (!p.q_flags) return tq;
   if (tid < 64) {
     const uint8_t* f = p.q_flags + (b * p.H + h) * nqt;
     int last = -1;
@@ -57,7 +79,7 @@ __device__ __forceinline__ int live_query_end(const AttnParams& p, int64_t b, in
   }
   __syncthreads();
   const int e = *sh;
-  return e < (int)p.Tq ? e : (int)p.Tq;
+  return e < tq ? e : tq;
 }
 
 // the row (within a 32-row MFMA tile) that k-slot j of half-wave `hi` holds for the 16-row step t
@@ -128,10 +150,12 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_fwd_ke
   const int64_t b = blockIdx.z, h = blockIdx.y;
   const int q_blk0 = blockIdx.x * (NW * QB);
   const int q = q_blk0 + wave * QB + (lane & 31);
-  const T* Qg = (const T*)p.Q + b * p.q_sb + h * p.q_sh;
-  const T* Kg = (const T*)p.K + b * p.k_sb + h * p.k_sh;
-  const T* Vg = (const T*)p.V + b * p.v_sb + h * p.v_sh;
-  const int cshift = (int)(p.Tk - p.Tq);  // causal: key j visible to query i iff j <= i + cshift
+  const SeqView sv = seq_view(p, b);
+  if (q_blk0 >= sv.tq) return;  // packed: this sequence is shorter than the longest one (workgroup-uniform)
+  const T* Qg = (const T*)p.Q + (p.seq_off ? sv.row0 * p.q_st : b * p.q_sb) + h * p.q_sh;
+  const T* Kg = (const T*)p.K + (p.seq_off ? sv.row0 * p.k_st : b * p.k_sb) + h * p.k_sh;
+  const T* Vg = (const T*)p.V + (p.seq_off ? sv.row0 * p.v_st : b * p.v_sb) + h * p.v_sh;
+  const int cshift = sv.tk - sv.tq;  // causal: key j visible to query i iff j <= i + cshift
   const float c2 = p.scale * 1.4426950408889634f;  // softmax in the exp2 domain: p = 2^(s*c2 - m)
   // attention dropout (modules/multihead_attention.py:359): element (b,h,q,k) of the probability tensor has index
   // ((b*H + h)*Tq + q) * Tkp + k with Tkp = Tk rounded up to even, so one mask word serves keys (2j, 2j+1) of a query
@@ -140,7 +164,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_fwd_ke
   const uint32_t rowpair = (uint32_t)((b * p.H + h) * p.Tq + q) * hp;
 
   Frag<T> fq[D / 16];
-  load_row_frags<T, D>(fq, Qg, p.q_st, q, (int)p.Tq, lane);
+  load_row_frags<T, D>(fq, Qg, p.q_st, q, sv.tq, lane);
 
   f32x16 o[D / 32];
 #pragma unroll
@@ -149,8 +173,8 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_fwd_ke
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.0f;
   float m_run = -1.0e30f, l_run = 0.0f;
 
-  int64_t kend = p.Tk;
-  if (p.kv_len && p.kv_len[b] < kend) kend = p.kv_len[b] > 0 ? p.kv_len[b] : 0;  // trailing padding: P = exp2(-inf) = 0, alpha = 1 — skipping is exact
+  int64_t kend = sv.tk;
+  if (!p.seq_off && p.kv_len && p.kv_len[b] < kend) kend = p.kv_len[b] > 0 ? p.kv_len[b] : 0;  // trailing padding: P = exp2(-inf) = 0, alpha = 1 — skipping is exact
   if (p.causal) {
     const int64_t last = (int64_t)q_blk0 + NW * QB - 1 + cshift + 1;
     if (last < kend) kend = last;
@@ -158,7 +182,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_fwd_ke
   TileRegs<T, D> rk, rv;
   uint8_t rmask = 0;
   auto prefetch = [&](int64_t j0) {
-    const int nk = (int)((p.Tk - j0 < KT) ? (p.Tk - j0) : KT);
+    const int nk = (int)((sv.tk - j0 < KT) ? (sv.tk - j0) : KT);
     rk.fetch(Kg + j0 * p.k_st, p.k_st, nk, tid);
     rv.fetch(Vg + j0 * p.v_st, p.v_st, nk, tid);
     if (tid < KT) rmask = (tid >= nk) ? 1 : (p.kpm ? p.kpm[b * p.kpm_stride + j0 + tid] : 0);
@@ -240,7 +264,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_fwd_ke
           for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-              const uint32_t bits = cst_drop_bits32(p.drop_key, dkey2, base + ks * 16 + 4 * g + t);
+              const uint32_t bits = cst_drop_bits24(p.drop_key, dkey2, base + ks * 16 + 4 * g + t);
               s[ks][4 * g + 2 * t] = (bits & 0xffffU) >= p.drop_thr ? s[ks][4 * g + 2 * t] : 0.0f;
               s[ks][4 * g + 2 * t + 1] = (bits >> 16) >= p.drop_thr ? s[ks][4 * g + 2 * t + 1] : 0.0f;
             }
@@ -272,9 +296,9 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_fwd_ke
     cur ^= 1;
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  if (q < p.Tq) {
+  if (q < sv.tq) {
     const float inv = l_tot > 0.0f ? p.drop_scale / l_tot : 0.0f;
-    T* Og = (T*)p.O + b * p.o_sb + h * p.o_sh + (int64_t)q * p.o_st;
+    T* Og = (T*)p.O + (p.seq_off ? sv.row0 * p.o_st : b * p.o_sb) + h * p.o_sh + (int64_t)q * p.o_st;
 #pragma unroll
     for (int dt = 0; dt < D / 32; ++dt) store_dcol<T>(Og, o[dt], dt * 32, lane, inv);
     if (hi == 0) p.lse[(b * p.H + h) * p.Tq + q] = l_tot > 0.0f ? m_run * 0.6931471805599453f + __logf(l_tot) : -INFINITY;
@@ -291,9 +315,10 @@ __global__ __launch_bounds__(64) void attn_delta_kernel(AttnParams p) {
   const int qt = blockIdx.x, lane = threadIdx.x;
   const int64_t q = (int64_t)qt * 64 + lane;
   bool nz = false;
-  if (q < p.Tq) {
-    const T* o = (const T*)p.O + b * p.o_sb + h * p.o_sh + q * p.o_st;
-    const T* g = (const T*)p.dO + b * p.do_sb + h * p.do_sh + q * p.do_st;
+  const SeqView sv = seq_view(p, b);
+  if (q < sv.tq) {
+    const T* o = (const T*)p.O + (p.seq_off ? sv.row0 * p.o_st : b * p.o_sb) + h * p.o_sh + q * p.o_st;
+    const T* g = (const T*)p.dO + (p.seq_off ? sv.row0 * p.do_st : b * p.do_sb) + h * p.do_sh + q * p.do_st;
     float acc = 0.0f;
 #pragma unroll
     for (int d = 0; d < D; d += 8) {
@@ -321,11 +346,14 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_bwd_dq
   const int64_t b = blockIdx.z, h = blockIdx.y;
   const int q_blk0 = blockIdx.x * (NW * QB);
   const int q = q_blk0 + wave * QB + (lane & 31);
-  const T* Qg = (const T*)p.Q + b * p.q_sb + h * p.q_sh;
-  const T* Kg = (const T*)p.K + b * p.k_sb + h * p.k_sh;
-  const T* Vg = (const T*)p.V + b * p.v_sb + h * p.v_sh;
-  const T* dOg = (const T*)p.dO + b * p.do_sb + h * p.do_sh;
-  const int cshift = (int)(p.Tk - p.Tq);
+  const SeqView sv = seq_view(p, b);
+  if (q_blk0 >= sv.tq) return;  // packed: beyond this sequence (workgroup-uniform, before any barrier)
+  const T* Qg = (const T*)p.Q + (p.seq_off ? sv.row0 * p.q_st : b * p.q_sb) + h * p.q_sh;
+  const T* Kg = (const T*)p.K + (p.seq_off ? sv.row0 * p.k_st : b * p.k_sb) + h * p.k_sh;
+  const T* Vg = (const T*)p.V + (p.seq_off ? sv.row0 * p.v_st : b * p.v_sb) + h * p.v_sh;
+  const T* dOg = (const T*)p.dO + (p.seq_off ? sv.row0 * p.do_st : b * p.do_sb) + h * p.do_sh;
+  T* const dQb = (T*)p.dQ + (p.seq_off ? sv.row0 * p.dq_st : b * p.dq_sb) + h * p.dq_sh;
+  const int cshift = sv.tk - sv.tq;
   const float c2 = p.scale * 1.4426950408889634f;
   const uint32_t dkey2 = cst_drop_key2(p.drop_key);
   const uint32_t hp = (uint32_t)((p.Tk + 1) >> 1);
@@ -333,10 +361,10 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_bwd_dq
 
   {
     int* sh_qend = reinterpret_cast<int*>(sMask + 2);
-    const int qend = live_query_end(p, b, h, sh_qend, tid);
+    const int qend = live_query_end(p, b, h, sh_qend, tid, sv.tq);
     if (q_blk0 >= qend) {  // every query of this workgroup has a zero upstream gradient: dQ = 0 (workgroup-uniform exit)
-      if (q < p.Tq) {
-        T* g = (T*)p.dQ + b * p.dq_sb + h * p.dq_sh + (int64_t)q * p.dq_st;
+      if (q < sv.tq) {
+        T* g = dQb + (int64_t)q * p.dq_st;
         f32x16 z;
 #pragma unroll
         for (int r = 0; r < 16; ++r) z[r] = 0.0f;
@@ -347,11 +375,11 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_bwd_dq
     }
   }
   Frag<T> fq[D / 16], fdo[D / 16];
-  load_row_frags<T, D>(fq, Qg, p.q_st, q, (int)p.Tq, lane);
-  load_row_frags<T, D>(fdo, dOg, p.do_st, q, (int)p.Tq, lane);
+  load_row_frags<T, D>(fq, Qg, p.q_st, q, sv.tq, lane);
+  load_row_frags<T, D>(fdo, dOg, p.do_st, q, sv.tq, lane);
   // log2 domain.  Rows beyond Tq and fully masked rows (lse = -inf) get +inf: exp2(s - inf) = 0 without a per-element select
   float lse = INFINITY, dlt = 0.0f;
-  if (q < p.Tq) {
+  if (q < sv.tq) {
     const float l = p.lse[(b * p.H + h) * p.Tq + q];
     lse = l == -INFINITY ? INFINITY : l * 1.4426950408889634f;
     dlt = p.delta[(b * p.H + h) * p.Tq + q];
@@ -362,8 +390,8 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_bwd_dq
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[dt][r] = 0.0f;
 
-  int64_t kend = p.Tk;
-  if (p.kv_len && p.kv_len[b] < kend) kend = p.kv_len[b] > 0 ? p.kv_len[b] : 0;
+  int64_t kend = sv.tk;
+  if (!p.seq_off && p.kv_len && p.kv_len[b] < kend) kend = p.kv_len[b] > 0 ? p.kv_len[b] : 0;
   if (p.causal) {
     const int64_t last = (int64_t)q_blk0 + NW * QB + cshift;
     if (last < kend) kend = last;
@@ -371,7 +399,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_bwd_dq
   TileRegs<T, D> rk, rv;
   uint8_t rmask = 0;
   auto prefetch = [&](int64_t j0) {
-    const int nk = (int)((p.Tk - j0 < KT) ? (p.Tk - j0) : KT);
+    const int nk = (int)((sv.tk - j0 < KT) ? (sv.tk - j0) : KT);
     rk.fetch(Kg + j0 * p.k_st, p.k_st, nk, tid);
     rv.fetch(Vg + j0 * p.v_st, p.v_st, nk, tid);
     if (tid < KT) rmask = (tid >= nk) ? 1 : (p.kpm ? p.kpm[b * p.kpm_stride + j0 + tid] : 0);
@@ -415,7 +443,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_bwd_dq
         for (int g = 0; g < 4; ++g)
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
-            const uint32_t bits = cst_drop_bits32(p.drop_key, dkey2, base + 4 * g + t);
+            const uint32_t bits = cst_drop_bits24(p.drop_key, dkey2, base + 4 * g + t);
             dp[4 * g + 2 * t] = (bits & 0xffffU) >= p.drop_thr ? dp[4 * g + 2 * t] * p.drop_scale : 0.0f;
             dp[4 * g + 2 * t + 1] = (bits >> 16) >= p.drop_thr ? dp[4 * g + 2 * t + 1] * p.drop_scale : 0.0f;
           }
@@ -448,8 +476,8 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_bwd_dq
     __syncthreads();
     cur ^= 1;
   }
-  if (q < p.Tq) {
-    T* g = (T*)p.dQ + b * p.dq_sb + h * p.dq_sh + (int64_t)q * p.dq_st;
+  if (q < sv.tq) {
+    T* g = dQb + (int64_t)q * p.dq_st;
 #pragma unroll
     for (int dt = 0; dt < D / 32; ++dt) store_dcol<T>(g, dq[dt], dt * 32, lane, p.scale);
   }
@@ -466,11 +494,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnParams p) 
   const int64_t b = blockIdx.z, h = blockIdx.y;
   const int k_blk0 = blockIdx.x * (NW * QB);
   const int key = k_blk0 + wave * QB + (lane & 31);
-  const T* Qg = (const T*)p.Q + b * p.q_sb + h * p.q_sh;
-  const T* Kg = (const T*)p.K + b * p.k_sb + h * p.k_sh;
-  const T* Vg = (const T*)p.V + b * p.v_sb + h * p.v_sh;
-  const T* dOg = (const T*)p.dO + b * p.do_sb + h * p.do_sh;
-  const int cshift = (int)(p.Tk - p.Tq);
+  const SeqView sv = seq_view(p, b);
+  const int krows = p.seq_off ? sv.tq : sv.tk;  // rows of dK / dV this sequence owns (packed: the query-only rows get zeros)
+  if (k_blk0 >= krows) return;  // packed: beyond this sequence (workgroup-uniform, before any barrier)
+  const T* Qg = (const T*)p.Q + (p.seq_off ? sv.row0 * p.q_st : b * p.q_sb) + h * p.q_sh;
+  const T* Kg = (const T*)p.K + (p.seq_off ? sv.row0 * p.k_st : b * p.k_sb) + h * p.k_sh;
+  const T* Vg = (const T*)p.V + (p.seq_off ? sv.row0 * p.v_st : b * p.v_sb) + h * p.v_sh;
+  const T* dOg = (const T*)p.dO + (p.seq_off ? sv.row0 * p.do_st : b * p.do_sb) + h * p.do_sh;
+  T* const dKb = (T*)p.dK + (p.seq_off ? sv.row0 * p.dk_st : b * p.dk_sb) + h * p.dk_sh;
+  T* const dVb = (T*)p.dV + (p.seq_off ? sv.row0 * p.dv_st : b * p.dv_sb) + h * p.dv_sh;
+  const int cshift = sv.tk - sv.tq;
   const float c2 = p.scale * 1.4426950408889634f;
   // here a lane owns one key and its registers run over queries, so every element needs its own mask word (the word of the
   // key pair (key & ~1, key | 1) in that query's row); this lane's half of the word is `dsh`
@@ -480,9 +513,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnParams p) 
   const uint32_t rowpair0 = (uint32_t)((b * p.H + h) * p.Tq) * hp + (uint32_t)(key >> 1) + (uint32_t)(4 * hi) * hp;
 
   if (p.kv_len && k_blk0 >= p.kv_len[b]) {  // every key of this block is padding: dK = dV = 0 (workgroup-uniform exit)
-    if (key < p.Tk) {
-      T* gk = (T*)p.dK + b * p.dk_sb + h * p.dk_sh + (int64_t)key * p.dk_st;
-      T* gv = (T*)p.dV + b * p.dv_sb + h * p.dv_sh + (int64_t)key * p.dv_st;
+    if (key < krows) {
+      T* gk = dKb + (int64_t)key * p.dk_st;
+      T* gv = dVb + (int64_t)key * p.dv_st;
       f32x16 z;
 #pragma unroll
       for (int r = 0; r < 16; ++r) z[r] = 0.0f;
@@ -495,9 +528,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnParams p) 
     return;
   }
   Frag<T> fk[D / 16], fv[D / 16];
-  load_row_frags<T, D>(fk, Kg, p.k_st, key, (int)p.Tk, lane);
-  load_row_frags<T, D>(fv, Vg, p.v_st, key, (int)p.Tk, lane);
-  const bool key_masked = key >= p.Tk || (p.kpm && p.kpm[b * p.kpm_stride + key]);
+  load_row_frags<T, D>(fk, Kg, p.k_st, key, sv.tk, lane);
+  load_row_frags<T, D>(fv, Vg, p.v_st, key, sv.tk, lane);
+  const bool key_masked = key >= sv.tk || (p.kpm && p.kpm[b * p.kpm_stride + key]);
 
   f32x16 dk[D / 32], dv[D / 32];
 #pragma unroll
@@ -514,7 +547,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnParams p) 
   TileRegs<T, D> rq, rdo;
   float rl = -INFINITY, rd = 0.0f;
   auto prefetch = [&](int64_t i0) {
-    const int nq = (int)((p.Tq - i0 < KT) ? (p.Tq - i0) : KT);
+    const int nq = (int)((sv.tq - i0 < KT) ? (sv.tq - i0) : KT);
     rq.fetch(Qg + i0 * p.q_st, p.q_st, nq, tid);
     rdo.fetch(dOg + i0 * p.do_st, p.do_st, nq, tid);
     if (tid < KT) {
@@ -529,7 +562,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnParams p) 
     rdo.stage(smem + st * 2 * TILE + TILE, tid);
     if (tid < KT) { sStat[st * 2 * KT + tid] = rl; sStat[st * 2 * KT + KT + tid] = rd; }
   };
-  const int64_t qlim = live_query_end(p, b, h, reinterpret_cast<int*>(sStat + 4 * KT), tid);  // queries beyond it have dO = 0
+  const int64_t qlim = live_query_end(p, b, h, reinterpret_cast<int*>(sStat + 4 * KT), tid, sv.tq);  // queries beyond it have dO = 0
   if (qstart < qlim) { prefetch(qstart); stage(0); }
   __syncthreads();
   int cur = 0;
@@ -564,7 +597,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnParams p) 
         for (int j = 0; j < 8; ++j) {
           const int r0 = 2 * j;  // query rows of registers r0 and r0 + 1 differ by one
           const uint32_t qrow = (uint32_t)((int)i0 + qs * 32 + (r0 & 3) + 8 * (r0 >> 2)) + odd;
-          const uint32_t mine = cst_drop_bits32(p.drop_key, dkey2, rowpair0 + qrow * hp);
+          const uint32_t mine = cst_drop_bits24(p.drop_key, dkey2, rowpair0 + qrow * hp);
           const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
           const uint32_t w0 = odd ? other : mine, w1 = odd ? mine : other;
           keepbits |= (((w0 >> dsh) & 0xffffU) >= p.drop_thr ? 1u : 0u) << r0;
@@ -616,9 +649,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnParams p) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.0f; dv[dt][r] = 0.0f; }
   }
-  if (key < p.Tk) {
-    T* gk = (T*)p.dK + b * p.dk_sb + h * p.dk_sh + (int64_t)key * p.dk_st;
-    T* gv = (T*)p.dV + b * p.dv_sb + h * p.dv_sh + (int64_t)key * p.dv_st;
+  if (key < krows) {
+    T* gk = dKb + (int64_t)key * p.dk_st;
+    T* gv = dVb + (int64_t)key * p.dv_st;
 #pragma unroll
     for (int dt = 0; dt < D / 32; ++dt) {
       store_dcol<T>(gk, dk[dt], dt * 32, lane, p.scale);
@@ -658,6 +691,11 @@ int fill_params(const cst_attn_desc* d, AttnParams& p, bool bwd) {
   p.dv_sb = d->dv_sb; p.dv_sh = d->dv_sh; p.dv_st = d->dv_st;
   p.delta = d->delta;
   p.kv_len = d->kv_len;
+  p.seq_off = d->seq_offsets;
+  if (p.seq_off) {
+    CST_REQUIRE(d->Tq == d->Tk && d->key_padding_mask == nullptr, "cst_attn: packed sequences are self-attention (Tq == Tk = longest segment) without a key padding mask (kv_len gives the keys per sequence)");
+    CST_REQUIRE(d->q_st == d->k_st && d->q_st == d->v_st, "cst_attn: packed Q/K/V must share one row stride");
+  }
   p.q_flags = bwd ? d->q_flags : nullptr;
   if (bwd) {
     CST_REQUIRE(d->dO && d->dQ && d->dK && d->dV && d->delta, "cst_attn_bwd: null gradient tensor");

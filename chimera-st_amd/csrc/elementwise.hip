@@ -191,6 +191,64 @@ __global__ void dropout_kernel(const T* x, T* y, int64_t n, uint32_t key, uint32
     for (int64_t i = n8 * 8 + threadIdx.x; i < n; i += blockDim.x) DT<T>::st(y + i, DT<T>::ld(x + i) * cst_drop1(key, (uint64_t)i, thr16, scale));
 }
 
+// ---- packed rows: [B, T, C] <-> [N, C] with sequence b at rows [off[b], off[b+1]) --------------------------------------
+// pack:   dst[off[b] + t] = src[b, t] for t < n_b - 1;  the LAST packed row of a sequence takes src[b, n_b - 1] (tail == 0) or the
+//         sum of src[b, n_b - 1 .. T - 1] (tail == 1: the gradient of `unpack` with broadcast), added in a fixed order.
+// unpack: dst[b, t] = src[off[b] + min(t, n_b - 1)] (tail == 1: rows beyond the sequence repeat its last row) or 0 beyond (tail == 0).
+// One wave per row, 16-byte vectors; grid (ceil(T / 4), B).
+template <typename T>
+__device__ __forceinline__ void copy8(T* d, const T* s) {  // 8 elements: one 16-byte vector (bf16) or two (fp32)
+  constexpr int NV = (int)(8 * sizeof(T) / 16);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) reinterpret_cast<u32x4*>(d)[i] = reinterpret_cast<const u32x4*>(s)[i];
+}
+template <typename T>
+__device__ __forceinline__ void zero8(T* d) {
+  constexpr int NV = (int)(8 * sizeof(T) / 16);
+  const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int i = 0; i < NV; ++i) reinterpret_cast<u32x4*>(d)[i] = z;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rows_pack_kernel(const T* src, const int32_t* off, T* dst, int Tn, int C, int tail) {
+  const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + wave;
+  const int n = off[b + 1] - off[b];
+  if (t >= n) return;
+  const T* s = src + ((int64_t)b * Tn + t) * C;
+  T* d = dst + ((int64_t)off[b] + t) * C;
+  if (t < n - 1 || !tail) {
+    for (int c = lane * 8; c < C; c += 512) copy8(d + c, s + c);
+    return;
+  }
+  for (int c = lane * 8; c < C; c += 512) {  // last row: rows n-1 .. Tn-1 in index order, fp32 accumulation, one rounding
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = t; r < Tn; ++r) {
+      float v[8];
+      load8(src + ((int64_t)b * Tn + r) * C + c, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += v[e];
+    }
+    store8(d + c, a);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rows_unpack_kernel(const T* src, const int32_t* off, T* dst, int Tn, int C, int tail) {
+  const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + wave;
+  if (t >= Tn) return;
+  const int n = off[b + 1] - off[b];
+  T* d = dst + ((int64_t)b * Tn + t) * C;
+  if (t >= n && !tail) {
+    for (int c = lane * 8; c < C; c += 512) zero8(d + c);
+    return;
+  }
+  const T* s = src + ((int64_t)off[b] + (t < n ? t : n - 1)) * C;
+  for (int c = lane * 8; c < C; c += 512) copy8(d + c, s + c);
+}
+
 }  // namespace
 
 #define CST_EW_DISPATCH(kern, grid, block, s, dtype, ...)                                        \
@@ -337,4 +395,31 @@ extern "C" int cst_dropout(const void* x, void* y, int64_t n, float p, uint32_t 
   if (dtype == CST_BF16) hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, n, key, thr, scale);
   else hipLaunchKernelGGL(dropout_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, (float*)y, n, key, thr, scale);
   return cst_check_launch("cst_dropout");
+}
+
+
+extern "C" int cst_rows_pack(const void* src, const int32_t* seq_off, void* dst, int64_t B, int64_t T, int64_t C, int tail_sum, int dtype,
+                             cst_stream stream) {
+  CST_REQUIRE(src && seq_off && dst && B > 0 && T > 0 && C > 0, "cst_rows_pack: bad args");
+  CST_REQUIRE(dtype == CST_F32 || dtype == CST_BF16, "cst_rows_pack: bad dtype %d", dtype);
+  CST_REQUIRE(C % 8 == 0 && B < 65536, "cst_rows_pack: C=%lld must be a multiple of 8", (long long)C);
+  hipStream_t s = (hipStream_t)stream;
+  CstProfScope prof(CST_K_ELEMENTWISE, s, 0.0, 2.0 * B * T * C * cst_dtype_size(dtype));
+  const dim3 grid((unsigned)cst_ceil_div(T, 4), (unsigned)B);
+  if (dtype == CST_BF16) hipLaunchKernelGGL(rows_pack_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)src, seq_off, (bf16_t*)dst, (int)T, (int)C, tail_sum);
+  else hipLaunchKernelGGL(rows_pack_kernel<float>, grid, dim3(256), 0, s, (const float*)src, seq_off, (float*)dst, (int)T, (int)C, tail_sum);
+  return cst_check_launch("cst_rows_pack");
+}
+
+extern "C" int cst_rows_unpack(const void* src, const int32_t* seq_off, void* dst, int64_t B, int64_t T, int64_t C, int tail_broadcast, int dtype,
+                               cst_stream stream) {
+  CST_REQUIRE(src && seq_off && dst && B > 0 && T > 0 && C > 0, "cst_rows_unpack: bad args");
+  CST_REQUIRE(dtype == CST_F32 || dtype == CST_BF16, "cst_rows_unpack: bad dtype %d", dtype);
+  CST_REQUIRE(C % 8 == 0 && B < 65536, "cst_rows_unpack: C=%lld must be a multiple of 8", (long long)C);
+  hipStream_t s = (hipStream_t)stream;
+  CstProfScope prof(CST_K_ELEMENTWISE, s, 0.0, 2.0 * B * T * C * cst_dtype_size(dtype));
+  const dim3 grid((unsigned)cst_ceil_div(T, 4), (unsigned)B);
+  if (dtype == CST_BF16) hipLaunchKernelGGL(rows_unpack_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)src, seq_off, (bf16_t*)dst, (int)T, (int)C, tail_broadcast);
+  else hipLaunchKernelGGL(rows_unpack_kernel<float>, grid, dim3(256), 0, s, (const float*)src, seq_off, (float*)dst, (int)T, (int)C, tail_broadcast);
+  return cst_check_launch("cst_rows_unpack");
 }

@@ -373,24 +373,26 @@ class _AttnPackedFn(torch.autograd.Function):
     into ONE [B, T, 3C] buffer, so the projection's dX / dW are single GEMMs and x receives a single gradient."""
 
     @staticmethod
-    def forward(ctx, qkv, kpm, kvl, H, causal, scale, drop_p, drop_key, pad_tiles=None):
+    def forward(ctx, qkv, kpm, kvl, H, causal, scale, drop_p, drop_key, pad_tiles=None, seq=None):
         ctx.pad_tiles = pad_tiles
         C = qkv.shape[-1] // 3
         D = C // H
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
         B, T = qkv.shape[0], qkv.shape[1]
         o = torch.empty(B, T, C, dtype=qkv.dtype, device=qkv.device)
-        lse = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
-        d = K.attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, "bt", "bt", drop_p, drop_key, kvl)
+        # packed sequences: lse / delta are [sequences, H, longest sequence]
+        lse = torch.empty((seq[0].numel() - 1) if seq is not None else B, H, int(seq[1]) if seq is not None else T, dtype=torch.float32, device=qkv.device)
+        d = K.attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, "bt", "bt", drop_p, drop_key, kvl, seq)
         K.attn_fwd_desc(d)
-        ctx.save_for_backward(qkv, o, lse, kpm, kvl)
-        ctx.cfg = (H, D, C, causal, scale, drop_p, drop_key)
+        ctx.save_for_backward(qkv, o, lse, kpm, kvl, seq[0] if seq is not None else None)
+        ctx.cfg = (H, D, C, causal, scale, drop_p, drop_key, int(seq[1]) if seq is not None else None)
         return o
 
     @staticmethod
     def backward(ctx, do):
-        qkv, o, lse, kpm, kvl = ctx.saved_tensors
-        H, D, C, causal, scale, drop_p, drop_key = ctx.cfg
+        qkv, o, lse, kpm, kvl, seq_off = ctx.saved_tensors
+        H, D, C, causal, scale, drop_p, drop_key, seq_max = ctx.cfg
+        seq = (seq_off, seq_max) if seq_off is not None else None
         live = _tiles_of(do, qkv.shape[0] * qkv.shape[1]) if ctx.pad_tiles is not None else None
         if not do.is_contiguous():
             do = do.contiguous()
@@ -398,7 +400,7 @@ class _AttnPackedFn(torch.autograd.Function):
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
         dq, dk, dv = dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:]
         delta = torch.empty_like(lse)
-        d = K.attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, "bt", "bt", drop_p, drop_key, kvl)
+        d = K.attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, "bt", "bt", drop_p, drop_key, kvl, seq)
         K.attn_bwd_fill(d, do, dq, dk, dv, delta, D, "bt", "bt")
         K.attn_bwd_desc(d)
         if live is not None:
@@ -406,18 +408,86 @@ class _AttnPackedFn(torch.autograd.Function):
             # that is dead in dO and all padding is dead here; every other tile is declared live
             stamps = torch.where(ctx.pad_tiles, live[0], torch.full_like(live[0], live[1] if live[1] < 2 ** 31 else live[1] - 2 ** 32))
             dqkv = _with_tiles(dqkv, (stamps, live[1]))
-        return dqkv, None, None, None, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None, None, None, None
 
 
-def attention_packed(qkv, num_heads, key_padding_mask=None, causal=False, scale=None, dropout_p=0.0):
-    """qkv [B, T, 3C] contiguous -> [B, T, C]."""
+def attention_packed(qkv, num_heads, key_padding_mask=None, causal=False, scale=None, dropout_p=0.0, seq=None):
+    """qkv [B, T, 3C] contiguous -> [B, T, C].
+    seq = PackedRows (see pack_rows): qkv is [1, rows, 3C] holding variable-length sequences back to back; sequence b attends to its
+    first seq.kv_len[b] rows (its real frames); key_padding_mask must be None."""
     C = qkv.shape[-1] // 3
     if scale is None:
         scale = (C // num_heads) ** -0.5
-    key_padding_mask, kv_len = _mask_and_len(key_padding_mask)
     assert qkv.is_contiguous()
+    if seq is not None:
+        assert key_padding_mask is None and qkv.shape[0] == 1 and qkv.shape[1] == seq.rows
+        return _AttnPackedFn.apply(qkv, None, seq.kv_len, num_heads, bool(causal), float(scale), *_drop_args(dropout_p), None, (seq.offsets, seq.longest))
+    key_padding_mask, kv_len = _mask_and_len(key_padding_mask)
     pad_tiles = _pad_tiles(key_padding_mask) if (key_padding_mask is not None and qkv.requires_grad) else None
     return _AttnPackedFn.apply(qkv, key_padding_mask, kv_len, num_heads, bool(causal), float(scale), *_drop_args(dropout_p), pad_tiles)
+
+
+# ------------------------------------------------------------------------------------------------
+# packed (padding-free) row sets — include/cst.h: cst_rows_pack / cst_rows_unpack
+# ------------------------------------------------------------------------------------------------
+class PackedRows:
+    """Where the sequences of a packed [rows, C] tensor live: offsets int32 [B+1] (device), kv_len int32 [B] (device: real frames per
+    sequence = its keys), rows (total), longest (longest sequence), B, T (the padded shape it came from)."""
+
+    def __init__(self, offsets, kv_len, rows, longest, B, T):
+        self.offsets, self.kv_len, self.rows, self.longest, self.B, self.T = offsets, kv_len, rows, longest, B, T
+
+
+def plan_packed_rows(padding_mask, margin):
+    """padding_mask bool [B, T] (True = padding, a suffix per row).  Sequence b keeps n_b = min(T, len_b + margin + 1) rows: its real
+    frames, the `margin` padding frames that are still influenced by real ones, and ONE more that stands for every identical
+    padding frame behind it.  One host read of B integers (the plan sizes the packed allocations)."""
+    B, T = padding_mask.shape
+    lens = (~padding_mask).sum(dim=1).to(torch.int32)
+    n = torch.clamp(lens + (margin + 1), max=T)
+    off = torch.zeros(B + 1, dtype=torch.int32, device=padding_mask.device)
+    off[1:] = torch.cumsum(n, 0)
+    host = torch.stack((off[-1], n.max())).tolist()  # the step's packing plan: total rows, longest sequence
+    return PackedRows(off.contiguous(), lens.contiguous(), int(host[0]), int(host[1]), B, T)
+
+
+class _PackRowsFn(torch.autograd.Function):
+    """[B, T, C] -> [1, rows, C]: the rows each sequence keeps; backward = unpack with zeros behind the kept rows."""
+
+    @staticmethod
+    def forward(ctx, x, seq):
+        ctx.seq = seq
+        return K.rows_pack(x if x.is_contiguous() else x.contiguous(), seq.offsets, seq.rows, tail_sum=False).unsqueeze(0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        s = ctx.seq
+        dy2 = dy.reshape(s.rows, dy.shape[-1])
+        return K.rows_unpack(dy2 if dy2.is_contiguous() else dy2.contiguous(), s.offsets, s.B, s.T, tail_broadcast=False), None
+
+
+class _UnpackRowsFn(torch.autograd.Function):
+    """[1, rows, C] -> [B, T, C]: rows behind a sequence's kept ones repeat its last kept row (they are identical padding frames);
+    backward = pack with the gradients of those copies summed into that row, in index order."""
+
+    @staticmethod
+    def forward(ctx, y, seq):
+        ctx.seq = seq
+        y2 = y.reshape(seq.rows, y.shape[-1])
+        return K.rows_unpack(y2 if y2.is_contiguous() else y2.contiguous(), seq.offsets, seq.B, seq.T, tail_broadcast=True)
+
+    @staticmethod
+    def backward(ctx, dx):
+        s = ctx.seq
+        return K.rows_pack(dx if dx.is_contiguous() else dx.contiguous(), s.offsets, s.rows, tail_sum=True).unsqueeze(0), None
+
+
+def pack_rows(x, seq):
+    return _PackRowsFn.apply(x, seq)
+
+
+def unpack_rows(y, seq):
+    return _UnpackRowsFn.apply(y, seq)
 
 
 # ------------------------------------------------------------------------------------------------

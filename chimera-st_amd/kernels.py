@@ -147,8 +147,9 @@ def _bhtd_strides(t, layout):
     return t.stride(1), None, t.stride(0)  # [T, B, C]
 
 
-def attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, layout_q="bt", layout_kv="bt", drop_p=0.0, drop_key=0, kv_len=None):
-    """q,o: [B,Tq,H*D] (layout "bt") or [Tq,B,H*D] ("tb"); k,v likewise with Tk.  Head h at channel offset h*D."""
+def attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, layout_q="bt", layout_kv="bt", drop_p=0.0, drop_key=0, kv_len=None, seq=None):
+    """q,o: [B,Tq,H*D] (layout "bt") or [Tq,B,H*D] ("tb"); k,v likewise with Tk.  Head h at channel offset h*D.
+    seq = (seq_offsets int32 [B+1], longest sequence): packed self-attention, q/k/v/o are [1, rows, H*D] (include/cst.h)."""
     d = L.AttnDesc()
     d.dtype = L.dtype_code(q.dtype)
     if layout_q == "bt":
@@ -156,6 +157,14 @@ def attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, layout_q="bt", layout_k
     else:
         Tq, B = q.shape[0], q.shape[1]
     Tk = k.shape[1] if layout_kv == "bt" else k.shape[0]
+    if seq is not None:
+        assert layout_q == "bt" and layout_kv == "bt" and B == 1 and kpm is None
+        assert seq[0].dtype == torch.int32 and seq[0].is_contiguous()
+        B, Tq, Tk = seq[0].numel() - 1, int(seq[1]), int(seq[1])
+        d.seq_offsets = seq[0].data_ptr()
+        STATS["attn_packed"] = STATS.get("attn_packed", 0) + 1
+    else:
+        d.seq_offsets = None
     d.B, d.H, d.Tq, d.Tk, d.D = B, H, Tq, Tk, D
 
     def st(t, lay):
@@ -175,7 +184,7 @@ def attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, layout_q="bt", layout_k
     d.causal, d.scale = int(causal), scale
     d.drop_p, d.drop_key = float(drop_p), int(drop_key) & 0xFFFFFFFF
     if kv_len is not None:
-        assert kpm is not None and kv_len.dtype == torch.int32 and kv_len.numel() == B and kv_len.is_contiguous()
+        assert (kpm is not None or seq is not None) and kv_len.dtype == torch.int32 and kv_len.numel() == B and kv_len.is_contiguous()
         d.kv_len = kv_len.data_ptr()
         STATS["attn_kv_len"] = STATS.get("attn_kv_len", 0) + 1
     else:
@@ -215,7 +224,7 @@ def attn_bwd_fill(d, do, dq, dk, dv, delta, D, layout_q="bt", layout_kv="bt"):
     d.dV = dv.data_ptr(); d.dv_sb, d.dv_sh, d.dv_st = st(dv, layout_kv)
     d.delta = delta.data_ptr()
     # live-tile flags (cst_attn_desc.q_flags): the backward stops at the last 64-query tile with a non-zero upstream gradient
-    flags = torch.empty(int(d.B) * int(d.H) * ((int(d.Tq) + 63) // 64), dtype=torch.uint8, device=do.device)
+    flags = torch.empty(int(d.B) * int(d.H) * ((int(d.Tq) + 63) // 64), dtype=torch.uint8, device=do.device)  # d.B / d.Tq: sequences / longest one when packed
     d.q_flags = flags.data_ptr()
     STATS["attn_q_flags"] = STATS.get("attn_q_flags", 0) + 1
     d._q_flags_owner = flags  # the workspace lives as long as the descriptor (i.e. until the launch has been enqueued)
@@ -334,6 +343,24 @@ def mask_rows(x, mask_u8):
     L.check(L.load().cst_mask_rows(L.ptr(x), L.ptr(mask_u8), L.ptr(y), x.shape[0], x.shape[1], L.dtype_code(x.dtype),
                                    L.stream_ptr()), "cst_mask_rows")
     return y
+
+
+def rows_pack(x, seq_off, n_rows, tail_sum):
+    """[B, T, C] -> [n_rows, C] (include/cst.h: cst_rows_pack)."""
+    assert x.dim() == 3 and x.is_contiguous() and seq_off.dtype == torch.int32 and seq_off.numel() == x.shape[0] + 1
+    out = torch.empty(n_rows, x.shape[2], dtype=x.dtype, device=x.device)
+    L.check(L.load().cst_rows_pack(L.ptr(x), L.ptr(seq_off), L.ptr(out), x.shape[0], x.shape[1], x.shape[2], int(bool(tail_sum)), L.dtype_code(x.dtype),
+                                   L.stream_ptr()), "cst_rows_pack")
+    return out
+
+
+def rows_unpack(y, seq_off, B, T, tail_broadcast):
+    """[n_rows, C] -> [B, T, C] (include/cst.h: cst_rows_unpack)."""
+    assert y.dim() == 2 and y.is_contiguous() and seq_off.dtype == torch.int32 and seq_off.numel() == B + 1
+    out = torch.empty(B, T, y.shape[1], dtype=y.dtype, device=y.device)
+    L.check(L.load().cst_rows_unpack(L.ptr(y), L.ptr(seq_off), L.ptr(out), B, T, y.shape[1], int(bool(tail_broadcast)), L.dtype_code(y.dtype),
+                                     L.stream_ptr()), "cst_rows_unpack")
+    return out
 
 
 def dropout(x, p, key):

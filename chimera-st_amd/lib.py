@@ -63,6 +63,7 @@ class AttnDesc(ctypes.Structure):
         ("delta", c_p),
         ("kv_len", c_p),
         ("q_flags", c_p),
+        ("seq_offsets", c_p),
     ]
 
 
@@ -112,6 +113,8 @@ SYMBOLS = [
     ("cst_col2im1d", c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, c_p]),
     ("cst_mask_rows", c_int, [c_p, c_p, c_p, c_i64, c_i64, c_int, c_p]),
     ("cst_dropout", c_int, [c_p, c_p, c_i64, c_f, ctypes.c_uint32, c_int, c_p]),
+    ("cst_rows_pack", c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_int, c_int, c_p]),
+    ("cst_rows_unpack", c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_int, c_int, c_p]),
     ("cst_dropout_scale", c_int, [c_p, c_p, c_i64, c_f, c_f, ctypes.c_uint32, c_int, c_p]),
     ("cst_embed_pos_fwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_f, c_i64, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_f, ctypes.c_uint32, c_int, c_p]),
     ("cst_embed_bwd", c_int, [c_p, c_p, c_p, c_f, c_i64, c_i64, c_i64, c_i64, c_f, ctypes.c_uint32, c_int, c_int, c_p]),

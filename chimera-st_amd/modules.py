@@ -255,11 +255,13 @@ class MultiheadAttention(FairseqIncrementalState, nn.Module):
             nn.init.constant_(self.out_proj.bias, 0.0)
 
     def forward(self, query, key, value, key_padding_mask=None, incremental_state=None, need_weights=True,
-                static_kv=False, attn_mask=None, before_softmax=False, need_head_weights=False, resid=None, out_dropout_p=0.0):
+                static_kv=False, attn_mask=None, before_softmax=False, need_head_weights=False, resid=None, out_dropout_p=0.0, seq=None):
         """Input shape: Time x Batch x Channel.  Returns (attn [T,B,C], None).
         `resid` / `out_dropout_p` (extensions): out = resid + dropout(out_proj(attn)) inside out_proj's GEMM epilogue — the
         caller's `residual + self.dropout_module(x)` (transformer_layer.py:139-141) without a separate pass.
-        Attention-probability dropout (self.dropout_module, :359) runs inside the attention kernels."""
+        Attention-probability dropout (self.dropout_module, :359) runs inside the attention kernels.
+        `seq` (extension): a functional.PackedRows plan — query is [rows, 1, C], the padding-free packing of a right-padded batch;
+        every sequence attends to its own real frames (what key_padding_mask expresses for the padded batch)."""
         if need_head_weights or before_softmax:
             raise NotImplementedError("attention weights never leave the fused kernel (need_weights is ignored)")
         attn_p = self.dropout_module.p if (self.training and self.dropout_module.p > 0) else 0.0
@@ -282,6 +284,7 @@ class MultiheadAttention(FairseqIncrementalState, nn.Module):
                 assert self.encoder_decoder_attention and not self.self_attention
                 key = value = None
 
+        assert seq is None or (self.self_attention and saved_state is None), "packed rows are a self-attention training path"
         if self.self_attention and saved_state is None:
             # packed projection: one [3C, C] GEMM (and one dX / dW GEMM in backward) instead of three; the fused attention
             # kernel reads q | k | v as channel slices of the [B, T, 3C] result and writes dq | dk | dv the same way.
@@ -295,7 +298,8 @@ class MultiheadAttention(FairseqIncrementalState, nn.Module):
                 qkv = CF.linear(qb, w, bqkv)
             if key_padding_mask is not None and key_padding_mask.dim() == 0:
                 key_padding_mask = None
-            attn = CF.attention_packed(qkv, self.num_heads, key_padding_mask, causal, self.scaling, dropout_p=attn_p)
+            attn = CF.attention_packed(qkv, self.num_heads, None if seq is not None else key_padding_mask, causal, self.scaling,
+                                       dropout_p=attn_p, seq=seq)
             out = self.out_proj(attn, resid=resid_b, dropout_p=out_dropout_p)
             return to_time_major_view(out), None
         q = self.q_proj(qb)

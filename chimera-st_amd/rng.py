@@ -61,3 +61,20 @@ def keep_mask_numpy(key, n, p):
     x ^= x >> u(13)
     half = np.where((idx & u(1)) == 1, x >> u(16), x & u(0xFFFF))
     return half >= u(int(p * 65536.0 + 0.5))
+
+
+def keep_mask_attn_numpy(key, n, p):
+    """Keep mask of the attention-probability dropout sites (csrc/cst_common.h: cst_drop_bits24 — the mixer made of 24-bit
+    multiply-adds the attention kernels evaluate; same element-pair / 16-bit-threshold scheme as keep_mask_numpy)."""
+    u = np.uint64
+    idx = np.arange(n, dtype=np.uint64)
+    pair = (idx >> u(1)) & u(_M32)
+    key2 = (int(key) * 0x2C1B3C6D + 0x297A2D39) & _M32
+    x = (pair ^ u(int(key) & _M32)) & u(_M32)
+    t = ((x & u(0xFFFFFF)) * u(0x9E3779)) & u(_M32)
+    t = ((((x >> u(8)) & u(0xFFFFFF)) * u(0x7FEB35)) + t) & u(_M32)
+    t ^= t >> u(15)
+    w = (((t & u(0xFFFFFF)) * u(0x85EBCB)) + u(key2)) & u(_M32)
+    w ^= w >> u(13)
+    half = np.where((idx & u(1)) == 1, w >> u(16), w & u(0xFFFF))
+    return half >= u(int(p * 65536.0 + 0.5))

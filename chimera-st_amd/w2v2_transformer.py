@@ -88,6 +88,9 @@ class S2T_W2V2_TransformerEncoder(FairseqEncoder):
         self.wav2vec_model = Wav2Vec2Model.build_model(ckpt["args"], task=None)
         if not self.reset_w2v and ckpt["model"] is not None:
             self.wav2vec_model.load_state_dict(ckpt["model"])
+        # this encoder reads the wav2vec2 output only through the subsampler (a few frames past each utterance's end) and masks
+        # padding from there on: the padding frames of the wav2vec2 layer stack are never consumed (wav2vec2.TransformerEncoder)
+        self.wav2vec_model.encoder.padding_rows_consumed = False
         self.dropout_module = FairseqDropout(p=args.dropout, module_name=self.__class__.__name__)
         self.embed_scale = 1.0 if args.no_scale_embedding else math.sqrt(args.encoder_embed_dim)
         self.padding_idx = 1

@@ -89,6 +89,9 @@ class S2TTransformerInterlinguaModelW2V2(S2TTransformerModelW2V2):
 class S2T_W2V2_TransformerInterlinguaEncoder(S2T_W2V2_TransformerEncoder):
     def __init__(self, args, src_tokens, embed_tokens):
         super().__init__(args)
+        # quirk Q1: the memory layers attend EVERY padded frame (all-False key padding mask, :292-295), so the values of the wav2vec2
+        # padding frames are consumed here: the padding-free wav2vec2 stack is used only while no dropout is active
+        self.wav2vec_model.encoder.padding_rows_consumed = True
         self.max_source_positions = args.max_source_positions
         self.text_embed_tokens = embed_tokens
         if embed_tokens is not None:

@@ -9,6 +9,7 @@ state dicts round-trip.
 MI355X layout: the whole CNN runs channels-last [B, L, C] so every conv after layer 0 is an implicit GEMM on
 MFMA tiles with the GELU in the epilogue, and `features.transpose(1, 2)` (:539) is free."""
 import math
+import os
 from argparse import Namespace
 
 import numpy as np
@@ -102,12 +103,12 @@ class TransformerSentenceEncoderLayer(nn.Module):
         self.fc2 = Linear(ffn_embedding_dim, embedding_dim)
         self.final_layer_norm = LayerNorm(embedding_dim)
 
-    def forward(self, x, self_attn_mask=None, self_attn_padding_mask=None, need_weights=False, att_args=None):
+    def forward(self, x, self_attn_mask=None, self_attn_padding_mask=None, need_weights=False, att_args=None, seq=None):
         p_drop = float(self.dropout) if self.training else 0.0             # dropout1 / dropout3 (wav2vec2.py:940-955)
         p_act = float(self.activation_dropout) if self.training else 0.0   # dropout2
         residual = x
         x, _ = self.self_attn(query=x, key=x, value=x, key_padding_mask=self_attn_padding_mask, need_weights=False,
-                              resid=residual, out_dropout_p=p_drop)  # x = residual + dropout1(attn) (out_proj epilogue)
+                              resid=residual, out_dropout_p=p_drop, seq=seq)  # x = residual + dropout1(attn) (out_proj epilogue)
         x = self.self_attn_layer_norm(x)
         residual = x
         x = to_time_major_view(CF.ffn(to_batch_major(x), self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
@@ -163,16 +164,43 @@ class TransformerEncoder(nn.Module):
         norm = v.float().pow(2).sum(dim=(0, 1), keepdim=True).sqrt()
         return (v.float() * (pc.weight_g.float() / norm)).to(v.dtype)
 
-    def forward(self, x, padding_mask=None):
-        x, padding_mask = self.extract_features(x, padding_mask)
+    def forward(self, x, padding_mask=None, plan=None):
+        x, padding_mask = self.extract_features(x, padding_mask, plan)
         return x, padding_mask
 
-    def extract_features(self, x, padding_mask=None):
+    # Padding-free layer stack.  Rows of the 12 post-norm layers are independent of each other except through attention, whose
+    # keys are the real frames only.  A padding frame t >= len + conv_pos/2 of an utterance sees nothing but zeros through the
+    # positional convolution (the frames were zeroed at :820-821), so ALL such frames of an utterance enter the stack with one and
+    # the same vector and leave every layer with one and the same vector: the stack runs on len + conv_pos/2 + 1 rows per
+    # utterance and the last row is copied to the frames behind it (functional.pack_rows / unpack_rows).  With every dropout
+    # inactive this reproduces the padded computation bit for bit, padding frames included.  With dropout active the copies
+    # share one mask instead of drawing their own: allowed only where nobody reads those frames (`padding_rows_consumed = False`,
+    # set by the s2t_transformer_w2v2 encoder: its subsampler reads a handful of frames past the end, all inside the margin, and
+    # every later layer masks the padding); the Chimera memory attends every padded frame (quirk Q1), so there the padded stack
+    # stays whenever a dropout is active.
+    padding_rows_consumed = True
+
+    def packing_margin(self):
+        return self.conv_pos // 2
+
+    def wants_packing(self, padding_mask):
+        if padding_mask is None or os.environ.get("CST_NO_PACK"):
+            return False
+        noisy = self.training and (self.dropout > 0 or any(l.self_attn.dropout_module.p > 0 or l.activation_dropout > 0 for l in self.layers))
+        return (not noisy) or (not self.padding_rows_consumed)
+
+    def extract_features(self, x, padding_mask=None, plan=None):
         """x [B,T,C] batch-major."""
         if padding_mask is not None:
             x = CF.mask_rows(x, padding_mask)  # x[padding_mask] = 0 (:820-821)
         pc = getattr(self.pos_conv, "0")
         x = CF.pos_conv_gelu_residual(x, self.pos_conv_weight(), pc.bias, self.conv_pos_groups)  # x += GELU(SamePad(conv(x)))
+        if plan is None and self.wants_packing(padding_mask):
+            plan = CF.plan_packed_rows(padding_mask, self.packing_margin())
+        if plan is not None and plan.rows >= plan.B * plan.T:
+            plan = None  # nothing to drop (no padding beyond the margin)
+        if plan is not None:
+            x = CF.pack_rows(x, plan)  # [1, rows, C]
         x = self.layer_norm(x)
         if self.training and self.dropout > 0:
             x = CF.dropout(x, self.dropout)  # F.dropout(x, p=self.dropout) (:830)
@@ -180,10 +208,13 @@ class TransformerEncoder(nn.Module):
         for layer in self.layers:
             dropout_probability = np.random.random()  # same RNG call order as the reference (:836-840)
             if not self.training or (dropout_probability > self.layerdrop):
-                x, _ = layer(x, self_attn_padding_mask=padding_mask, need_weights=False)
+                x, _ = layer(x, self_attn_padding_mask=None if plan is not None else padding_mask, need_weights=False, seq=plan)
             else:
                 notify_unused_parameters(layer.parameters())  # keeps the overlapped bucket order moving (distributed.py)
-        return to_batch_major(x), padding_mask
+        x = to_batch_major(x)
+        if plan is not None:
+            x = CF.unpack_rows(x, plan)  # [B, T, C]; frames behind the kept rows repeat the last kept row
+        return x, padding_mask
 
 
 @register_model("wav2vec2")
@@ -251,6 +282,16 @@ class Wav2Vec2Model(nn.Module):
                 if m is not None:
                     heads += list(m.parameters())
             notify_unused_parameters(heads)
+        plan = None
+        if padding_mask is not None and self.encoder.wants_packing(padding_mask):
+            # the packing plan needs two integers on the host (rows in total, longest sequence): read them HERE, before the CNN is
+            # queued — the stream is empty at this point of an update, later it would drain 20 ms of queued convolutions
+            t1 = self.feature_extractor.output_length(source.shape[1])
+            pm = padding_mask
+            extra = pm.size(1) % t1
+            if extra > 0:
+                pm = pm[:, :-extra]
+            plan = CF.plan_packed_rows(pm.view(pm.size(0), t1, -1).all(-1), self.encoder.packing_margin())
         nz_last = None
         if padding_mask is not None and self.training:
             # the frame-level padding mask of :543-548, known before the CNN runs: frames past the last real one get a zero gradient
@@ -279,7 +320,7 @@ class Wav2Vec2Model(nn.Module):
             feats = self.post_extract_proj(feats)
         if self.training and self.dropout_input_p > 0:
             feats = CF.dropout(feats, self.dropout_input_p)  # self.dropout_input (:553)
-        x, padding_mask = self.encoder(feats, padding_mask=padding_mask)
+        x, padding_mask = self.encoder(feats, padding_mask=padding_mask, plan=plan)
         return {"x": x, "padding_mask": padding_mask}
 
     def extract_features(self, source, padding_mask, mask=False):

@@ -185,6 +185,13 @@ typedef struct {
    * have a non-zero dO row and the dQ / dK-dV kernels stop at the last such tile — the tiles beyond it contribute exact zeros
    * (dP = dO V^T = 0 and delta = 0 give dS = 0), so the gradients are bit-identical to the full walk. */
   uint8_t* q_flags;
+  /* optional int32 [B+1] (NULL = dense [B, T] batches): PACKED self-attention over the row sets of cst_rows_pack.  Q / K / V / O and
+   * all gradients are [rows, H*D] (the *_sb batch strides are ignored; Q, K and V share one row stride); sequence b owns rows
+   * [seq_offsets[b], seq_offsets[b+1]) as QUERIES and its first kv_len[b] rows as KEYS (kv_len NULL: all of them; the remaining
+   * rows are the padding frames kept for their outputs: they attend, nobody attends to them, their dK / dV are zero).  Tq = Tk =
+   * the longest sequence: it sizes the grid and strides lse / delta / q_flags [B, H, Tq] and the dropout index space, so that a
+   * packed call draws exactly the dropout masks of the dense call it replaces.  key_padding_mask must be NULL. */
+  const int32_t* seq_offsets;
 } cst_attn_desc;
 
 int cst_attn_fwd(const cst_attn_desc* d, cst_stream stream);
@@ -243,6 +250,23 @@ int cst_col2im1d(const void* dcol, const void* z, void* dx, int64_t B, int64_t L
                  int64_t C, int k, int stride, int pad, int dact, int dtype, cst_stream stream);
 /* y[r,:] = mask[r] ? 0 : x[r,:]   (x[padding_mask] = 0, wav2vec2.py:820-821) */
 int cst_mask_rows(const void* x, const uint8_t* mask, void* y, int64_t rows, int64_t cols, int dtype, cst_stream stream);
+
+/* Packed (padding-free) row sets.  A length-sorted, right-padded batch [B, T, C] of a row-wise network (LayerNorm, Linear, FFN,
+ * self-attention with a key-padding mask: wav2vec2.py:818-845, 937-957) carries, per utterance, `len` real frames followed by
+ * padding frames whose values the reference also computes.  Past the reach of the positional convolution (len + conv_pos/2) all
+ * padding frames of an utterance enter the layer stack with the SAME vector and keep identical values through every row-wise
+ * layer, so the stack may run on  n_b = min(T, len_b + conv_pos/2 + 1)  rows per utterance — the last one standing for all the
+ * identical rows behind it — and reproduce the padded result bit for bit (dropout off; with dropout on the padding rows share a
+ * mask).  seq_off int32 [B+1]: sequence b owns packed rows [seq_off[b], seq_off[b+1]).
+ *   cst_rows_pack   : dst[seq_off[b] + t] = src[b, t]; with tail_sum the last packed row of a sequence receives the SUM of
+ *                     src[b, n_b - 1 .. T - 1] in index order (the gradient of cst_rows_unpack with tail_broadcast; deterministic).
+ *   cst_rows_unpack : dst[b, t] = src[seq_off[b] + min(t, n_b - 1)] with tail_broadcast, zeros beyond n_b otherwise (the
+ *                     gradient of cst_rows_pack without tail_sum).
+ * C % 8 == 0. */
+int cst_rows_pack(const void* src, const int32_t* seq_off, void* dst, int64_t B, int64_t T, int64_t C, int tail_sum, int dtype,
+                  cst_stream stream);
+int cst_rows_unpack(const void* src, const int32_t* seq_off, void* dst, int64_t B, int64_t T, int64_t C, int tail_broadcast, int dtype,
+                    cst_stream stream);
 
 /* y = x * keep / (1 - p): FairseqDropout (modules/fairseq_dropout.py:20-37) forward; the same call on dy is its backward.
  * The mask is counter-based — keep(key, element index), csrc/cst_common.h — so nothing is stored between the two calls and

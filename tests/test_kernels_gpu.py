@@ -678,7 +678,7 @@ def test_gemm_epilogue_dropout(K, dt, big):
 @pytest.mark.parametrize("Tq,Tk,causal", [(100, 100, False), (77, 131, False), (64, 64, True)])
 def test_attention_dropout(K, dt, Tq, Tk, causal):
     """Attention-probability dropout inside the fused kernels, forward and all three gradients, against explicit
-    softmax -> mask -> PV in fp32 with the mask from rng.keep_mask_numpy (index ((b*H+h)*Tq+q)*Tkp + k, Tkp = even(Tk))."""
+    softmax -> mask -> PV in fp32 with the mask from rng.keep_mask_attn_numpy (index ((b*H+h)*Tq+q)*Tkp + k, Tkp = even(Tk))."""
     k, L = K
     B, H, D = 2, 3, 64
     p, key = 0.2, 4242
@@ -692,7 +692,9 @@ def test_attention_dropout(K, dt, Tq, Tk, causal):
     do = rnd(B, Tq, H * D, dt=dt, seed=5)
     dq, dk, dv = k.attn_bwd(do, q.detach(), kk.detach(), v.detach(), o, lse, H, D, kpm, causal, scale, "bt", "bt", p, key)
     Tkp = (Tk + 1) // 2 * 2
-    keep = _keep(key, B * H * Tq * Tkp, p).view(B, H, Tq, Tkp)[..., :Tk].cuda()
+    from importlib import import_module
+    keep = torch.from_numpy(import_module("chimera-st_amd.rng").keep_mask_attn_numpy(key, B * H * Tq * Tkp, p)).view(B, H, Tq, Tkp)[..., :Tk].cuda()
+    assert abs(float(keep.float().mean()) - (1 - p)) < 0.02
     qf, kf, vf = (t.detach().float().requires_grad_(True) for t in (q, kk, v))
     qh = qf.view(B, Tq, H, D).transpose(1, 2); kh = kf.view(B, Tk, H, D).transpose(1, 2); vh = vf.view(B, Tk, H, D).transpose(1, 2)
     s = (qh @ kh.transpose(-1, -2)) * scale
@@ -824,3 +826,93 @@ def test_embed_positions_dense_path_and_mask_source(K, dt, with_pos):
         E = rnd(50, C, dt=dt, seed=9)
         out = k.embed_pos_fwd(tok.cuda(), mask.to(torch.uint8).cuda(), E, None, table, scale, pad, 0.0, 0)
         check(out, scale * E.float()[tok.cuda()] + O.positional_embedding(mask, C, pad).cuda(), dt, "embed_pos ids + mask")
+
+
+# --------------------------------------------------------------------------------------------
+# packed (padding-free) rows: cst_rows_pack / cst_rows_unpack and packed self-attention against the dense padded calls
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DT)
+def test_rows_pack_unpack(K, dt):
+    k, L = K
+    B, T, C = 5, 77, 136
+    n = torch.tensor([77, 60, 33, 77, 1], dtype=torch.int32)
+    off = torch.zeros(B + 1, dtype=torch.int32)
+    off[1:] = torch.cumsum(n, 0)
+    rows = int(off[-1])
+    x = rnd(B, T, C, dt=dt, seed=1)
+    offd = off.cuda()
+    packed = k.rows_pack(x, offd, rows, tail_sum=False)
+    for b in range(B):
+        assert torch.equal(packed[off[b]:off[b + 1]], x[b, :n[b]])
+    back = k.rows_unpack(packed, offd, B, T, tail_broadcast=True)
+    back0 = k.rows_unpack(packed, offd, B, T, tail_broadcast=False)
+    for b in range(B):
+        nb = int(n[b])
+        assert torch.equal(back[b, :nb], x[b, :nb]) and torch.equal(back0[b, :nb], x[b, :nb])
+        if nb < T:
+            assert torch.equal(back[b, nb:], x[b, nb - 1].expand(T - nb, C)) and float(back0[b, nb:].float().abs().max()) == 0.0
+    g = rnd(B, T, C, dt=dt, seed=2)
+    gs = k.rows_pack(g, offd, rows, tail_sum=True)
+    assert torch.equal(gs, k.rows_pack(g, offd, rows, tail_sum=True))  # fixed summation order
+    for b in range(B):
+        nb = int(n[b])
+        assert torch.equal(gs[off[b]:off[b] + nb - 1], g[b, :nb - 1])
+        check(gs[off[b] + nb - 1], g[b, nb - 1:].float().sum(0), dt, "tail sum b=%d" % b)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("p", [0.0, 0.15])
+def test_attention_packed_rows_equal_the_padded_call_bit_for_bit(K, dt, p):
+    """Self-attention over packed rows (cst_attn_desc.seq_offsets: queries = the kept rows of each sequence, keys = its real frames)
+    against the dense call with a key padding mask on the same data: identical bits for the kept rows — outputs, lse, and the
+    three gradients — including the dropout masks (the packed call indexes the mask space of the padded one)."""
+    from importlib import import_module
+    CF = import_module("chimera-st_amd.functional")
+    k, L = K
+    B, T, H, D = 4, 300, 3, 64
+    C = H * D
+    lens = torch.tensor([300, 251, 130, 17])
+    margin = 9
+    pm = (torch.arange(T)[None, :] >= lens[:, None]).cuda()
+    plan = CF.plan_packed_rows(pm, margin)
+    assert plan.longest == 300 and plan.rows == int(torch.clamp(lens + margin + 1, max=T).sum())
+    qkv = rnd(B, T, 3 * C, dt=dt, seed=11)
+    do = rnd(B, T, C, dt=dt, seed=12)
+    key = 777
+    # dense padded call
+    q, kk, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    kpm = pm.to(torch.uint8).contiguous()
+    o = torch.empty(B, T, C, dtype=dt, device="cuda"); lse = torch.empty(B, H, T, dtype=torch.float32, device="cuda")
+    d = k.attn_desc(q, kk, v, o, lse, H, D, kpm, False, D ** -0.5, "bt", "bt", p, key, None)
+    k.attn_fwd_desc(d)
+    dqkv = torch.empty_like(qkv); delta = torch.empty_like(lse)
+    k.attn_bwd_fill(d, do, dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:], delta, D)
+    k.attn_bwd_desc(d)
+    # packed call on the kept rows
+    off = plan.offsets
+    pq = k.rows_pack(qkv, off, plan.rows, False).unsqueeze(0)
+    pdo = k.rows_pack(do, off, plan.rows, False).unsqueeze(0)
+    po = torch.empty(1, plan.rows, C, dtype=dt, device="cuda"); plse = torch.empty(B, H, plan.longest, dtype=torch.float32, device="cuda")
+    d2 = k.attn_desc(pq[..., :C], pq[..., C:2 * C], pq[..., 2 * C:], po, plse, H, D, None, False, D ** -0.5, "bt", "bt", p, key, plan.kv_len, (off, plan.longest))
+    k.attn_fwd_desc(d2)
+    pdqkv = torch.empty_like(pq); pdelta = torch.empty_like(plse)
+    k.attn_bwd_fill(d2, pdo, pdqkv[..., :C], pdqkv[..., C:2 * C], pdqkv[..., 2 * C:], pdelta, D)
+    k.attn_bwd_desc(d2)
+    offh = off.cpu()
+    for b in range(B):
+        nb, lb = int(offh[b + 1] - offh[b]), int(lens[b])
+        sl = slice(int(offh[b]), int(offh[b + 1]))
+        assert torch.equal(po[0, sl], o[b, :nb]), "output rows of sequence %d" % b
+        assert torch.equal(plse[b, :, :nb], lse[b, :, :nb])
+        # gradients: the dense call also receives dO on the rows the packed call dropped, which changes dK / dV of the real frames;
+        # compare against a dense backward whose dO is zero behind the kept rows
+    do_kept = do.clone()
+    for b in range(B):
+        do_kept[b, int(offh[b + 1] - offh[b]):] = 0
+    dqkv2 = torch.empty_like(qkv)
+    k.attn_bwd_fill(d, do_kept, dqkv2[..., :C], dqkv2[..., C:2 * C], dqkv2[..., 2 * C:], delta, D)
+    k.attn_bwd_desc(d)
+    for b in range(B):
+        nb = int(offh[b + 1] - offh[b])
+        sl = slice(int(offh[b]), int(offh[b + 1]))
+        assert torch.equal(pdqkv[0, sl], dqkv2[b, :nb]), "gradient rows of sequence %d" % b

@@ -282,3 +282,52 @@ def test_cnn_gradient_is_zero_past_the_bound_the_weight_gradients_use():
             assert n == 0 or float(gr[b, max(0, n - 3):n].abs().max()) > 0.0
             ragged += n < gr.shape[1]
     assert ragged > 0  # the fixture has utterances shorter than the batch maximum
+
+
+@pytest.mark.parametrize("kind,fixture", [("chimera", "chimera_tiny.npz"), ("s2t", "s2t_w2v2_tiny.npz")])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_padding_free_wav2vec2_stack_is_bit_identical(kind, fixture, dtype):
+    """The wav2vec2 layer stack on packed rows (wav2vec2.TransformerEncoder: real frames + the reach of the positional convolution
+    + one row standing for all identical padding frames behind it) against the padded stack (CST_NO_PACK=1), dropout off: the
+    SAME bits in the forward pass — the wav2vec2 output on every frame, padding included, the encoder output, the loss.  The
+    parameter gradients are sums over token rows; dropping rows that contribute exact zeros changes how the reduction is cut into
+    split-K slices and tiles, i.e. the ORDER of the fp32 additions, so they agree to summation rounding (fp32: 2e-5 of the tensor's
+    largest entry; bf16: one ulp of the rounded result), not bit for bit."""
+    import os
+    from importlib import import_module
+    K = import_module("chimera-st_amd.kernels")
+    g = load_golden(fixture)
+    model, task, args = build_from_golden(g, kind, dtype)
+    tasks = import_module("chimera-st_amd.tasks")
+    # utterances of very different lengths, so that most of the shorter ones' frames are padding
+    sample = to_cuda(tasks.synthetic_sample(task.target_dictionary, 4, [9000, 5200, 2600, 1300], [9, 3, 12, 5], [4, 7, 2, 11], seed=7))
+    crit_mod = import_module("chimera-st_amd.criterions")
+    crit = (crit_mod.TripletSTMTContrastiveCriterion(task, False, 0.1, [1.0, 1.0, 1.0], 0.1) if kind == "chimera"
+            else crit_mod.LabelSmoothedCrossEntropyCriterion(task, False, 0.1))
+    model.train()
+
+    def run():
+        model.zero_grad()
+        K.STATS.clear()
+        enc = model.encoder(sample["net_input"]["src_tokens"], sample["net_input"]["src_lengths"])
+        w2v = model.encoder._get_w2v_feature(sample["net_input"]["src_tokens"], sample["net_input"]["src_lengths"])[0]
+        loss, _, _ = crit(model, sample)
+        loss.backward()
+        return (enc.encoder_out.detach().clone(), w2v.detach().clone(), loss.detach().clone(),
+                {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}, dict(K.STATS))
+
+    out_p, w2v_p, loss_p, grads_p, stats_p = run()
+    os.environ["CST_NO_PACK"] = "1"
+    try:
+        out_d, w2v_d, loss_d, grads_d, stats_d = run()
+    finally:
+        del os.environ["CST_NO_PACK"]
+    assert stats_p.get("attn_packed", 0) > 0 and stats_d.get("attn_packed", 0) == 0, (stats_p, stats_d)
+    assert torch.equal(w2v_p, w2v_d), "wav2vec2 output differs on %d elements" % int((w2v_p != w2v_d).sum())
+    assert torch.equal(out_p, out_d) and torch.equal(loss_p, loss_d)
+    assert grads_p.keys() == grads_d.keys()
+    tol = 2e-5 if dtype == torch.float32 else 8e-3
+    for n in grads_p:
+        a, b = grads_p[n].float(), grads_d[n].float()
+        err = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+        assert err <= tol, "gradient %s: %.3e of its largest entry" % (n, err)
