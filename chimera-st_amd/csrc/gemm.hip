@@ -269,6 +269,10 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmParams p) {
     for (int t = t0; t < t1; ++t) live |= ml[t] == p.m_epoch;
     if (!live) nk = 0;
   }
+  if (p.m_len) {  // this batch's rows from m_len[b0] on are all zero and unread: tiles behind it keep zero accumulators
+    typedef const __attribute__((address_space(4))) int32_t* cptr_t;
+    if (m0 >= (int64_t)((cptr_t)p.m_len)[b0]) nk = 0;
+  }
   int pos = kt0;  // the K tile the staging pointers stand at
   auto fetch = [&](int kt) {
     const int d = kt - pos;
@@ -423,7 +427,11 @@ __global__ __launch_bounds__(C::NT) void gemm_glds_kernel(GemmParams p) {
   const int per = (ktiles + p.splits - 1) / p.splits;
   const int kt0 = split * per;
   const int kt1 = (kt0 + per < ktiles) ? kt0 + per : ktiles;
-  const int nt = kt1 - kt0;
+  int nt = kt1 - kt0;
+  if (p.m_len) {  // this batch's rows from m_len[b0] on are all zero and unread: tiles behind it keep zero accumulators
+    typedef const __attribute__((address_space(4))) int32_t* cptr_t;
+    if (m0 >= (int64_t)((cptr_t)p.m_len)[b0]) nt = 0;
+  }
 
   // ---- per-lane DMA sources.  Group g of an operand tile = LDS bytes [g*1024, g*1024 + 1024); this wave owns groups
   //      wave + NWAVES*i.  Lane l fills bytes [l*16, l*16+16) of the group: which (row, chunk) that is, and therefore which
@@ -777,6 +785,7 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
     p.m_live = no_klive ? nullptr : d->m_live;
     p.m_epoch = d->m_epoch;
     p.k_len = no_klive ? nullptr : d->k_len;
+    p.m_len = no_klive ? nullptr : d->m_len;
   }
   {
     // m tiles per group of the XCD-local tile walk: 4 (a 4 x 8 patch of concurrent tiles per XCD) measured 2-8 % faster than 8 on the
@@ -819,6 +828,18 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
       double sum = 0.0;
       for (int64_t b = 0; b < d->batch0; ++b) sum += (double)(kl[b] < 0 ? 0 : (kl[b] < d->K ? kl[b] : d->K));
       kfrac *= sum / ((double)d->batch0 * (double)d->K);
+    }
+  }
+  if (p.m_len && cst_prof_is_on()) {  // conv GEMMs: credit the output tiles that still run their K loop
+    std::vector<int32_t> ml((size_t)d->batch0);
+    if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(ml.data(), p.m_len, sizeof(int32_t) * d->batch0, hipMemcpyDeviceToHost) == hipSuccess) {
+      const int64_t tiles = cst_ceil_div(d->M, 256);
+      double live = 0.0;
+      for (int64_t b = 0; b < d->batch0; ++b) {
+        const int64_t t = ml[b] <= 0 ? 0 : cst_ceil_div((int64_t)ml[b], 256);
+        live += (double)(t < tiles ? t : tiles);
+      }
+      kfrac *= live / ((double)d->batch0 * (double)tiles);
     }
   }
   if (p.m_live && cst_prof_is_on()) {  // dX GEMMs: credit the 256-row output tiles that still run their K loop (8p / 16-wave tile)

@@ -162,6 +162,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
       for (int i = 0; i < 4; ++i) live |= (t0 + i < tn) && ml[t0 + i < tn ? t0 + i : t0] == ep;
       if (!live) nt = 0;
     }
+    if (kp->m_len) {  // rows of this batch from m_len[b0] on: all zero in A, unread in C
+      typedef const __attribute__((address_space(4))) int32_t* iptr_t;
+      if (m0 >= (int64_t)((iptr_t)kp->m_len)[b0]) nt = 0;
+    }
     krem0 = (int)p.K - kt0 * BK;
     const T* abase = AK ? A + m0 * p.lda + (int64_t)kt0 * BK : A + (int64_t)kt0 * BK * p.lda + m0;
     const T* bbase = BKM ? B + n0 * p.ldb + (int64_t)kt0 * BK : B + (int64_t)kt0 * BK * p.ldb + n0;

@@ -31,6 +31,7 @@ struct GemmParams {
   int* sched;       // gemm8p: 16 zeroed ints of scheduling state (8 per-XCD item counters, 1 exit counter), nullptr = static walk
   const uint32_t* m_live; uint32_t m_epoch;  // rows of A in blocks of 64: an output tile with no live block skips its K loop
   const int32_t* k_len;  // gemm_kernel, per batch0: K rows >= k_len[b0] of A are zero
+  const int32_t* m_len;  // per batch0: output tiles with m0 >= m_len[b0] skip their K loop (rows of A all zero, values of C unused)
   const uint32_t* k_live; uint32_t k_epoch;  // gemm_kernel: K blocks of 64 whose stamp != k_epoch are all-zero in A and skipped
 };
 

@@ -540,8 +540,14 @@ class _Conv1dCLFn(torch.autograd.Function):
     so the zero rows the dX windows need at utterance boundaries exist without copying."""
 
     @staticmethod
-    def forward(ctx, x, w_cl, bias, k, stride, pad, act, prev_z, grad_is_dz, nz_out=None):
+    def forward(ctx, x, w_cl, bias, k, stride, pad, act, prev_z, grad_is_dz, nz_out=None, nz_in=None):
+        if _os.environ.get("CST_NO_MLEN"):  # A/B switch of the tests: compute the frames past each utterance's end as well
+            nz_in = None
+            fwd_len = None
+        else:
+            fwd_len = nz_out if bias is None else None
         ctx.nz_out = nz_out  # int32 [B]: the incoming gradient's rows t >= nz_out[b] are exactly zero (frames past the utterance's end)
+        ctx.nz_in = nz_in    # int32 [B]: the same bound for this layer's input rows ((nz_out - 1) * stride + k): dx is zero from there on
         B, Lin, Cin = x.shape
         Cout = w_cl.shape[0]
         if pad:
@@ -560,7 +566,7 @@ class _Conv1dCLFn(torch.autograd.Function):
         coff = Cout if padded_out else 0
         K.gemm(xp, w_cl, y_full, Lout, Cout, k * Cin, a_kmajor=1, b_kmajor=1, lda=stride * Cin, ldb=k * Cin, ldc=Cout, bias=bias,
                act=act, aux_out=z_full, ld_aux_out=Cout, batch0=B, sa=(xp.stride(0), 0), sc=(rows * Cout, 0), split_k=1,
-               a_off=0, c_off=coff)
+               a_off=0, c_off=coff, m_len=fwd_len)  # frames past an utterance's end: unread, left at act(0) = 0
         y = y_full[:, 1:1 + Lout] if padded_out else y_full
         z = (z_full[:, 1:1 + Lout] if padded_out else z_full) if z_full is not None else None
         ctx.save_for_backward(xp, w_cl, z, prev_z)
@@ -609,10 +615,14 @@ class _Conv1dCLFn(torch.autograd.Function):
                         continue
                     # B_r[ci][q*Cout + co] = W[co][ci][r + s*(n-1-q)]   (window position q <-> dz[u - (n-1) + q])
                     wr = w3[:, [taps[n - 1 - q] for q in range(n)], :].permute(2, 1, 0).reshape(Cin, n * Cout).contiguous()
+                    # rows u with stride * u + r >= nz_in[b] read only dz rows that are exactly zero: their K loop is skipped
+                    ml = None
+                    if ctx.nz_in is not None:
+                        ml = torch.clamp((ctx.nz_in - r + stride - 1) // stride, min=0).to(torch.int32).contiguous()
                     K.gemm(dzp, wr, dx_full, U, Cin, n * Cout, a_kmajor=1, b_kmajor=1, lda=Cout, ldb=n * Cout, ldc=stride * Cin,
                            batch0=B, sa=((Lout + 2) * Cout, 0), sc=(rows * Cin, 0), a_off=(2 - n) * Cout,
                            c_off=(Cin if dx_padded else 0) + r * Cin, dact=L.ACT_GELU if prev_z is not None else L.ACT_NONE,
-                           aux_in=pz_base, ld_aux_in=stride * Cin, split_k=1)
+                           aux_in=pz_base, ld_aux_in=stride * Cin, split_k=1, m_len=ml)
                 dx = dx_full[:, 1:1 + Lin] if dx_padded else dx_full
             else:
                 dz2 = dz_rows.reshape(B * Lout, Cout) if dzp is None else dzp[:, 1:1 + Lout].reshape(B * Lout, Cout)
@@ -632,10 +642,10 @@ class _Conv1dCLFn(torch.autograd.Function):
             dw = part.sum(0).to(w_cl.dtype)
         if has_bias and ctx.needs_input_grad[2]:
             db = K.colsum(dz_rows.reshape(B * Lout, Cout) if dzp is None else dzp[:, 1:1 + Lout].reshape(B * Lout, Cout), w_cl.dtype)
-        return dx, dw, db, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
-def conv1d_cl(x, weight, bias, stride, pad=0, act=None, prev_z=None, grad_is_dz=False, nz_out=None):
+def conv1d_cl(x, weight, bias, stride, pad=0, act=None, prev_z=None, grad_is_dz=False, nz_out=None, nz_in=None):
     """Channels-last conv1d.  x [B,Lin,Cin]; weight [Cout,Cin,k] (torch layout).  Returns (y, z) where z is
     the pre-activation (None without activation).  If `prev_z` (pre-GELU tensor that produced x = GELU(prev_z))
     is given, the returned input-gradient is already multiplied by GELU'(prev_z), i.e. it is d/d prev_z; the
@@ -645,7 +655,7 @@ def conv1d_cl(x, weight, bias, stride, pad=0, act=None, prev_z=None, grad_is_dz=
     w_cl = weight.permute(0, 2, 1).reshape(Cout, k * Cin)
     if not w_cl.is_contiguous():
         w_cl = w_cl.contiguous()
-    return _Conv1dCLFn.apply(x, w_cl, bias, k, stride, pad, _ACT[act], prev_z, bool(grad_is_dz), nz_out)
+    return _Conv1dCLFn.apply(x, w_cl, bias, k, stride, pad, _ACT[act], prev_z, bool(grad_is_dz), nz_out, nz_in)
 
 
 # ------------------------------------------------------------------------------------------------

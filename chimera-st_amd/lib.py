@@ -41,6 +41,7 @@ class GemmDesc(ctypes.Structure):
         ("k_live", c_p), ("k_epoch", ctypes.c_uint32),
         ("m_live", c_p), ("m_epoch", ctypes.c_uint32),
         ("k_len", c_p),
+        ("m_len", c_p),
     ]
 
 

@@ -57,7 +57,7 @@ class ConvFeatureExtractionModel(nn.Module):
         frame t of layer i+1 reads rows [s t, s t + k) of layer i, so layer i's gradient is zero from (nz - 1) s + k on — and the
         weight-gradient GEMMs of each layer stop their reduction over frames there (cst_gemm_desc.k_len): exact."""
         nz = [None] * len(self.conv_spec)
-        if nz_last is not None and torch.is_grad_enabled():
+        if nz_last is not None:
             cur, lens = nz_last, []
             s_ = x.shape[1]
             for (_, k_, st_) in self.conv_spec:
@@ -68,6 +68,7 @@ class ConvFeatureExtractionModel(nn.Module):
                 nz[i] = cur
                 _, k_, st_ = self.conv_spec[i]
                 cur = torch.where(cur > 0, (cur - 1) * st_ + k_, torch.zeros_like(cur))
+            nz[0] = torch.clamp(cur, max=lens[0]).to(torch.int32).contiguous()
         l0 = self.conv_layers[0]
         dim, k, stride = self.conv_spec[0]
         y = CF.conv0_gn_gelu(x, getattr(l0, "0").weight, getattr(l0, "2").weight, getattr(l0, "2").bias, stride)
@@ -77,7 +78,9 @@ class ConvFeatureExtractionModel(nn.Module):
             dim, k, stride = self.conv_spec[i]
             w = getattr(self.conv_layers[i], "0").weight
             # fold GELU' of layer i-1 into layer i's col2im pass; layer i then receives d/dz directly
-            y, z = CF.conv1d_cl(y, w, None, stride, pad=0, act="gelu", prev_z=z, grad_is_dz=(i < n - 1), nz_out=nz[i])
+            # rows t >= nz[i][b] of layer i are frames nobody reads (the stack's output is zeroed behind the utterance's end,
+            # wav2vec2.py:820-821) and whose gradient is exactly zero: their GEMM tiles skip the K loop (cst_gemm_desc.m_len / k_len)
+            y, z = CF.conv1d_cl(y, w, None, stride, pad=0, act="gelu", prev_z=z, grad_is_dz=(i < n - 1), nz_out=nz[i], nz_in=nz[i - 1])
         return y
 
     def output_length(self, s):
@@ -293,7 +296,7 @@ class Wav2Vec2Model(nn.Module):
                 pm = pm[:, :-extra]
             plan = CF.plan_packed_rows(pm.view(pm.size(0), t1, -1).all(-1), self.encoder.packing_margin())
         nz_last = None
-        if padding_mask is not None and self.training:
+        if padding_mask is not None:
             # the frame-level padding mask of :543-548, known before the CNN runs: frames past the last real one get a zero gradient
             # (they are overwritten with zeros at the encoder input), which bounds every conv layer's weight-gradient reduction
             t1 = self.feature_extractor.output_length(source.shape[1])

@@ -141,6 +141,11 @@ typedef struct {
   const int32_t* k_len;              /* optional, [batch0]: rows k >= k_len[b0] of batch b0's A are all zero (a trailing run — the
                                         frames past an utterance's end in the conv weight-gradient GEMMs); the K loop of that batch
                                         stops there and split-K divides the live range.  Exact. */
+  const int32_t* m_len;              /* optional, [batch0]: rows m >= m_len[b0] of batch b0's A are all zero AND nobody reads those rows
+                                        of C for their value (the frames past an utterance's end in the conv feature extractor: the
+                                        reference zeroes them behind the CNN, wav2vec2.py:820-821, and their gradient is exactly zero).
+                                        Output tiles that lie entirely behind m_len[b0] skip their K loop and run the epilogue on
+                                        zero accumulators (C = epilogue(0): 0 for the bias-free GELU / GELU' epilogues of that stack). */
 } cst_gemm_desc;
 
 int64_t cst_gemm_workspace(const cst_gemm_desc* d);
