@@ -522,3 +522,48 @@ extern "C" int cst_conv0_gn_gelu_bwd(const void* dy, const float* wav, const voi
   }
   return cst_check_launch("cst_conv0_gn_gelu_bwd");
 }
+
+// ---- live-frame limits of the whole conv stack (include/cst.h: cst_conv_row_limits) -----------------------------------------------
+namespace {
+struct ConvSpec8 { int k[8], s[8], len[8]; };
+__global__ void conv_row_limits_kernel(const int32_t* nz_last, ConvSpec8 sp, int L, int smax, int32_t* out, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int nz[8];
+  int cur = nz_last[b];
+  for (int i = L - 1; i >= 1; --i) {
+    cur = cur < sp.len[i] ? cur : sp.len[i];
+    nz[i] = cur;
+    cur = cur > 0 ? (cur - 1) * sp.s[i] + sp.k[i] : 0;
+  }
+  nz[0] = cur < sp.len[0] ? cur : sp.len[0];
+  const int64_t plane = (int64_t)(1 + smax) * B;
+  for (int i = 0; i < L; ++i) {
+    out[i * plane + b] = nz[i];
+    for (int r = 0; r < smax; ++r) {
+      int v = 0;
+      if (i >= 1 && r < sp.s[i]) {
+        const int d = nz[i - 1] - r;
+        v = d > 0 ? (d + sp.s[i] - 1) / sp.s[i] : 0;
+      }
+      out[i * plane + (int64_t)(1 + r) * B + b] = v;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int cst_conv_row_limits(const int32_t* nz_last, const int32_t* k, const int32_t* stride, int L, int64_t S, int32_t* out,
+                                   int64_t B, int smax, cst_stream stream) {
+  CST_REQUIRE(nz_last && k && stride && out && B > 0 && L >= 1 && L <= 8 && smax >= 1 && smax <= 8, "cst_conv_row_limits: bad args");
+  ConvSpec8 sp;
+  int64_t len = S;
+  for (int i = 0; i < 8; ++i) {
+    sp.k[i] = i < L ? k[i] : 1;
+    sp.s[i] = i < L ? stride[i] : 1;
+    CST_REQUIRE(sp.k[i] >= 1 && sp.s[i] >= 1 && sp.s[i] <= 8 && (i == 0 || i >= L || sp.s[i] <= smax), "cst_conv_row_limits: bad layer %d", i);
+    if (i < L) len = len >= sp.k[i] ? (len - sp.k[i]) / sp.s[i] + 1 : 0;
+    sp.len[i] = (int)len;
+  }
+  hipLaunchKernelGGL(conv_row_limits_kernel, dim3((unsigned)cst_ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, nz_last, sp, L, smax, out, (int)B);
+  return cst_check_launch("cst_conv_row_limits");
+}

@@ -884,6 +884,8 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
   // (A k-major only: with an mn-major A the register-staged 16-wave kernel measured 20-30 % faster on the dW shapes; and not
   //  with an act'(aux_in) epilogue, whose 128 KiB-per-tile operand read is exposed at one workgroup per CU: 0.49 vs 0.42 ms)
   static const bool all_8p = getenv("CST_GEMM_8P_ALL") != nullptr;
+  // act'(aux_in) epilogues: taken since the operand vectors are requested in one burst ahead of the epilogue passes (gemm8p.hip)
+  static const bool dact_8p = getenv("CST_GEMM_8P_NO_DACT") == nullptr;
   static const bool no_skinny = getenv("CST_GEMM_NO_SKINNY") != nullptr;
   static const bool no_narrow = getenv("CST_GEMM_NO_NARROW") != nullptr;
   if (!no_narrow && !seg && !large && ak && bk && d->N <= 64 && d->M > 256) {
@@ -895,7 +897,7 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
   } else if (!no_skinny && ak && bk && !seg && d->M <= 256 && nbatch == 1 && p.splits == 1) {
     rc = d->dtype == CST_BF16 ? launch_glds<bf16_t, true, true, CfgSkinny, 4>(p, d->M, d->N, nbatch, s)
                               : launch_glds<float, true, true, CfgSkinny, 4>(p, d->M, d->N, nbatch, s);
-  } else if (d->dtype == CST_BF16 && !seg && !no_8p && (ak || all_8p || force_8p) && (!d->dact || all_8p || force_8p) && (large || force_8p) && cst_gemm8p_supported(p, ak, bk, nbatch))
+  } else if (d->dtype == CST_BF16 && !seg && !no_8p && (ak || all_8p || force_8p) && (!d->dact || (dact_8p && !d->resid && !d->aux_out) || all_8p || force_8p) && (large || force_8p) && cst_gemm8p_supported(p, ak, bk, nbatch))
     rc = cst_gemm8p_launch(p, ak, bk, nbatch, s);
   else if (d->dtype == CST_BF16) rc = CST_GEMM_DISPATCH(bf16_t);
   else rc = CST_GEMM_DISPATCH(float);

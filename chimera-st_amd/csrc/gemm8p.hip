@@ -77,11 +77,24 @@ __device__ __forceinline__ u32x4 lds_read_b128(unsigned addr) {
   return v;
 }
 
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read_b128_off(unsigned addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, 0, 0, 0);
 }
 
-template <bool AK, bool BKM>
+// MODE selects the epilogue code compiled into an instantiation (the launcher picks it from the descriptor):
+//   0  everything (fp32 outputs, split-K slabs, row bias, two extra operands, ...)
+//   1  bf16 output through the LDS image, no extra operand: plain / bias / activation / pre-activation output / dropout
+//   2  bf16 output, exactly ONE extra operand (act'(aux_in) or a residual), no pre-activation output
+// The hot Linear shapes are all mode 1 or 2: without the general path's parameters the register allocator spills 20-30 scalars
+// instead of 160, and the operand registers of mode 2 never weigh on the others.
+template <bool AK, bool BKM, int MODE>
 __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -106,8 +119,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
   const int pb = BKM ? 8 * wave + (lane >> 3) : (lane & 15) * 8;  //   inside a half, group 0
   const unsigned step_a = AK ? (unsigned)(BK * 2) : (unsigned)(BK * p.lda * 2);
   const unsigned step_b = BKM ? (unsigned)(BK * 2) : (unsigned)(BK * p.ldb * 2);
-  const bool fast_epi = !p.c_f32 && p.splits == 1 && p.vec_epi && (p.N % 8) == 0 && p.bias_mode != CST_BIAS_ROW &&
-                        (p.bias_mode == CST_BIAS_NONE || p.alpha == 1.0f);
+  constexpr bool EXF = MODE == 2;
+  const bool fast_epi = MODE != 0 || (!p.c_f32 && p.splits == 1 && p.vec_epi && (p.N % 8) == 0 && p.bias_mode != CST_BIAS_ROW &&
+                                (p.bias_mode == CST_BIAS_NONE || p.alpha == 1.0f));
   const bool bias_in_acc = fast_epi && p.bias_mode == CST_BIAS_COL;  // the bias row seeds the accumulators
   char* const bias_lds = smem + 2 * BUFB;                              // 512 B: bias[n0 .. n0 + 256) of the streamed item
 
@@ -402,11 +416,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
     const bool has_next = v < total;
     if (has_next) {
       setup(v);
+      CST_STAMP(5);
       const int Sn = 4 * nt;
       if (0 < Sn) stage(I0{}, I0{}, 0);
       if (1 < Sn) stage(I1{}, I0{}, 0);
       if (2 < Sn) stage(I2{}, I0{}, 0);
       if (3 < Sn) stage(I3{}, I0{}, 0);
+      CST_STAMP(6);
       claim_issue();  // the item after the one set up here; published in the epilogue, read back after that item's K loop
     }
 
@@ -424,9 +440,27 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
       //   loop A (only with an aux_in / residual operand): z, operand -> final value, written back into the image in place;
       //   loop B: image -> [pre-activation output] -> [activation, dropout] -> C.
       constexpr int ERS = 528;
-      const T* exsrc = q.dact ? (const T*)q.aux_in : (const T*)q.resid;
+      const T* exsrc = MODE == 1 ? nullptr : (q.dact ? (const T*)q.aux_in : (const T*)q.resid);
       const int64_t exld = q.dact ? q.ld_aux_in : q.ld_resid;
       const bool both = q.dact && q.resid;
+      // EXF (one extra operand, no pre-activation output): the eight operand vectors of a pass are requested in one burst BEFORE
+      // that pass's image traffic — pass 0's here, pass 1's between pass 0's arithmetic and pass 0's stores — so their latency
+      // hides behind LDS work, and inside a pass the pieces are finished in registers first and stored afterwards (a load is
+      // never waited for with a store of the same pass pending).
+      constexpr bool ex_fast = EXF;
+      u32x4 exq[8];
+      const T* ex_b = nullptr;
+      if (ex_fast) {
+        int64_t colc = e_n0 + (tid & 31) * 8;
+        colc = colc < q.N ? colc : q.N - 8;
+        ex_b = exsrc + e_cofs + colc;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          int64_t row = e_m0 + (tid >> 5) + 16 * it;
+          row = row < q.M ? row : q.M - 1;
+          exq[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ex_b + row * exld));
+        }
+      }
 #pragma unroll
       for (int hm = 0; hm < 2; ++hm) {
         if (hm) __builtin_amdgcn_s_barrier();  // previous pass fully read back
@@ -445,7 +479,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
         wait_lgkm<0>();
         __builtin_amdgcn_s_barrier();
         if (hm == 0 && has_next) claim_land();
-        if (exsrc) {
+        if (exsrc && !ex_fast) {
 #pragma unroll 2
           for (int it = 0; it < 8; ++it) {
             const int vi = tid + NTHREADS * it;
@@ -498,40 +532,108 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
           wait_lgkm<0>();  // loop B re-reads this thread's own slots
         }
         const bool post = !exsrc && (q.act != CST_ACT_NONE || q.drop_thr);
-#pragma unroll 2
-        for (int it = 0; it < 8; ++it) {
-          const int vi = tid + NTHREADS * it;
-          const int rl = vi >> 5, cl = (vi & 31) * 8;
-          const int64_t row = e_m0 + hm * 128 + rl, col = e_n0 + cl;
-          if (row >= q.M || col >= q.N) continue;
-          const u32x4 zraw = lds_read_b128(ebase_off + rl * ERS + cl * 2);
-          wait_lgkm<0>();
-          __builtin_amdgcn_sched_barrier(0);
-          T* cdst = (T*)q.C + e_cofs + row * q.ldc + col;
-          if (!exsrc && q.aux_out) __builtin_nontemporal_store(zraw, reinterpret_cast<u32x4*>((T*)q.aux_out + e_cofs + row * q.ld_aux_out + col));
-          if (!post) {
-            __builtin_nontemporal_store(zraw, reinterpret_cast<u32x4*>(cdst));
+        // loop B.  The eight 16-byte pieces of this thread (rows 16 apart, same columns) are read back with ONE burst of ds_read_b128
+        // (immediate offsets from one address) and stored as they arrive (counted lgkmcnt): a read -> wait -> store chain per piece
+        // exposed one LDS round trip per iteration with only two waves per SIMD to cover it.
+        {
+          constexpr int RSTEP = 16 * ERS;  // byte distance of consecutive pieces in the image
+          const int rl0 = tid >> 5, cl = (tid & 31) * 8;
+          const unsigned a0 = ebase_off + rl0 * ERS + cl * 2;
+          const int64_t col = e_n0 + cl, row0 = e_m0 + hm * 128 + rl0;
+          const bool col_ok = col < q.N;
+          u32x4 zr[8];
+          zr[0] = lds_read_b128_off<0 * RSTEP>(a0); zr[1] = lds_read_b128_off<1 * RSTEP>(a0);
+          zr[2] = lds_read_b128_off<2 * RSTEP>(a0); zr[3] = lds_read_b128_off<3 * RSTEP>(a0);
+          zr[4] = lds_read_b128_off<4 * RSTEP>(a0); zr[5] = lds_read_b128_off<5 * RSTEP>(a0);
+          zr[6] = lds_read_b128_off<6 * RSTEP>(a0); zr[7] = lds_read_b128_off<7 * RSTEP>(a0);
+          T* const cbase = (T*)q.C + e_cofs + row0 * q.ldc + col;
+          T* const xbase = (T*)q.aux_out + e_cofs + row0 * q.ld_aux_out + col;
+          const bool want_aux = !exsrc && q.aux_out;
+          if (ex_fast) {
+            wait_lgkm<0>();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+              const u32x4 zraw = zr[it], exv = exq[it];
+              float x[8];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                x[2 * e] = __uint_as_float(zraw[e] << 16);
+                x[2 * e + 1] = __uint_as_float(zraw[e] & 0xffff0000u);
+              }
+              if (q.act == CST_ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.0f);
+              } else if (q.act == CST_ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = gelu_t<T>(x[e]);
+              }
+              if (q.drop_thr) cst_drop8(x, q.drop_key, (uint64_t)((row0 + 16 * it + q.drop_row0) * q.N + col), q.drop_thr, q.drop_scale);
+              if (q.dact) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  x[2 * e] *= dact_t<T>(__uint_as_float(exv[e] << 16), q.dact);
+                  x[2 * e + 1] *= dact_t<T>(__uint_as_float(exv[e] & 0xffff0000u), q.dact);
+                }
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  x[2 * e] += __uint_as_float(exv[e] << 16);
+                  x[2 * e + 1] += __uint_as_float(exv[e] & 0xffff0000u);
+                }
+              }
+              bf16x8 ob;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) ob[e] = static_cast<__bf16>(x[e]);
+              zr[it] = __builtin_bit_cast(u32x4, ob);
+            }
+            if (hm == 0) {  // pass 1's operand vectors, ahead of pass 0's stores
+#pragma unroll
+              for (int it = 0; it < 8; ++it) {
+                int64_t row = e_m0 + 128 + (tid >> 5) + 16 * it;
+                row = row < q.M ? row : q.M - 1;
+                exq[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ex_b + row * exld));
+              }
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+              if (col_ok && row0 + 16 * it < q.M)
+                __builtin_nontemporal_store(zr[it], reinterpret_cast<u32x4*>(cbase + (int64_t)(16 * it) * q.ldc));
             continue;
           }
-          float x[8];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            x[2 * e] = __uint_as_float(zraw[e] << 16);
-            x[2 * e + 1] = __uint_as_float(zraw[e] & 0xffff0000u);
-          }
-          if (q.act == CST_ACT_RELU) {
+          for (int it = 0; it < 8; ++it) {
+            if (it == 0) wait_lgkm<7>(); else if (it == 1) wait_lgkm<6>(); else if (it == 2) wait_lgkm<5>(); else if (it == 3) wait_lgkm<4>();
+            else if (it == 4) wait_lgkm<3>(); else if (it == 5) wait_lgkm<2>(); else if (it == 6) wait_lgkm<1>(); else wait_lgkm<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            const u32x4 zraw = zr[it];
+            if (!(col_ok && row0 + 16 * it < q.M)) continue;
+            T* cdst = cbase + (int64_t)(16 * it) * q.ldc;
+            if (want_aux) __builtin_nontemporal_store(zraw, reinterpret_cast<u32x4*>(xbase + (int64_t)(16 * it) * q.ld_aux_out));
+            if (!post) {
+              __builtin_nontemporal_store(zraw, reinterpret_cast<u32x4*>(cdst));
+              continue;
+            }
+            float x[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.0f);
-          } else if (q.act == CST_ACT_GELU) {
+            for (int e = 0; e < 4; ++e) {
+              x[2 * e] = __uint_as_float(zraw[e] << 16);
+              x[2 * e + 1] = __uint_as_float(zraw[e] & 0xffff0000u);
+            }
+            if (q.act == CST_ACT_RELU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = gelu_t<T>(x[e]);
-          }
-          if (q.drop_thr) cst_drop8(x, q.drop_key, (uint64_t)((row + q.drop_row0) * q.N + col), q.drop_thr, q.drop_scale);
-          {
-            bf16x8 ob;
+              for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.0f);
+            } else if (q.act == CST_ACT_GELU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ob[e] = static_cast<__bf16>(x[e]);
-            __builtin_nontemporal_store(__builtin_bit_cast(u32x4, ob), reinterpret_cast<u32x4*>(cdst));
+              for (int e = 0; e < 8; ++e) x[e] = gelu_t<T>(x[e]);
+            }
+            if (q.drop_thr) cst_drop8(x, q.drop_key, (uint64_t)((row0 + 16 * it + q.drop_row0) * q.N + col), q.drop_thr, q.drop_scale);
+            {
+              bf16x8 ob;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) ob[e] = static_cast<__bf16>(x[e]);
+              __builtin_nontemporal_store(__builtin_bit_cast(u32x4, ob), reinterpret_cast<u32x4*>(cdst));
+            }
           }
         }
       }
@@ -629,11 +731,11 @@ int* sched_slot() {
   return r + 16 * (next[dev].fetch_add(1, std::memory_order_relaxed) % SLOTS);
 }
 
-template <bool AK, bool BKM>
+template <bool AK, bool BKM, int MODE>
 int launch8p(GemmParams p, int64_t nbatch, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_kernel<AK, BKM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_kernel<AK, BKM, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   p.tiles_m = (int)cst_ceil_div(p.M, BM);
@@ -644,6 +746,7 @@ int launch8p(GemmParams p, int64_t nbatch, hipStream_t s) {
     int dev = 0, n = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    if (const char* e = getenv("CST_GEMM8P_CUS")) n = atoi(e);  // experiments: persistent workgroups on a part of the chip only
     return n > 0 ? n : 256;
   }();
   dim3 grid((unsigned)(total < ncu ? total : ncu), 1, 1);
@@ -652,7 +755,7 @@ int launch8p(GemmParams p, int64_t nbatch, hipStream_t s) {
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   const bool capturing = hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
   p.sched = (!static_walk && !capturing && total > ncu && grid.x % 8 == 0) ? sched_slot() : nullptr;
-  hipLaunchKernelGGL((gemm8p_kernel<AK, BKM>), grid, dim3(NTHREADS), LDS_BYTES + 1024 + 64, s, p);
+  hipLaunchKernelGGL((gemm8p_kernel<AK, BKM, MODE>), grid, dim3(NTHREADS), LDS_BYTES + 1024 + 64, s, p);
   return cst_check_launch("cst_gemm (8-phase)");
 }
 
@@ -669,6 +772,16 @@ bool cst_gemm8p_supported(const cstg::GemmParams& p, bool ak, bool bk, int64_t n
 }
 
 int cst_gemm8p_launch(cstg::GemmParams p, bool ak, bool bk, int64_t nbatch, hipStream_t s) {
-  if (ak) return bk ? launch8p<true, true>(p, nbatch, s) : launch8p<true, false>(p, nbatch, s);
-  return bk ? launch8p<false, true>(p, nbatch, s) : launch8p<false, false>(p, nbatch, s);
+  // the one-extra-operand epilogue instantiation (see EXF): same conditions as the kernel's bf16 image path + exactly one operand
+  const bool fast = !p.c_f32 && p.splits == 1 && p.vec_epi && (p.N % 8) == 0 && p.bias_mode != CST_BIAS_ROW &&
+                    (p.bias_mode == CST_BIAS_NONE || p.alpha == 1.0f);
+  const bool exf = fast && !p.aux_out && ((p.dact != 0) != (p.resid != nullptr)) && (!p.dact || p.aux_in);
+  const bool plainf = fast && !p.dact && !p.resid;
+#define CST_8P_MODE(MODE)                                                                                          \
+  (ak ? (bk ? launch8p<true, true, MODE>(p, nbatch, s) : launch8p<true, false, MODE>(p, nbatch, s))              \
+      : (bk ? launch8p<false, true, MODE>(p, nbatch, s) : launch8p<false, false, MODE>(p, nbatch, s)))
+  if (exf) return CST_8P_MODE(2);
+  if (plainf) return CST_8P_MODE(1);
+  return CST_8P_MODE(0);
+#undef CST_8P_MODE
 }

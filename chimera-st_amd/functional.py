@@ -434,8 +434,9 @@ class PackedRows:
     """Where the sequences of a packed [rows, C] tensor live: offsets int32 [B+1] (device), kv_len int32 [B] (device: real frames per
     sequence = its keys), rows (total), longest (longest sequence), B, T (the padded shape it came from)."""
 
-    def __init__(self, offsets, kv_len, rows, longest, B, T):
+    def __init__(self, offsets, kv_len, rows, longest, B, T, host_lens=None):
         self.offsets, self.kv_len, self.rows, self.longest, self.B, self.T = offsets, kv_len, rows, longest, B, T
+        self.host_lens = host_lens  # real frames per sequence as host integers (read with the plan's one host transfer)
 
 
 def plan_packed_rows(padding_mask, margin):
@@ -447,8 +448,20 @@ def plan_packed_rows(padding_mask, margin):
     n = torch.clamp(lens + (margin + 1), max=T)
     off = torch.zeros(B + 1, dtype=torch.int32, device=padding_mask.device)
     off[1:] = torch.cumsum(n, 0)
-    host = torch.stack((off[-1], n.max())).tolist()  # the step's packing plan: total rows, longest sequence
-    return PackedRows(off.contiguous(), lens.contiguous(), int(host[0]), int(host[1]), B, T)
+    host = torch.cat((off[-1:], n.max().view(1), lens)).tolist()  # the step's packing plan: total rows, longest sequence, lengths
+    return PackedRows(off.contiguous(), lens.contiguous(), int(host[0]), int(host[1]), B, T, [int(v) for v in host[2:]])
+
+
+def plan_from_lengths(lens_dev, host_lens, T):
+    """The plan of a later stage whose sequence lengths follow from an earlier plan's by host arithmetic (the subsampled frames
+    behind wav2vec2): device offsets by device ops, the allocation sizes from the host copies — no further host read.  Sequence b
+    keeps exactly its lens[b] real rows."""
+    B = lens_dev.numel()
+    n = torch.clamp(lens_dev.to(torch.int32), max=T)
+    off = torch.zeros(B + 1, dtype=torch.int32, device=lens_dev.device)
+    off[1:] = torch.cumsum(n, 0)
+    hl = [min(int(v), T) for v in host_lens]
+    return PackedRows(off.contiguous(), n.contiguous(), sum(hl), max(hl), B, T, hl)
 
 
 class _PackRowsFn(torch.autograd.Function):
@@ -471,23 +484,24 @@ class _UnpackRowsFn(torch.autograd.Function):
     backward = pack with the gradients of those copies summed into that row, in index order."""
 
     @staticmethod
-    def forward(ctx, y, seq):
-        ctx.seq = seq
+    def forward(ctx, y, seq, broadcast):
+        ctx.seq, ctx.broadcast = seq, broadcast
         y2 = y.reshape(seq.rows, y.shape[-1])
-        return K.rows_unpack(y2 if y2.is_contiguous() else y2.contiguous(), seq.offsets, seq.B, seq.T, tail_broadcast=True)
+        return K.rows_unpack(y2 if y2.is_contiguous() else y2.contiguous(), seq.offsets, seq.B, seq.T, tail_broadcast=broadcast)
 
     @staticmethod
     def backward(ctx, dx):
         s = ctx.seq
-        return K.rows_pack(dx if dx.is_contiguous() else dx.contiguous(), s.offsets, s.rows, tail_sum=True).unsqueeze(0), None
+        return K.rows_pack(dx if dx.is_contiguous() else dx.contiguous(), s.offsets, s.rows, tail_sum=ctx.broadcast).unsqueeze(0), None, None
 
 
 def pack_rows(x, seq):
     return _PackRowsFn.apply(x, seq)
 
 
-def unpack_rows(y, seq):
-    return _UnpackRowsFn.apply(y, seq)
+def unpack_rows(y, seq, broadcast=True):
+    """broadcast=False: the rows behind a sequence's kept ones come back as zeros (nobody reads them) and their gradient is dropped."""
+    return _UnpackRowsFn.apply(y, seq, bool(broadcast))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -547,7 +561,7 @@ class _Conv1dCLFn(torch.autograd.Function):
         else:
             fwd_len = nz_out if bias is None else None
         ctx.nz_out = nz_out  # int32 [B]: the incoming gradient's rows t >= nz_out[b] are exactly zero (frames past the utterance's end)
-        ctx.nz_in = nz_in    # int32 [B]: the same bound for this layer's input rows ((nz_out - 1) * stride + k): dx is zero from there on
+        ctx.nz_in = nz_in    # int32 [stride, B]: live rows of each residue class of dx (cst_conv_row_limits); dx is zero behind them
         B, Lin, Cin = x.shape
         Cout = w_cl.shape[0]
         if pad:
@@ -616,9 +630,7 @@ class _Conv1dCLFn(torch.autograd.Function):
                     # B_r[ci][q*Cout + co] = W[co][ci][r + s*(n-1-q)]   (window position q <-> dz[u - (n-1) + q])
                     wr = w3[:, [taps[n - 1 - q] for q in range(n)], :].permute(2, 1, 0).reshape(Cin, n * Cout).contiguous()
                     # rows u with stride * u + r >= nz_in[b] read only dz rows that are exactly zero: their K loop is skipped
-                    ml = None
-                    if ctx.nz_in is not None:
-                        ml = torch.clamp((ctx.nz_in - r + stride - 1) // stride, min=0).to(torch.int32).contiguous()
+                    ml = ctx.nz_in[r] if ctx.nz_in is not None else None
                     K.gemm(dzp, wr, dx_full, U, Cin, n * Cout, a_kmajor=1, b_kmajor=1, lda=Cout, ldb=n * Cout, ldc=stride * Cin,
                            batch0=B, sa=((Lout + 2) * Cout, 0), sc=(rows * Cin, 0), a_off=(2 - n) * Cout,
                            c_off=(Cin if dx_padded else 0) + r * Cin, dact=L.ACT_GELU if prev_z is not None else L.ACT_NONE,

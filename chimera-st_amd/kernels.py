@@ -378,6 +378,21 @@ def dropout(x, p, key):
     return y
 
 
+def conv_row_limits(nz_last, conv_spec, samples):
+    """int32 [L, 1 + smax, B] live-frame limits of every conv layer from the real frame counts behind the last one (include/cst.h:
+    cst_conv_row_limits) — one launch instead of ~15 tiny torch kernels per layer."""
+    import ctypes
+    Lc = len(conv_spec)
+    ks = (ctypes.c_int32 * Lc)(*[int(c[1]) for c in conv_spec])
+    st = (ctypes.c_int32 * Lc)(*[int(c[2]) for c in conv_spec])
+    smax = max([int(c[2]) for c in conv_spec[1:]] or [1])
+    B = nz_last.numel()
+    assert nz_last.dtype == torch.int32 and nz_last.is_contiguous()
+    out = torch.empty(Lc, 1 + smax, B, dtype=torch.int32, device=nz_last.device)
+    L.check(L.load().cst_conv_row_limits(L.ptr(nz_last), ks, st, Lc, int(samples), L.ptr(out), B, smax, L.stream_ptr()), "cst_conv_row_limits")
+    return out
+
+
 def dropout_scale(x, alpha, p, key):
     """y = alpha * x * keep(key, idx) / (1 - p); x contiguous, numel % 8 == 0."""
     assert x.is_contiguous()

@@ -429,7 +429,7 @@ class TransformerEncoderLayer(nn.Module):
             return 0.0, 0.0
         return float(self.dropout_module.p), float(self.activation_dropout_module.p)
 
-    def forward(self, x, encoder_padding_mask, attn_mask: Optional[torch.Tensor] = None, kv=None):
+    def forward(self, x, encoder_padding_mask, attn_mask: Optional[torch.Tensor] = None, kv=None, seq=None):
         """x: (T,B,C).  `kv` (extension used by the memory module): separate key/value rows (Tk,B,C) that go through
         the same self_attn_layer_norm, i.e. exactly the rows of cat(h_enc, memory) the masked reference attends to."""
         residual = x
@@ -440,8 +440,9 @@ class TransformerEncoderLayer(nn.Module):
             h, hk = x, (kv if kv is not None else x)
         p_drop, p_act = self._drop_ps()
         if kv is None:
-            x, _ = self.self_attn(h, h, h, key_padding_mask=encoder_padding_mask, attn_mask=attn_mask,
-                                  resid=residual, out_dropout_p=p_drop)  # residual + dropout(attn)
+            # seq: x holds packed rows [rows, 1, C] (functional.PackedRows); every sequence attends to its own rows only
+            x, _ = self.self_attn(h, h, h, key_padding_mask=None if seq is not None else encoder_padding_mask, attn_mask=attn_mask,
+                                  resid=residual, out_dropout_p=p_drop, seq=seq)  # residual + dropout(attn)
         else:
             x, _ = self._cross(h, hk, encoder_padding_mask, residual, p_drop)
         if not self.normalize_before:

@@ -4,6 +4,7 @@ This is BASELINE config 2/3 ("s2t_transformer_m dims + wav2vec2 frontend")."""
 import argparse
 import logging
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -107,7 +108,20 @@ class S2T_W2V2_TransformerEncoder(FairseqEncoder):
         output_length = (1 - padding_mask.int()).sum(dim=1)
         return w2v_feature, padding_mask, output_length
 
+    def _packing_plan(self, input_lengths, encoder_padding_mask):
+        w2v_plan = getattr(self.wav2vec_model, "last_plan", None)
+        if w2v_plan is None or w2v_plan.host_lens is None or os.environ.get("CST_NO_PACK") or os.environ.get("CST_NO_PACK_S2T"):
+            return None
+        hl = list(w2v_plan.host_lens)
+        for _ in range(self.subsample.n_layers):  # Conv1dSubsampler.get_out_seq_lens_tensor on host integers
+            hl = [int(math.floor((v - 1) / 2 + 1)) for v in hl]
+        T = encoder_padding_mask.size(1)
+        if sum(min(v, T) for v in hl) >= len(hl) * T:
+            return None  # nothing to drop
+        return CF.plan_from_lengths(input_lengths, hl, T)
+
     def forward(self, src_tokens, src_lengths, **extra_args):
+        self.wav2vec_model.last_plan = None
         w2v_feature, _, input_lengths = self._get_w2v_feature(src_tokens, src_lengths)
         x, input_lengths = self.subsample(w2v_feature, input_lengths)
         encoder_padding_mask = lengths_to_padding_mask(input_lengths, max_len=x.size(0))
@@ -116,8 +130,20 @@ class S2T_W2V2_TransformerEncoder(FairseqEncoder):
                                                   pos_table=self.embed_positions.table(encoder_padding_mask.size(1), x.device),
                                                   scale=self.embed_scale, pad_idx=self.padding_idx,
                                                   dropout_p=self.dropout_module.p if self.training else 0.0))
+        # padding-free layer stack: a padded frame is read by nobody (every attention masks it as a key, the decoder included) and
+        # its gradient is exactly zero, so the layers run on the real frames only and the padded rows of the output are zeros.
+        # The plan costs no host read of its own: the frame counts follow from the wav2vec2 plan's by the subsampler's formula.
+        seq = self._packing_plan(input_lengths, encoder_padding_mask)
+        if seq is not None:
+            x = to_time_major_view(CF.pack_rows(to_batch_major(x), seq))
         for layer in self.transformer_layers:
-            x = layer(x, encoder_padding_mask)
+            x = layer(x, encoder_padding_mask, seq=seq)
+        if seq is not None:
+            if self.layer_norm is not None:
+                x = self.layer_norm(x)
+            x = to_time_major_view(CF.unpack_rows(to_batch_major(x), seq, broadcast=False))
+            return EncoderOut(encoder_out=x, encoder_padding_mask=encoder_padding_mask, encoder_embedding=None,
+                              encoder_states=None, src_tokens=None, src_lengths=None)
         # (the reference drops an all-False mask here, w2v2_transformer.py:377-378: `.any()` is a host sync in the middle of the
         #  forward pass — the queue drains and the decoder's small kernels are then launch-bound.  An all-False mask gives the
         #  same results in the fused attention kernels, so it is kept.)

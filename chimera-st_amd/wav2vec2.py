@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as CF
+from . import kernels as K
 from .distributed import notify_unused_parameters
 from .modules import LayerNorm, Linear, MultiheadAttention, to_batch_major, to_time_major_view
 from .registry import register_model, register_model_architecture
@@ -57,18 +58,13 @@ class ConvFeatureExtractionModel(nn.Module):
         frame t of layer i+1 reads rows [s t, s t + k) of layer i, so layer i's gradient is zero from (nz - 1) s + k on — and the
         weight-gradient GEMMs of each layer stop their reduction over frames there (cst_gemm_desc.k_len): exact."""
         nz = [None] * len(self.conv_spec)
+        res = [None] * len(self.conv_spec)
         if nz_last is not None:
-            cur, lens = nz_last, []
-            s_ = x.shape[1]
-            for (_, k_, st_) in self.conv_spec:
-                s_ = (s_ - k_) // st_ + 1
-                lens.append(s_)
-            for i in range(len(self.conv_spec) - 1, 0, -1):
-                cur = torch.clamp(cur, max=lens[i]).to(torch.int32).contiguous()
-                nz[i] = cur
-                _, k_, st_ = self.conv_spec[i]
-                cur = torch.where(cur > 0, (cur - 1) * st_ + k_, torch.zeros_like(cur))
-            nz[0] = torch.clamp(cur, max=lens[0]).to(torch.int32).contiguous()
+            # nz[i][b]: frames of layer i that anything reads; res[i][r][b]: live rows of residue class r of layer i's input gradient
+            lim = K.conv_row_limits(nz_last.to(torch.int32).contiguous(), self.conv_spec, x.shape[1])
+            for i, (_, _, st_) in enumerate(self.conv_spec):
+                nz[i] = lim[i, 0]
+                res[i] = lim[i, 1:1 + st_]
         l0 = self.conv_layers[0]
         dim, k, stride = self.conv_spec[0]
         y = CF.conv0_gn_gelu(x, getattr(l0, "0").weight, getattr(l0, "2").weight, getattr(l0, "2").bias, stride)
@@ -80,7 +76,7 @@ class ConvFeatureExtractionModel(nn.Module):
             # fold GELU' of layer i-1 into layer i's col2im pass; layer i then receives d/dz directly
             # rows t >= nz[i][b] of layer i are frames nobody reads (the stack's output is zeroed behind the utterance's end,
             # wav2vec2.py:820-821) and whose gradient is exactly zero: their GEMM tiles skip the K loop (cst_gemm_desc.m_len / k_len)
-            y, z = CF.conv1d_cl(y, w, None, stride, pad=0, act="gelu", prev_z=z, grad_is_dz=(i < n - 1), nz_out=nz[i], nz_in=nz[i - 1])
+            y, z = CF.conv1d_cl(y, w, None, stride, pad=0, act="gelu", prev_z=z, grad_is_dz=(i < n - 1), nz_out=nz[i], nz_in=res[i])
         return y
 
     def output_length(self, s):
@@ -295,6 +291,7 @@ class Wav2Vec2Model(nn.Module):
             if extra > 0:
                 pm = pm[:, :-extra]
             plan = CF.plan_packed_rows(pm.view(pm.size(0), t1, -1).all(-1), self.encoder.packing_margin())
+        self.last_plan = plan  # (the caller's own layer stack derives its packing plan from this one's host lengths)
         nz_last = None
         if padding_mask is not None:
             # the frame-level padding mask of :543-548, known before the CNN runs: frames past the last real one get a zero gradient

@@ -212,6 +212,18 @@ int cst_attn_bwd(const cst_attn_desc* d, cst_stream stream);
  *   mean,rstd fp32 [B,C];  gram fp32 [B, k*k + k] (per-utterance lag moments, saved for backward);
  *   L = (S-k)/stride + 1;  k <= 16;  C % 8 == 0.
  * ------------------------------------------------------------------------------------------ */
+/* Live-frame limits of the conv feature extractor (wav2vec2.py:685-763) for one batch, all layers in ONE launch: which frames of every
+ * layer's output anything reads, from the count of real frames behind the LAST layer (frames past an utterance's end are zeroed
+ * behind the stack, wav2vec2.py:820-821, and carry exactly zero gradient).  They feed cst_gemm_desc.m_len / k_len of the conv GEMMs.
+ *   nz_last int32 [B]: real frames per utterance behind layer L-1;  k, stride: int32 [L] kernel widths / strides;  S: samples.
+ *   out int32 [L][1 + smax][B], smax = max stride of layers 1..L-1:
+ *     out[i][0][b]     = nz_i[b]: layer i's frames t >= nz_i[b] are unread; nz_{i-1} = (nz_i - 1) stride_i + k_i (0 if nz_i = 0),
+ *                        each clamped to the layer's frame count
+ *     out[i][1 + r][b] = max(0, ceil((nz_{i-1}[b] - r) / stride_i)) for i >= 1, r < stride_i: the live rows of residue class r of
+ *                        layer i's INPUT gradient (the windowed dX GEMMs of functional.conv1d_cl)
+ * L <= 8, strides <= 8. */
+int cst_conv_row_limits(const int32_t* nz_last, const int32_t* k, const int32_t* stride, int L, int64_t S, int32_t* out, int64_t B,
+                        int smax, cst_stream stream);
 /* workspace: cst_conv0_fwd_workspace() bytes — per-block partial moments, added up in a fixed order (no atomics: the statistics,
  * and with them the whole forward pass, are bit-reproducible run to run). */
 int64_t cst_conv0_fwd_workspace(int64_t B, int64_t S, int k, int stride);

@@ -24,8 +24,19 @@ N, Kd = int(os.environ.get("N", 3072)), int(os.environ.get("K", 768))
 A = (torch.randn(256, Kd, device="cuda") * 0.5).to(dt)
 B = (torch.randn(N, Kd, device="cuda") * 0.05).to(dt)
 tiles_n = (N + 255) // 256
+EPI = int(os.environ.get("EPI", 0))  # 1: bias + GELU + pre-activation output (the fc1 forward epilogue: two stored images per tile)
+L = importlib.import_module("chimera-st_amd.lib")
+bias = torch.zeros(N, device="cuda", dtype=dt)
 for nb in (1, 2, 4, 8, 11, 16, 21, 22, 32, 43, 64, 86, 128, 188, 256, 376, 512):
     C = torch.empty(nb * 256, N, dtype=dt, device="cuda")
-    ms = timeit(lambda: K.gemm(A, B, C, 256, N, Kd, a_kmajor=1, b_kmajor=1, lda=Kd, ldb=Kd, ldc=N, batch0=nb, sa=(0, 0), sb=(0, 0), sc=(256 * N, 0), split_k=1))
+    if EPI:
+        Z = torch.empty_like(C)
+        C2, Z2 = C.view(-1, N), Z.view(-1, N)
+        # aux_out has no batch stride of its own: run the epilogue variant as ONE problem of nb * 256 rows over a row-repeating A
+        A2 = A.repeat(nb, 1)
+        ms = timeit(lambda: K.gemm(A2, B, C2, 256 * nb, N, Kd, a_kmajor=1, b_kmajor=1, lda=Kd, ldb=Kd, ldc=N, bias=bias, act=L.ACT_GELU,
+                                   aux_out=Z2, ld_aux_out=N, split_k=1))
+    else:
+        ms = timeit(lambda: K.gemm(A, B, C, 256, N, Kd, a_kmajor=1, b_kmajor=1, lda=Kd, ldb=Kd, ldc=N, batch0=nb, sa=(0, 0), sb=(0, 0), sc=(256 * N, 0), split_k=1))
     tiles = nb * tiles_n
     print("batches %4d tiles %5d rounds %6.2f : %.4f ms  %.0f TF/s  (%.2f us per round)" % (nb, tiles, tiles / 256.0, ms, 2.0 * 256 * nb * N * Kd / ms / 1e9, ms * 1e3 / max(tiles / 256.0, 1.0)))

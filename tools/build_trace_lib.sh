@@ -3,7 +3,9 @@
 set -e
 cd "$(dirname "$0")/../chimera-st_amd/csrc"
 mkdir -p ../../tools/trace
-for f in cst_core gemm gemm8p attention layernorm conv0 elementwise loss_optim; do
+rm -f ../../tools/trace/*.o
+for src in *.hip; do
+  f=${src%.hip}
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DCST_TRACE -Wno-unused-function -I../../include -c $f.hip -o ../../tools/trace/$f.o &
 done
 wait

@@ -37,5 +37,8 @@ names = ["setup+prologueB+wait", "K loop", "next setup+DMA issue", "epilogue"]
 for k in range(4):
     dts = (t[:, :, k + 1] - t[:, :, k])[ok]
     print("%-24s median %8.0f  mean %8.0f cycles" % (names[k], np.median(dts), dts.mean()))
+ok2 = ok & (t[:, :, 5] > 0)
+print("  of which: claim read-back + next item setup %8.0f, 4 half-tile DMA issues %8.0f, claim issue %8.0f (medians)" % (
+    np.median((t[:, :, 5] - t[:, :, 2])[ok2]), np.median((t[:, :, 6] - t[:, :, 5])[ok2]), np.median((t[:, :, 3] - t[:, :, 6])[ok2])))
 tot = (t[:, :, 4] - t[:, :, 0])[ok]
 print("item total median %.0f cycles over %d items; item-to-item %s" % (np.median(tot), ok.sum(), np.median((t[:, 1:, 0] - t[:, :-1, 0])[ok[:, 1:]])))
