@@ -695,9 +695,186 @@ int to_params(const cst_beam_desc* d, BeamP& p) {
   return CST_OK;
 }
 
+// ---- decode-step Linear (include/cst.h: cst_dec_linear) ---------------------------------------------------------------------------
+// y[M, N] = act(x[M, K] W[N, K]^T + b) (+ resid) for the few hundred hypothesis rows of a beam-search step.  The step is bound by
+// streaming each weight matrix (2-8 MB) from HBM ONCE; that takes every byte of it requested within one memory round trip, so the
+// matrix is cut into many small workgroups that keep nothing but loads in flight:
+//   workgroup = NT x 16 weight rows (output columns) x TT x 16 hypothesis rows, 4 waves; wave w owns K quarter w for the whole tile,
+//   operands go global -> registers (no LDS staging: each wave reads its 16-byte k chunks of W rows and x rows straight into
+//   MFMA fragments; x comes from L2, it is shared by every workgroup), v_mfma_f32_16x16x32_bf16 with D = W-frag x x-frag, so a lane
+//   ends up with 4 consecutive output columns of one hypothesis row; the weights of the next UN k-steps are requested before the
+//   MFMAs of the current ones.  The four waves' partial sums are added in wave order through LDS (deterministic), then bias /
+//   activation / residual and one 8-byte store per lane and tile.
+// LN (fused LayerNorm of the rows of x, models/transformer_layer.py:346-349 / :369-372 / :403-406 in front of the projection):
+//   LN(x) W^T + b = rstd_m (x Wg^T - mean_m sg) + sb   with Wg = W * gamma (columns scaled, rounded to bf16 once when the engine packs
+//   its weights), sg[n] = sum_k Wg[n,k], sb[n] = sum_k W[n,k] beta[k] + b[n] (fp32).  The kernel multiplies the RAW rows by Wg and
+//   gathers sum(x), sum(x^2) of every row from the fragments it loads anyway (each workgroup sees whole rows), so the LayerNorm
+//   launch and its activation round trip disappear; W is then Wg, `bias` is unused, ln_sg / ln_sb are the two vectors.
+template <int NT, int TT, int UN, bool LN>
+__global__ __launch_bounds__(256) void dec_linear_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W, const bf16_t* __restrict__ bias,
+                                                         const bf16_t* resid, bf16_t* y, int M, int N, int K, int64_t ldx, int64_t ldr,
+                                                         int64_t ldy, int act, const int32_t* stepp, int max_len, const float* ln_sg,
+                                                         const float* ln_sb, float ln_eps) {
+  if (stepp && *stepp > max_len) return;
+  using f32x4v = __attribute__((ext_vector_type(4))) float;
+  __shared__ float red[4][NT * TT][64][4];
+  __shared__ float stat[LN ? 4 : 1][TT][16][2];
+  float s1[TT], s2[TT];
+#pragma unroll
+  for (int i = 0; i < TT; ++i) s1[i] = s2[i] = 0.0f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, c = lane >> 4;
+  const int n0 = blockIdx.x * (16 * NT), t0 = blockIdx.y * (16 * TT);
+  const int kq = K >> 2;
+  const bf16_t* wp[NT];
+  const bf16_t* xp[TT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    int n = n0 + 16 * j + r;
+    n = n < N ? n : N - 1;
+    wp[j] = W + (int64_t)n * K + wave * kq + c * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < TT; ++i) {
+    int t = t0 + 16 * i + r;
+    t = t < M ? t : M - 1;
+    xp[i] = x + (int64_t)t * ldx + wave * kq + c * 8;
+  }
+  f32x4v acc[NT][TT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int i = 0; i < TT; ++i) acc[j][i] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+  bf16x8 wv[UN][NT], wn[UN][NT], xv[UN][TT];
+#pragma unroll
+  for (int u = 0; u < UN; ++u)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wn[u][j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[j] + 32 * u));
+  for (int k = 0; k < kq; k += 32 * UN) {
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) wv[u][j] = wn[u][j];
+#pragma unroll
+      for (int i = 0; i < TT; ++i) xv[u][i] = *reinterpret_cast<const bf16x8*>(xp[i] + k + 32 * u);
+    }
+    if (k + 32 * UN < kq) {
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wn[u][j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[j] + k + 32 * UN + 32 * u));
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < TT; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[u][j], xv[u][i], acc[j][i], 0, 0, 0);
+    if (LN) {
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+#pragma unroll
+        for (int i = 0; i < TT; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float f = static_cast<float>(xv[u][i][e]);
+            s1[i] += f;
+            s2[i] = fmaf(f, f, s2[i]);
+          }
+    }
+  }
+  if (LN) {  // row sums: over the four k-chunk lane groups of this wave, then (below) over the four waves' K quarters, in a fixed order
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+      s1[i] += __shfl_xor(s1[i], 16, 64); s2[i] += __shfl_xor(s2[i], 16, 64);
+      s1[i] += __shfl_xor(s1[i], 32, 64); s2[i] += __shfl_xor(s2[i], 32, 64);
+      if (c == 0) { stat[wave][i][r][0] = s1[i]; stat[wave][i][r][1] = s2[i]; }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int i = 0; i < TT; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[wave][j * TT + i][lane][e] = acc[j][i][e];
+  __syncthreads();
+  for (int tile = wave; tile < NT * TT; tile += 4) {
+    const int j = tile / TT, i = tile % TT;
+    const int n = n0 + 16 * j + 4 * c, t = t0 + 16 * i + r;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = ((red[0][tile][lane][e] + red[1][tile][lane][e]) + red[2][tile][lane][e]) + red[3][tile][lane][e];
+    if (t >= M || n >= N) continue;
+    float mean = 0.0f, rstd = 1.0f;
+    if (LN) {
+      const float a = ((stat[0][i][r][0] + stat[1][i][r][0]) + stat[2][i][r][0]) + stat[3][i][r][0];
+      const float b2 = ((stat[0][i][r][1] + stat[1][i][r][1]) + stat[2][i][r][1]) + stat[3][i][r][1];
+      mean = a / (float)K;
+      const float var = fmaxf(b2 / (float)K - mean * mean, 0.0f);
+      rstd = rsqrtf(var + ln_eps);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (n + e < N) {
+        float o = LN ? fmaf(rstd, v[e] - mean * ln_sg[n + e], ln_sb[n + e]) : v[e] + (bias ? DT<bf16_t>::ld(bias + n + e) : 0.0f);
+        o = act_t<bf16_t>(o, act);
+        if (resid) o += DT<bf16_t>::ld(resid + (int64_t)t * ldr + n + e);
+        v[e] = o;
+      }
+    }
+    bf16_t* dst = y + (int64_t)t * ldy + n;
+    if (n + 4 <= N && ((ldy | n) & 3) == 0) {
+      typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+      bf16x4_t pk;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pk[e] = static_cast<__bf16>(v[e]);
+      *reinterpret_cast<bf16x4_t*>(dst) = pk;
+    } else {
+      for (int e = 0; e < 4 && n + e < N; ++e) DT<bf16_t>::st(dst + e, v[e]);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
+static int dec_linear_impl(const void* x, const void* W, const void* bias, const void* resid, void* y, int64_t M, int64_t N, int64_t K,
+                           int64_t ldx, int64_t ld_resid, int64_t ldy, int act, const int32_t* step, int64_t max_len, int dtype,
+                           const float* ln_sg, const float* ln_sb, float ln_eps, cst_stream stream) {
+  CST_REQUIRE(x && W && y && M > 0 && N > 0 && K > 0, "cst_dec_linear: bad args");
+  CST_REQUIRE(dtype == CST_BF16, "cst_dec_linear: bf16 only (fp32 problems go through cst_gemm)");
+  CST_REQUIRE(K % 512 == 0 && ldx % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)W % 16) == 0, "cst_dec_linear: K %% 512 == 0 and 16-byte aligned rows required (K=%lld)", (long long)K);
+  CST_REQUIRE(M <= 4096, "cst_dec_linear: a decode-step kernel (M=%lld rows)", (long long)M);
+  hipStream_t s = (hipStream_t)stream;
+  CstProfScope prof(CST_K_GEMM, s, 2.0 * M * N * K, 2.0 * ((double)N * K + (double)M * K + (double)M * N));
+  const int ty = (int)cst_ceil_div(M, 80);
+  const int64_t wg1 = cst_ceil_div(N, 16) * ty;
+  const bool ln = ln_sg != nullptr;
+  // enough workgroups to have every CU pulling weights, few enough that the shared x rows are not re-read from L2 more than needed
+#define CST_DL(NTv, UNv, LNv)                                                                                                       \
+  hipLaunchKernelGGL((dec_linear_kernel<NTv, 5, UNv, LNv>), dim3((unsigned)cst_ceil_div(N, 16 * NTv), (unsigned)ty), dim3(256), 0, s, \
+                     (const bf16_t*)x, (const bf16_t*)W, (const bf16_t*)bias, (const bf16_t*)resid, (bf16_t*)y, (int)M, (int)N, (int)K, ldx, \
+                     ld_resid, ldy, act, step, (int)max_len, ln_sg, ln_sb, ln_eps)
+  if (wg1 <= 320) { if (ln) CST_DL(1, 4, true); else CST_DL(1, 4, false); }
+  else if (wg1 <= 1024) { if (ln) CST_DL(2, 4, true); else CST_DL(2, 4, false); }
+  else { if (ln) CST_DL(4, 2, true); else CST_DL(4, 2, false); }
+#undef CST_DL
+  return cst_check_launch("cst_dec_linear");
+}
+
+int cst_dec_linear(const void* x, const void* W, const void* bias, const void* resid, void* y, int64_t M, int64_t N, int64_t K,
+                   int64_t ldx, int64_t ld_resid, int64_t ldy, int act, const int32_t* step, int64_t max_len, int dtype,
+                   cst_stream stream) {
+  return dec_linear_impl(x, W, bias, resid, y, M, N, K, ldx, ld_resid, ldy, act, step, max_len, dtype, nullptr, nullptr, 0.0f, stream);
+}
+
+int cst_dec_ln_linear(const void* x, const void* Wg, const float* sg, const float* sb, float eps, const void* resid, void* y, int64_t M,
+                      int64_t N, int64_t K, int64_t ldx, int64_t ld_resid, int64_t ldy, int act, const int32_t* step, int64_t max_len,
+                      int dtype, cst_stream stream) {
+  CST_REQUIRE(sg && sb && eps > 0.0f, "cst_dec_ln_linear: the folded LayerNorm vectors are required");
+  return dec_linear_impl(x, Wg, nullptr, resid, y, M, N, K, ldx, ld_resid, ldy, act, step, max_len, dtype, sg, sb, eps, stream);
+}
+
 
 int cst_beam_init(const cst_beam_desc* d, cst_stream stream) {
   BeamP p;

@@ -224,7 +224,17 @@ __global__ __launch_bounds__(256) void rows_pack_kernel(const T* src, const int3
   }
   for (int c = lane * 8; c < C; c += 512) {  // last row: rows n-1 .. Tn-1 in index order, fp32 accumulation, one rounding
     float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int r = t; r < Tn; ++r) {
+    int r = t;
+    for (; r + 8 <= Tn; r += 8) {  // eight rows' loads in flight, added in the same index order (the chain is one row long otherwise)
+      float v[8][8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) load8(src + ((int64_t)b * Tn + r + u) * C + c, v[u]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += v[u][e];
+    }
+    for (; r < Tn; ++r) {
       float v[8];
       load8(src + ((int64_t)b * Tn + r) * C + c, v);
 #pragma unroll

@@ -17,6 +17,7 @@ The sequence is captured once per (batch, encoder length) in a HIP graph and rep
 scores (tests/test_decode_engine_gpu.py checks token ids bit-exactly against the reference's SequenceGenerator fixtures
 and against the module-by-module mirror path)."""
 import ctypes
+import os
 import math
 
 import torch
@@ -68,11 +69,17 @@ class BeamDecodeEngine:
             return self._packed[1]
         self._state.clear()
         layers = []
+        fuse = self._fuse_ln(dtype)
         for l in self.dec.layers:
             sa = l.self_attn
-            layers.append(dict(
+            d = dict(
                 wqkv=torch.cat((sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight), 0).detach().contiguous(),
-                bqkv=torch.cat((sa.q_proj.bias, sa.k_proj.bias, sa.v_proj.bias), 0).detach().contiguous()))
+                bqkv=torch.cat((sa.q_proj.bias, sa.k_proj.bias, sa.v_proj.bias), 0).detach().contiguous())
+            if fuse:  # LayerNorm folded into the projection that follows it (include/cst.h: cst_dec_ln_linear)
+                d["ln_qkv"] = self._fold_ln(l.self_attn_layer_norm, d["wqkv"], d["bqkv"])
+                d["ln_q"] = self._fold_ln(l.encoder_attn_layer_norm, l.encoder_attn.q_proj.weight, l.encoder_attn.q_proj.bias)
+                d["ln_fc1"] = self._fold_ln(l.final_layer_norm, l.fc1.weight, l.fc1.bias)
+            layers.append(d)
         pos = self.dec.embed_positions
         need = self.dec.padding_idx + 2 + self.max_len + 1
         table = pos.get_embedding(need, pos.embedding_dim, pos.padding_idx).to(device=device, dtype=torch.float32).contiguous()
@@ -81,6 +88,35 @@ class BeamDecodeEngine:
             table = table.to(dtype).float()
         self._packed = (key, dict(layers=layers, pos=table))
         return self._packed[1]
+
+    def nodes_per_step(self, dtype):
+        """Kernel launches (graph nodes) of one decode step: embed + per layer (LayerNorm, qkv, self-attention, out, LayerNorm, q,
+        cross-attention, out, LayerNorm, fc1, fc2 — the three LayerNorms folded into their projections on the bf16 path) + final
+        LayerNorm + vocabulary projection + the two beam-search kernels."""
+        per_layer = 8 if self._fuse_ln(dtype) else 11
+        return 1 + per_layer * len(self.dec.layers) + (1 if self.dec.layer_norm is not None else 0) + 1 + 2
+
+    def _fuse_ln(self, dtype):
+        C = self.dec.embed_dim
+        return dtype == torch.bfloat16 and C % 512 == 0 and not os.environ.get("CST_DEC_NO_LINEAR") and not os.environ.get("CST_DEC_NO_LN_FUSE")
+
+    @staticmethod
+    def _fold_ln(ln, w, b):
+        """(Wg, sg, sb) of cst_dec_ln_linear: gamma folded into the weight columns (one bf16 rounding), beta and the bias into sb."""
+        wf = w.detach().float()
+        wg = (wf * ln.weight.detach().float().unsqueeze(0)).to(w.dtype).contiguous()
+        sg = wg.float().sum(dim=1).contiguous()
+        sb = (wf @ ln.bias.detach().float()).contiguous()
+        if b is not None:
+            sb = (sb + b.detach().float()).contiguous()
+        return wg, sg, sb, float(ln.eps)
+
+    def _ln_linear(self, x, folded, out, act=L.ACT_NONE):
+        wg, sg, sb, eps = folded
+        M, Kd = x.shape
+        L.check(L.load().cst_dec_ln_linear(L.ptr(x), L.ptr(wg), L.ptr(sg), L.ptr(sb), eps, None, L.ptr(out), M, wg.shape[0], Kd,
+                                           x.stride(0), 0, out.stride(0), act, None, 0, L.dtype_code(x.dtype), L.stream_ptr()),
+                "cst_dec_ln_linear")
 
     # ------------------------------------------------------------------------------------------------------------
     def _alloc(self, bsz, S, dtype, device, has_mask):
@@ -126,6 +162,15 @@ class BeamDecodeEngine:
     def _linear(self, x, w, b, out, act=L.ACT_NONE, resid=None):
         M, Kd = x.shape
         N = w.shape[0]
+        if (M <= 1024 and x.dtype == torch.bfloat16 and Kd % 512 == 0 and x.stride(0) % 8 == 0 and w.is_contiguous()
+                and os.environ.get("CST_DEC_LINEAR_ALL")):
+            # (A/B switch.  Without a LayerNorm to fold in, the decode-step kernel is no faster than the general GEMM's 64 x 64
+            #  configuration: both sit at the ~8 us a dependent graph node costs on this stack — tools/bench_dec_linear.py)
+            L.check(L.load().cst_dec_linear(L.ptr(x), L.ptr(w), L.ptr(b) if b is not None else None,
+                                            L.ptr(resid) if resid is not None else None, L.ptr(out), M, N, Kd, x.stride(0),
+                                            0 if resid is None else resid.stride(0), out.stride(0), act, None, 0,
+                                            L.dtype_code(x.dtype), L.stream_ptr()), "cst_dec_linear")
+            return
         K.gemm(x, w, out, M, N, Kd, a_kmajor=1, b_kmajor=1, lda=Kd, ldb=Kd, ldc=out.stride(0), bias=b, act=act,
                resid=resid, ld_resid=0 if resid is None else resid.stride(0), split_k=1)
 
@@ -152,15 +197,22 @@ class BeamDecodeEngine:
         x, x2 = st["x"], st["x2"]
         for li, layer in enumerate(dec.layers):
             sa, ca, p = layer.self_attn, layer.encoder_attn, pk["layers"][li]
-            self._ln(x, layer.self_attn_layer_norm, st["h"], st)
-            self._linear(st["h"], p["wqkv"], p["bqkv"], st["qkv"])
+            fused = "ln_qkv" in p and bbsz <= 1024
+            if fused:
+                self._ln_linear(x, p["ln_qkv"], st["qkv"])
+            else:
+                self._ln(x, layer.self_attn_layer_norm, st["h"], st)
+                self._linear(st["h"], p["wqkv"], p["bqkv"], st["qkv"])
             L.check(lib.cst_dec_self_attn(L.ptr(st["qkv"]), L.ptr(st["kc"][li]), L.ptr(st["vc"][li]), L.ptr(st["anc"]),
                                           L.ptr(st["step"]), L.ptr(st["attn"]), bbsz, H, D, self.max_len, float(sa.scaling), dt,
                                           L.stream_ptr()), "cst_dec_self_attn")
             self._linear(st["attn"], sa.out_proj.weight, sa.out_proj.bias, x2, resid=x)
             x, x2 = x2, x
-            self._ln(x, layer.encoder_attn_layer_norm, st["h"], st)
-            self._linear(st["h"], ca.q_proj.weight, ca.q_proj.bias, st["q"])
+            if fused:
+                self._ln_linear(x, p["ln_q"], st["q"])
+            else:
+                self._ln(x, layer.encoder_attn_layer_norm, st["h"], st)
+                self._linear(st["h"], ca.q_proj.weight, ca.q_proj.bias, st["q"])
             # cross attention: one workgroup per (sentence, head); the sentence's K/V rows serve all of its beam rows
             S = st["kx"][li].shape[1]
             if self.cross_kernel == "flash_hm":  # the flash kernel over head-major K/V: (b, h, t) strides = (H*S*D, S*D, D)
@@ -180,9 +232,12 @@ class BeamDecodeEngine:
                 K.attn_fwd_desc(d)
             self._linear(st["attn"], ca.out_proj.weight, ca.out_proj.bias, x2, resid=x)
             x, x2 = x2, x
-            self._ln(x, layer.final_layer_norm, st["h"], st)
             act = L.ACT_GELU if layer.activation_fn == "gelu" else L.ACT_RELU
-            self._linear(st["h"], layer.fc1.weight, layer.fc1.bias, st["f"], act=act)
+            if fused:
+                self._ln_linear(x, p["ln_fc1"], st["f"], act=act)
+            else:
+                self._ln(x, layer.final_layer_norm, st["h"], st)
+                self._linear(st["h"], layer.fc1.weight, layer.fc1.bias, st["f"], act=act)
             self._linear(st["f"], layer.fc2.weight, layer.fc2.bias, x2, resid=x)
             x, x2 = x2, x
         if dec.layer_norm is not None:
@@ -191,7 +246,7 @@ class BeamDecodeEngine:
         else:
             feat = x
         w = dec.output_projection.weight
-        K.gemm(feat, w, st["logits"], bbsz, w.shape[0], C, a_kmajor=1, b_kmajor=1, lda=C, ldb=C, ldc=st["logits"].stride(0), split_k=1)
+        self._linear(feat, w, None, st["logits"])
         L.check(lib.cst_beam_step(ctypes.byref(st["desc"]), L.stream_ptr()), "cst_beam_step")
         # an even number of x/x2 swaps per layer (3) x layers may leave the residual stream in x2: the NEXT step's embed always
         # writes st["x"], and every step performs the same swaps, so the captured sequence is step-invariant.

@@ -401,6 +401,23 @@ int cst_beam_step(const cst_beam_desc* d, cst_stream stream);
 int cst_dec_embed(const int64_t* tokens, const int32_t* step, const void* embed, const float* pos_table, float scale,
                   int64_t pad_idx, void* out, int64_t rows, int64_t C, int64_t max_len, int64_t pos_rows, int dtype,
                   cst_stream stream);
+/* Linear layer of one decode step over the hypothesis rows: y[M, N] = act(x[M, K] W[N, K]^T + bias[N]) (+ resid[M, N]) — replaces the
+ * F.linear calls of the incremental decoder layer (modules/transformer_layer.py:293-420 at one target position) with a kernel shaped
+ * for M = bsz * beam rows: every weight byte is requested within one memory round trip (N/16..N/64 x ceil(M/80) small workgroups,
+ * operands global -> MFMA fragments, K split over the four waves and added in wave order: deterministic).  bf16 only;
+ * K % 512 == 0; ldx % 8 == 0; x, W 16-byte aligned.  bias / resid may be NULL.  step (optional, device): the launch does nothing
+ * once *step > max_len (a captured step replayed past the end of the search). */
+int cst_dec_linear(const void* x, const void* W, const void* bias, const void* resid, void* y, int64_t M, int64_t N, int64_t K,
+                   int64_t ldx, int64_t ld_resid, int64_t ldy, int act, const int32_t* step, int64_t max_len, int dtype,
+                   cst_stream stream);
+/* LayerNorm + Linear of one decode step in ONE launch: y = act(LN(x; gamma, beta, eps) W^T + b) (+ resid), the pre-norm sub-blocks of
+ * the decoder layer (modules/transformer_layer.py:346-349, :369-372, :403-406).  The caller folds the affine part into the weights
+ * once (they are constants while decoding): Wg[n,k] = bf16(W[n,k] gamma[k]);  sg[n] = sum_k Wg[n,k];  sb[n] = sum_k W[n,k] beta[k] +
+ * b[n] (fp32 vectors).  The kernel multiplies the raw rows by Wg, gathers every row's sum(x) and sum(x^2) from the operand fragments
+ * it loads anyway, and applies  rstd_m (acc - mean_m sg[n]) + sb[n]  in the epilogue.  Same limits as cst_dec_linear. */
+int cst_dec_ln_linear(const void* x, const void* Wg, const float* sg, const float* sb, float eps, const void* resid, void* y, int64_t M,
+                      int64_t N, int64_t K, int64_t ldx, int64_t ld_resid, int64_t ldy, int act, const int32_t* step, int64_t max_len,
+                      int dtype, cst_stream stream);
 /* Single-query self-attention at position s = *step: qkv [rows, 3*H*D] (q | k | v of the newest token), caches
  * [rows, L1, H*D]; appends k/v at slot s, attends over positions 0..s through anc (half s & 1), out [rows, H*D].
  * `scale` multiplies QK^T in fp32.  D in {32, 64}. */

@@ -152,6 +152,90 @@ def test_dec_self_attn_and_embed(KL, dtype, H, D):
         assert torch.equal(x, ref), s
 
 
+@pytest.mark.parametrize("M,N,K,act", [(160, 3072, 1024, "none"), (160, 1024, 1024, "none"), (160, 4096, 1024, "relu"),
+                                       (37, 1000, 512, "gelu"), (160, 10000, 1024, "none")])
+def test_dec_ln_linear_matches_layernorm_then_linear(KL, M, N, K, act):
+    """cst_dec_ln_linear (LayerNorm folded into the projection: raw rows x gamma-scaled weights, row statistics gathered in the
+    kernel) against F.layer_norm -> F.linear -> activation evaluated in fp32 on the same bf16 parameters.  Rows get a large common
+    offset (mean 3 sigma) so that the mean-correction term  - mean * sum_k Wg[n,k]  is exercised for real.  Tolerance: the bf16
+    rounding of the folded weights and of the result (2 x 2^-8 of the operand scale)."""
+    Kk, L = KL
+    g = torch.Generator().manual_seed(N + K)
+    dt = torch.bfloat16
+    x = (torch.randn(M, K, generator=g) + 3.0 * torch.randn(M, 1, generator=g)).to(dt).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dt).cuda()
+    b = torch.randn(N, generator=g).to(dt).cuda()
+    ln = torch.nn.LayerNorm(K).cuda()
+    with torch.no_grad():
+        ln.weight.copy_(1.0 + 0.3 * torch.randn(K, generator=g))
+        ln.bias.copy_(0.2 * torch.randn(K, generator=g))
+    ln = ln.to(dt)
+    eng = import_module("chimera-st_amd.decode_engine").BeamDecodeEngine
+    wg, sg, sb, eps = eng._fold_ln(ln, W, b)
+    y = torch.empty(M, N, dtype=dt, device="cuda")
+    code = {"none": L.ACT_NONE, "relu": L.ACT_RELU, "gelu": L.ACT_GELU}[act]
+    L.check(L.load().cst_dec_ln_linear(L.ptr(x), L.ptr(wg), L.ptr(sg), L.ptr(sb), eps, None, L.ptr(y), M, N, K, K, 0, N, code, None, 0,
+                                       L.dtype_code(dt), L.stream_ptr()), "cst_dec_ln_linear")
+    h = torch.nn.functional.layer_norm(x.float(), (K,), ln.weight.float(), ln.bias.float(), ln.eps)
+    pre = h @ W.float().t() + b.float()
+    ref = pre
+    if act == "relu":
+        ref = torch.relu(pre)
+    elif act == "gelu":
+        ref = torch.nn.functional.gelu(pre)
+    err = (y.float() - ref).abs()
+    scale = float(pre.abs().max())  # the roundings act on the pre-activation
+    assert float(err.max()) <= 2.0 * 2.0 ** -8 * max(scale, 1.0), (float(err.max()), scale)
+    assert float(err.mean()) <= 2.0 ** -8 * max(float(pre.abs().mean()), 0.1)
+
+
+@pytest.mark.parametrize("M,N,K,act,has_bias,has_resid", [
+    (160, 1024, 1024, "none", True, True),    # out_proj / fc2-shaped: one 16-column tile per workgroup
+    (160, 3072, 1024, "none", True, False),   # packed q | k | v projection
+    (160, 4096, 1024, "relu", True, False),   # fc1 + activation: two column tiles per workgroup
+    (160, 1024, 4096, "gelu", True, True),    # long K
+    (160, 10000, 1024, "none", False, False),  # vocabulary projection: four column tiles per workgroup
+    (37, 1000, 512, "relu", True, True),      # ragged rows and columns (N % 16 != 0)
+    (5, 520, 512, "none", False, True),
+])
+def test_dec_linear_matches_fp32_reference(KL, M, N, K, act, has_bias, has_resid):
+    """cst_dec_linear (decode.hip) against act(x W^T + b) + resid evaluated in fp32 on the same bf16 operands: the kernel accumulates
+    in fp32 and rounds once, so it must agree to one bf16 rounding of the result (2^-8 relative) plus the summation-order noise of
+    fp32 (K <= 4096 terms)."""
+    Kk, L = KL
+    g = torch.Generator().manual_seed(M * 7 + N)
+    dt = torch.bfloat16
+    x = torch.randn(M, K, generator=g).to(dt).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dt).cuda()
+    b = torch.randn(N, generator=g).to(dt).cuda() if has_bias else None
+    r = torch.randn(M, N, generator=g).to(dt).cuda() if has_resid else None
+    ldy = N + 8  # a padded output row (the logits buffer of the engine is one)
+    y = torch.full((M, ldy), 7.0, dtype=dt, device="cuda")
+    code = {"none": L.ACT_NONE, "relu": L.ACT_RELU, "gelu": L.ACT_GELU}[act]
+    L.check(L.load().cst_dec_linear(L.ptr(x), L.ptr(W), L.ptr(b) if b is not None else None, L.ptr(r) if r is not None else None,
+                                    L.ptr(y), M, N, K, K, N if r is not None else 0, ldy, code, None, 0, L.dtype_code(dt),
+                                    L.stream_ptr()), "cst_dec_linear")
+    ref = x.float() @ W.float().t()
+    if b is not None:
+        ref = ref + b.float()
+    if act == "relu":
+        ref = torch.relu(ref)
+    elif act == "gelu":
+        ref = torch.nn.functional.gelu(ref)
+    if r is not None:
+        ref = ref + r.float()
+    got = y[:, :N].float()
+    err = (got - ref).abs()
+    assert float((err - (2.0 ** -8) * ref.abs()).max()) <= 2e-3, float(err.max())
+    assert float((y[:, N:].float() - 7.0).abs().max()) == 0.0  # nothing written behind the row
+    # deterministic: a second launch gives the same bits
+    y2 = torch.full((M, ldy), 7.0, dtype=dt, device="cuda")
+    L.check(L.load().cst_dec_linear(L.ptr(x), L.ptr(W), L.ptr(b) if b is not None else None, L.ptr(r) if r is not None else None,
+                                    L.ptr(y2), M, N, K, K, N if r is not None else 0, ldy, code, None, 0, L.dtype_code(dt),
+                                    L.stream_ptr()), "cst_dec_linear")
+    assert torch.equal(y, y2)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("H,D,beam,S", [(8, 64, 5, 375), (2, 32, 1, 64), (4, 64, 10, 130), (16, 64, 3, 33)])
 def test_dec_cross_attn(KL, dtype, H, D, beam, S):

@@ -16,10 +16,11 @@ def main():
     rows.sort(key=lambda r: -r[2])
     calls = sum(r[1] for r in rows)
     total = sum(r[2] for r in rows)
-    print("%d kernels launched over %g updates = %.0f launches per update; kernel time %.2f ms per update" % (calls, steps, calls / steps, total / steps / 1e6))
-    print("%10s %12s %10s  %s" % ("calls/upd", "us/upd", "avg us", "kernel"))
+    # (top_kernels.total_duration is in microseconds)
+    print("%d kernels launched over %g updates = %.0f launches per update; kernel time %.2f ms per update" % (calls, steps, calls / steps, total / steps / 1e3))
+    print("%10s %12s %10s  %s" % ("calls/upd", "ms/upd", "avg us", "kernel"))
     for name, n, dur in rows[:rows_max]:
-        print("%10.1f %12.1f %10.2f  %s" % (n / steps, dur / steps / 1e3, dur / n / 1e3, name[:150]))
+        print("%10.1f %12.3f %10.2f  %s" % (n / steps, dur / steps / 1e3, dur / n, name[:150]))
 
 
 if __name__ == "__main__":
