@@ -710,22 +710,22 @@ int to_params(const cst_beam_desc* d, BeamP& p) {
 //   its weights), sg[n] = sum_k Wg[n,k], sb[n] = sum_k W[n,k] beta[k] + b[n] (fp32).  The kernel multiplies the RAW rows by Wg and
 //   gathers sum(x), sum(x^2) of every row from the fragments it loads anyway (each workgroup sees whole rows), so the LayerNorm
 //   launch and its activation round trip disappear; W is then Wg, `bias` is unused, ln_sg / ln_sb are the two vectors.
-template <int NT, int TT, int UN, bool LN>
-__global__ __launch_bounds__(256) void dec_linear_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W, const bf16_t* __restrict__ bias,
+template <int NT, int TT, int UN, bool LN, int NW>
+__global__ __launch_bounds__(NW * 64) void dec_linear_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W, const bf16_t* __restrict__ bias,
                                                          const bf16_t* resid, bf16_t* y, int M, int N, int K, int64_t ldx, int64_t ldr,
                                                          int64_t ldy, int act, const int32_t* stepp, int max_len, const float* ln_sg,
                                                          const float* ln_sb, float ln_eps) {
   if (stepp && *stepp > max_len) return;
   using f32x4v = __attribute__((ext_vector_type(4))) float;
-  __shared__ float red[4][NT * TT][64][4];
-  __shared__ float stat[LN ? 4 : 1][TT][16][2];
+  __shared__ float red[NW][NT * TT][64][4];
+  __shared__ float stat[LN ? NW : 1][TT][16][2];
   float s1[TT], s2[TT];
 #pragma unroll
   for (int i = 0; i < TT; ++i) s1[i] = s2[i] = 0.0f;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, c = lane >> 4;
   const int n0 = blockIdx.x * (16 * NT), t0 = blockIdx.y * (16 * TT);
-  const int kq = K >> 2;
+  const int kq = K / NW;  // this wave's K range: [wave * kq, (wave + 1) * kq)
   const bf16_t* wp[NT];
   const bf16_t* xp[TT];
 #pragma unroll
@@ -798,17 +798,23 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const bf16_t* __restric
 #pragma unroll
       for (int e = 0; e < 4; ++e) red[wave][j * TT + i][lane][e] = acc[j][i][e];
   __syncthreads();
-  for (int tile = wave; tile < NT * TT; tile += 4) {
+  for (int tile = wave; tile < NT * TT; tile += NW) {
     const int j = tile / TT, i = tile % TT;
     const int n = n0 + 16 * j + 4 * c, t = t0 + 16 * i + r;
     float v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = ((red[0][tile][lane][e] + red[1][tile][lane][e]) + red[2][tile][lane][e]) + red[3][tile][lane][e];
+    for (int e = 0; e < 4; ++e) {
+      float a = red[0][tile][lane][e];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) a += red[w][tile][lane][e];  // wave order: deterministic
+      v[e] = a;
+    }
     if (t >= M || n >= N) continue;
     float mean = 0.0f, rstd = 1.0f;
     if (LN) {
-      const float a = ((stat[0][i][r][0] + stat[1][i][r][0]) + stat[2][i][r][0]) + stat[3][i][r][0];
-      const float b2 = ((stat[0][i][r][1] + stat[1][i][r][1]) + stat[2][i][r][1]) + stat[3][i][r][1];
+      float a = stat[0][i][r][0], b2 = stat[0][i][r][1];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) { a += stat[w][i][r][0]; b2 += stat[w][i][r][1]; }
       mean = a / (float)K;
       const float var = fmaxf(b2 / (float)K - mean * mean, 0.0f);
       rstd = rsqrtf(var + ln_eps);
@@ -850,14 +856,31 @@ static int dec_linear_impl(const void* x, const void* W, const void* bias, const
   const int ty = (int)cst_ceil_div(M, 80);
   const int64_t wg1 = cst_ceil_div(N, 16) * ty;
   const bool ln = ln_sg != nullptr;
-  // enough workgroups to have every CU pulling weights, few enough that the shared x rows are not re-read from L2 more than needed
-#define CST_DL(NTv, UNv, LNv)                                                                                                       \
-  hipLaunchKernelGGL((dec_linear_kernel<NTv, 5, UNv, LNv>), dim3((unsigned)cst_ceil_div(N, 16 * NTv), (unsigned)ty), dim3(256), 0, s, \
+  // Waves per workgroup = how finely K is cut: each wave should have one or two batches of UN k-steps (32 columns each), so that
+  // nearly all of its weight bytes are requested at once.  Enough workgroups to have every CU pulling weights, few enough that the
+  // shared x rows are not re-read from L2 more than needed.
+  static const int env_nw = getenv("CST_DEC_LINEAR_NW") ? atoi(getenv("CST_DEC_LINEAR_NW")) : 0;
+  int nw = 8;  // measured (tools/bench_dec_linear.py): 8 waves 10.2 / 8.1 / 10.3 us on the three LayerNorm-fused shapes, 4 waves 10.9 / 8.6 / 11.0; 16 no better
+  if (env_nw == 4 || env_nw == 8 || env_nw == 16) nw = env_nw;
+  while (nw > 4 && K % (nw * 64) != 0) nw >>= 1;
+  const int steps = (int)(K / nw / 32);  // k-steps per wave
+#define CST_DL(NTv, UNv, LNv, NWv)                                                                                                  \
+  hipLaunchKernelGGL((dec_linear_kernel<NTv, 5, UNv, LNv, NWv>), dim3((unsigned)cst_ceil_div(N, 16 * NTv), (unsigned)ty), dim3(NWv * 64), 0, s, \
                      (const bf16_t*)x, (const bf16_t*)W, (const bf16_t*)bias, (const bf16_t*)resid, (bf16_t*)y, (int)M, (int)N, (int)K, ldx, \
                      ld_resid, ldy, act, step, (int)max_len, ln_sg, ln_sb, ln_eps)
-  if (wg1 <= 320) { if (ln) CST_DL(1, 4, true); else CST_DL(1, 4, false); }
-  else if (wg1 <= 1024) { if (ln) CST_DL(2, 4, true); else CST_DL(2, 4, false); }
-  else { if (ln) CST_DL(4, 2, true); else CST_DL(4, 2, false); }
+#define CST_DL_LN(NTv, UNv, NWv) do { if (ln) CST_DL(NTv, UNv, true, NWv); else CST_DL(NTv, UNv, false, NWv); } while (0)
+  if (wg1 <= 320) {  // one 16-column tile per workgroup
+    if (nw == 16) { if (steps % 4 == 0) CST_DL_LN(1, 4, 16); else CST_DL_LN(1, 2, 16); }
+    else if (nw == 8) { if (steps % 4 == 0) CST_DL_LN(1, 4, 8); else CST_DL_LN(1, 2, 8); }
+    else CST_DL_LN(1, 4, 4);
+  } else if (wg1 <= 1024) {  // two column tiles; the wave-partial image of 16 waves would not fit the LDS
+    const int nw2 = nw == 16 ? 8 : nw, steps2 = (int)(K / nw2 / 32);
+    if (nw2 == 8) { if (steps2 % 4 == 0) CST_DL_LN(2, 4, 8); else CST_DL_LN(2, 2, 8); }
+    else CST_DL_LN(2, 4, 4);
+  } else {
+    CST_DL_LN(4, 2, 4);
+  }
+#undef CST_DL_LN
 #undef CST_DL
   return cst_check_launch("cst_dec_linear");
 }

@@ -61,6 +61,10 @@ def main():
     argv, stats = sys.argv[1:], {}
     if argv and argv[0] == "--stats":
         stats, argv = load_stats(argv[1]), argv[2:]
+    elif argv and argv[0] == "--trace-db":  # a `rocprofv3 --kernel-trace --stats` results.db of the same command: average durations
+        c = sqlite3.connect(argv[1])
+        stats = {short(r[0])[:60]: r[2] / max(r[1], 1) for r in c.execute("select name,total_calls,total_duration from top_kernels")}
+        argv = argv[2:]
     for path in argv:
         agg = load(path)
         print("# %s" % path)
@@ -75,6 +79,8 @@ def main():
             line = "%-96s n=%5d gui_active %6.2f%%" % (short(name), n, 100.0 * gui / gui_all)
             if "SQ_VALU_MFMA_BUSY_CYCLES" in tot and gui > 0:
                 line += "  MFMA busy %5.1f%% of SIMD-cycles" % (100.0 * tot["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui / XCDS * 1024.0))
+            if "SQ_ACTIVE_INST_VALU" in tot and gui > 0:  # quad-cycles (MI355X_MICROARCH.md: SQ_ACTIVE_INST_* count 4-cycle units)
+                line += "  VALU active %5.1f%%" % (100.0 * 4.0 * tot["SQ_ACTIVE_INST_VALU"] / (gui / XCDS * 1024.0))
             if "TCC_EA0_RDREQ_sum" in tot and gui > 0:
                 by = 2.0 * tot["TCC_EA0_RDREQ_sum"] * 64.0 + tot.get("TCC_EA0_WRREQ_sum", 0.0) * 64.0
                 line += "  fabric %8.1f MB/launch  %7.1f B/cycle" % (by / n / 1e6, by / (gui / XCDS))
