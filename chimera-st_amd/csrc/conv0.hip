@@ -263,12 +263,14 @@ constexpr int C0R_TB = 128;  // frames per block (forward)
 template <typename T, int KC>
 __global__ __launch_bounds__(256) void conv0_fwd_reg_kernel(const float* wav, const T* w, const T* gamma, const T* beta,
                                                             const float* mean, const float* rstd, T* y, int64_t S, int64_t L,
-                                                            int C, int stride) {
+                                                            int C, int stride, const int32_t* flim) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* sx = sm;
   const int64_t b = blockIdx.y;
   const int64_t t0 = (int64_t)blockIdx.x * C0R_TB;
-  const int nt = (int)((L - t0 < C0R_TB) ? (L - t0) : C0R_TB);
+  const int64_t Lb = (flim && flim[b] < L) ? flim[b] : L;  // frames from flim[b] on are read by nobody: not computed, not stored
+  if (t0 >= Lb) return;
+  const int nt = (int)((Lb - t0 < C0R_TB) ? (Lb - t0) : C0R_TB);
   const int tpf = C / 4, fp = 256 / tpf;       // threads per frame, frames in flight
   const int cq = threadIdx.x % tpf, fl = threadIdx.x / tpf;
   const int c0 = cq * 4;
@@ -302,12 +304,14 @@ constexpr int C0R_BWD_TB = 2048;  // frames per block (backward)
 template <typename T, int KC>
 __global__ __launch_bounds__(256) void conv0_bwd_reg_kernel(const T* dy, const float* wav, const T* w, const T* gamma,
                                                             const T* beta, const float* mean, const float* rstd, float* ws,
-                                                            int64_t S, int64_t L, int C, int stride) {
+                                                            int64_t S, int64_t L, int C, int stride, const int32_t* blim) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* sx = sm;
   const int64_t b = blockIdx.y;
   const int64_t t0 = (int64_t)blockIdx.x * C0R_BWD_TB;
-  const int nt = (int)((L - t0 < C0R_BWD_TB) ? (L - t0) : C0R_BWD_TB);
+  const int64_t Lb = (blim && blim[b] < L) ? blim[b] : L;  // dy is exactly zero from frame blim[b] on: those frames add nothing
+  const int64_t left = Lb - t0;
+  const int nt = left <= 0 ? 0 : (int)(left < C0R_BWD_TB ? left : C0R_BWD_TB);  // 0: this block only writes its zero partials
   const int tpf = C / 4, fp = 256 / tpf;
   const int cq = threadIdx.x % tpf, fl = threadIdx.x / tpf;
   const int c0 = cq * 4;
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(256) void conv0_bwd_reg_kernel(const T* dy, const f
 #pragma unroll
     for (int j = 0; j < KC; ++j) wr[j][e] = DT<T>::ld(w + (int64_t)(c0 + e) * KC + j);
   }
-  const int span = (nt - 1) * stride + KC;
+  const int span = nt > 0 ? (nt - 1) * stride + KC : 0;
   for (int i = threadIdx.x; i < span; i += 256) sx[i] = wav[b * S + t0 * stride + i];
   __syncthreads();
   float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0}, r[KC][4];
@@ -437,8 +441,8 @@ extern "C" int64_t cst_conv0_fwd_workspace(int64_t B, int64_t S, int k, int stri
 }
 
 extern "C" int cst_conv0_gn_gelu_fwd(const float* wav, const void* w, const void* gamma, const void* beta, void* y,
-                                     float* mean, float* rstd, float* gram, float* workspace, int64_t B, int64_t S, int64_t C, int k,
-                                     int stride, float eps, int dtype, cst_stream stream) {
+                                     float* mean, float* rstd, float* gram, float* workspace, const int32_t* frame_limit, int64_t B,
+                                     int64_t S, int64_t C, int k, int stride, float eps, int dtype, cst_stream stream) {
   CST_REQUIRE(wav && w && gamma && beta && y && mean && rstd && gram && workspace, "cst_conv0_gn_gelu_fwd: null tensor");
   CST_REQUIRE(k >= 1 && k <= KMAX && stride >= 1 && S >= k, "cst_conv0_gn_gelu_fwd: unsupported k=%d stride=%d S=%lld", k, stride, (long long)S);
   CST_REQUIRE(C % 8 == 0 && C >= 8 && C / 8 <= 256, "cst_conv0_gn_gelu_fwd: C=%lld must be a multiple of 8 and <= 2048", (long long)C);
@@ -457,11 +461,11 @@ extern "C" int cst_conv0_gn_gelu_fwd(const float* wav, const void* w, const void
   dim3 fgr((unsigned)cst_ceil_div(L, C0R_TB), (unsigned)B);
   if (dtype == CST_BF16) {
     hipLaunchKernelGGL(conv0_stats_kernel<bf16_t>, sg, dim3(128), 0, s, (const bf16_t*)w, workspace, gb, gram, mean, rstd, C, L, k, eps);
-    if (reg_path) hipLaunchKernelGGL((conv0_fwd_reg_kernel<bf16_t, 10>), fgr, dim3(256), lds_r, s, wav, (const bf16_t*)w, (const bf16_t*)gamma, (const bf16_t*)beta, mean, rstd, (bf16_t*)y, S, L, (int)C, stride);
+    if (reg_path) hipLaunchKernelGGL((conv0_fwd_reg_kernel<bf16_t, 10>), fgr, dim3(256), lds_r, s, wav, (const bf16_t*)w, (const bf16_t*)gamma, (const bf16_t*)beta, mean, rstd, (bf16_t*)y, S, L, (int)C, stride, frame_limit);
     else hipLaunchKernelGGL(conv0_fwd_kernel<bf16_t>, fg, dim3(256), lds, s, wav, (const bf16_t*)w, (const bf16_t*)gamma, (const bf16_t*)beta, mean, rstd, (bf16_t*)y, S, L, (int)C, k, stride);
   } else {
     hipLaunchKernelGGL(conv0_stats_kernel<float>, sg, dim3(128), 0, s, (const float*)w, workspace, gb, gram, mean, rstd, C, L, k, eps);
-    if (reg_path) hipLaunchKernelGGL((conv0_fwd_reg_kernel<float, 10>), fgr, dim3(256), lds_r, s, wav, (const float*)w, (const float*)gamma, (const float*)beta, mean, rstd, (float*)y, S, L, (int)C, stride);
+    if (reg_path) hipLaunchKernelGGL((conv0_fwd_reg_kernel<float, 10>), fgr, dim3(256), lds_r, s, wav, (const float*)w, (const float*)gamma, (const float*)beta, mean, rstd, (float*)y, S, L, (int)C, stride, frame_limit);
     else hipLaunchKernelGGL(conv0_fwd_kernel<float>, fg, dim3(256), lds, s, wav, (const float*)w, (const float*)gamma, (const float*)beta, mean, rstd, (float*)y, S, L, (int)C, k, stride);
   }
   return cst_check_launch("cst_conv0_gn_gelu_fwd");
@@ -480,8 +484,8 @@ extern "C" int64_t cst_conv0_bwd_workspace(int64_t B, int64_t S, int64_t C, int 
 
 extern "C" int cst_conv0_gn_gelu_bwd(const void* dy, const float* wav, const void* w, const void* gamma, const void* beta,
                                      const float* mean, const float* rstd, const float* gram, float* dw, float* dgamma,
-                                     float* dbeta, float* workspace, int64_t B, int64_t S, int64_t C, int k, int stride,
-                                     int dtype, cst_stream stream) {
+                                     float* dbeta, float* workspace, const int32_t* frame_limit, int64_t B, int64_t S, int64_t C, int k,
+                                     int stride, int dtype, cst_stream stream) {
   CST_REQUIRE(dy && wav && w && gamma && beta && mean && rstd && gram && dw && dgamma && dbeta && workspace, "cst_conv0_gn_gelu_bwd: null tensor");
   CST_REQUIRE(k >= 1 && k <= KMAX && stride >= 1 && S >= k, "cst_conv0_gn_gelu_bwd: unsupported k=%d stride=%d", k, stride);
   CST_REQUIRE(C % 8 == 0 && C >= 8 && C / 8 <= 256, "cst_conv0_gn_gelu_bwd: C=%lld must be a multiple of 8 and <= 2048", (long long)C);
@@ -501,11 +505,11 @@ extern "C" int cst_conv0_gn_gelu_bwd(const void* dy, const float* wav, const voi
     if (lds_r < sizeof(float) * 256 * 4) lds_r = sizeof(float) * 256 * 4;
     dim3 gr((unsigned)cst_ceil_div(L, C0R_BWD_TB), (unsigned)B);
     if (dtype == CST_BF16) {
-      hipLaunchKernelGGL((conv0_bwd_reg_kernel<bf16_t, 10>), gr, dim3(256), lds_r, s, (const bf16_t*)dy, wav, (const bf16_t*)w, (const bf16_t*)gamma, (const bf16_t*)beta, mean, rstd, workspace, S, L, (int)C, stride);
+      hipLaunchKernelGGL((conv0_bwd_reg_kernel<bf16_t, 10>), gr, dim3(256), lds_r, s, (const bf16_t*)dy, wav, (const bf16_t*)w, (const bf16_t*)gamma, (const bf16_t*)beta, mean, rstd, workspace, S, L, (int)C, stride, frame_limit);
       hipLaunchKernelGGL(conv0_bwd_reduce_kernel, rg, dim3(256), 0, s, workspace, acc, nblk, k + 2, (int)C);
       hipLaunchKernelGGL(conv0_bwd_finish_kernel<bf16_t>, fg, dim3(FB * FC), 0, s, acc, gram, (const bf16_t*)w, (const bf16_t*)gamma, mean, rstd, dw, dgamma, dbeta, B, C, L, k);
     } else {
-      hipLaunchKernelGGL((conv0_bwd_reg_kernel<float, 10>), gr, dim3(256), lds_r, s, (const float*)dy, wav, (const float*)w, (const float*)gamma, (const float*)beta, mean, rstd, workspace, S, L, (int)C, stride);
+      hipLaunchKernelGGL((conv0_bwd_reg_kernel<float, 10>), gr, dim3(256), lds_r, s, (const float*)dy, wav, (const float*)w, (const float*)gamma, (const float*)beta, mean, rstd, workspace, S, L, (int)C, stride, frame_limit);
       hipLaunchKernelGGL(conv0_bwd_reduce_kernel, rg, dim3(256), 0, s, workspace, acc, nblk, k + 2, (int)C);
       hipLaunchKernelGGL(conv0_bwd_finish_kernel<float>, fg, dim3(FB * FC), 0, s, acc, gram, (const float*)w, (const float*)gamma, mean, rstd, dw, dgamma, dbeta, B, C, L, k);
     }
@@ -545,6 +549,11 @@ __global__ void conv_row_limits_kernel(const int32_t* nz_last, ConvSpec8 sp, int
       if (i >= 1 && r < sp.s[i]) {
         const int d = nz[i - 1] - r;
         v = d > 0 ? (d + sp.s[i] - 1) / sp.s[i] : 0;
+      } else if (i == 0 && r == 0 && L >= 2) {  // rows of layer 0 under layer 1's live 256-row tiles
+        const int64_t need = (int64_t)((nz[1] + 255) / 256) * 256 * sp.s[1] + sp.k[1];
+        v = need < sp.len[0] ? (int)need : sp.len[0];
+      } else if (i == 0 && r == 0) {
+        v = sp.len[0];
       }
       out[i * plane + (int64_t)(1 + r) * B + b] = v;
     }

@@ -6,7 +6,6 @@
 #include <math.h>
 #include "../../include/cst.h"
 
-#define CST_ABI_VERSION 2
 #define CST_WAVE 64
 
 // ---------------------------------------------------------------------------------------

@@ -509,25 +509,29 @@ def unpack_rows(y, seq, broadcast=True):
 # ------------------------------------------------------------------------------------------------
 class _Conv0Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, wav, w, gamma, beta, stride, eps):
+    def forward(ctx, wav, w, gamma, beta, stride, eps, write_limit, grad_limit):
         C, _, k = w.shape
         w2 = w.reshape(C, k).contiguous()
         wav = wav.float().contiguous()
-        y, mean, rstd, gram = K.conv0_fwd(wav, w2, gamma, beta, k, stride, eps)
+        if _os.environ.get("CST_NO_MLEN") or _os.environ.get("CST_GEMM_NO_KLIVE"):
+            write_limit = grad_limit = None  # (with the GEMM-side skipping off, every frame of this layer is read)
+        y, mean, rstd, gram = K.conv0_fwd(wav, w2, gamma, beta, k, stride, eps, frame_limit=write_limit)
         ctx.save_for_backward(wav, w2, gamma, beta, mean, rstd, gram)
-        ctx.k, ctx.stride = k, stride
+        ctx.k, ctx.stride, ctx.grad_limit = k, stride, grad_limit
         return y
 
     @staticmethod
     def backward(ctx, dy):
         wav, w2, gamma, beta, mean, rstd, gram = ctx.saved_tensors
-        dw, dg, db = K.conv0_bwd(dy.contiguous(), wav, w2, gamma, beta, mean, rstd, gram, ctx.k, ctx.stride)
-        return None, dw.view(w2.shape[0], 1, ctx.k).to(w2.dtype), dg.to(gamma.dtype), db.to(gamma.dtype), None, None
+        dw, dg, db = K.conv0_bwd(dy.contiguous(), wav, w2, gamma, beta, mean, rstd, gram, ctx.k, ctx.stride, frame_limit=ctx.grad_limit)
+        return None, dw.view(w2.shape[0], 1, ctx.k).to(w2.dtype), dg.to(gamma.dtype), db.to(gamma.dtype), None, None, None, None
 
 
-def conv0_gn_gelu(wav, weight, gn_weight, gn_bias, stride, eps=1e-5):
-    """wav [B,S] -> channels-last [B, L, C] = GELU(GroupNorm_C(conv1d(wav, weight[C,1,k], stride)))."""
-    return _Conv0Fn.apply(wav, weight, gn_weight, gn_bias, stride, eps)
+def conv0_gn_gelu(wav, weight, gn_weight, gn_bias, stride, eps=1e-5, write_limit=None, grad_limit=None):
+    """wav [B,S] -> channels-last [B, L, C] = GELU(GroupNorm_C(conv1d(wav, weight[C,1,k], stride))).
+    write_limit / grad_limit (int32 [B], cst_conv_row_limits rows [0][1] / [0][0]): frames nobody reads are not written, frames whose
+    gradient is exactly zero are not read in backward."""
+    return _Conv0Fn.apply(wav, weight, gn_weight, gn_bias, stride, eps, write_limit, grad_limit)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -245,8 +245,9 @@ def attn_bwd(do, q, k, v, o, lse, H, D, kpm, causal, scale, layout_q="bt", layou
     return dq, dk, dv
 
 
-def conv0_fwd(wav, w, gamma, beta, k, stride, eps=1e-5):
-    """wav [B,S] fp32; w [C,k]; -> y [B,L,C] channels-last, (mean, rstd, gram) saved for backward."""
+def conv0_fwd(wav, w, gamma, beta, k, stride, eps=1e-5, frame_limit=None):
+    """wav [B,S] fp32; w [C,k]; -> y [B,L,C] channels-last, (mean, rstd, gram) saved for backward.  frame_limit (int32 [B]): frames
+    from there on are unread and left unwritten (include/cst.h)."""
     assert wav.dtype == torch.float32 and wav.is_contiguous()
     B, S = wav.shape
     C = w.shape[0]
@@ -258,12 +259,20 @@ def conv0_fwd(wav, w, gamma, beta, k, stride, eps=1e-5):
     lib = L.load()
     ws = workspace(lib.cst_conv0_fwd_workspace(B, S, k, stride), wav.device)
     L.check(lib.cst_conv0_gn_gelu_fwd(L.ptr(wav), L.ptr(w), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(mean), L.ptr(rstd),
-                                      L.ptr(gram), L.ptr(ws), B, S, C, k, stride, eps, L.dtype_code(w.dtype), L.stream_ptr()),
-            "cst_conv0_gn_gelu_fwd")
+                                      L.ptr(gram), L.ptr(ws), _lim(frame_limit, B), B, S, C, k, stride, eps, L.dtype_code(w.dtype),
+                                      L.stream_ptr()), "cst_conv0_gn_gelu_fwd")
     return y, mean, rstd, gram
 
 
-def conv0_bwd(dy, wav, w, gamma, beta, mean, rstd, gram, k, stride):
+def _lim(frame_limit, B):
+    if frame_limit is None:
+        return None
+    assert frame_limit.dtype == torch.int32 and frame_limit.numel() == B and frame_limit.is_contiguous()
+    STATS["conv0_frame_limit"] = STATS.get("conv0_frame_limit", 0) + 1
+    return L.ptr(frame_limit)
+
+
+def conv0_bwd(dy, wav, w, gamma, beta, mean, rstd, gram, k, stride, frame_limit=None):
     B, S = wav.shape
     C = w.shape[0]
     lib = L.load()
@@ -272,7 +281,7 @@ def conv0_bwd(dy, wav, w, gamma, beta, mean, rstd, gram, k, stride):
     db = torch.empty(C, dtype=torch.float32, device=wav.device)
     ws = workspace(lib.cst_conv0_bwd_workspace(B, S, C, k, stride), wav.device)
     L.check(lib.cst_conv0_gn_gelu_bwd(L.ptr(dy), L.ptr(wav), L.ptr(w), L.ptr(gamma), L.ptr(beta), L.ptr(mean), L.ptr(rstd),
-                                      L.ptr(gram), L.ptr(dw), L.ptr(dg), L.ptr(db), L.ptr(ws), B, S, C, k, stride,
+                                      L.ptr(gram), L.ptr(dw), L.ptr(dg), L.ptr(db), L.ptr(ws), _lim(frame_limit, B), B, S, C, k, stride,
                                       L.dtype_code(w.dtype), L.stream_ptr()), "cst_conv0_gn_gelu_bwd")
     return dw, dg, db
 

@@ -9,6 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcst_hip.so")
+ABI_VERSION = 3  # include/cst.h: CST_ABI_VERSION
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
@@ -100,9 +101,9 @@ SYMBOLS = [
     ("cst_attn_fwd", c_int, [ctypes.POINTER(AttnDesc), c_p]),
     ("cst_attn_bwd", c_int, [ctypes.POINTER(AttnDesc), c_p]),
     ("cst_conv0_fwd_workspace", c_i64, [c_i64, c_i64, c_int, c_int]),
-    ("cst_conv0_gn_gelu_fwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_int, c_int, c_f, c_int, c_p]),
+    ("cst_conv0_gn_gelu_fwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_int, c_int, c_f, c_int, c_p]),
     ("cst_conv0_bwd_workspace", c_i64, [c_i64, c_i64, c_i64, c_int, c_int]),
-    ("cst_conv0_gn_gelu_bwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_p]),
+    ("cst_conv0_gn_gelu_bwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_p]),
     ("cst_glu_fwd", c_int, [c_p, c_p, c_i64, c_i64, c_int, c_p]),
     ("cst_glu_bwd", c_int, [c_p, c_p, c_p, c_i64, c_i64, c_int, c_p]),
     ("cst_act_bwd", c_int, [c_p, c_p, c_p, c_i64, c_int, c_int, c_p]),
@@ -157,6 +158,10 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    built = lib.cst_version()
+    if built != ABI_VERSION:
+        raise RuntimeError("chimera-st_amd: %s was built for ABI version %d, this package binds version %d (include/cst.h "
+                           "CST_ABI_VERSION) — rebuild it with `make -C chimera-st_amd/csrc`." % (LIB_PATH, built, ABI_VERSION))
     _lib = lib
     return lib
 

@@ -59,6 +59,7 @@ class ConvFeatureExtractionModel(nn.Module):
         weight-gradient GEMMs of each layer stop their reduction over frames there (cst_gemm_desc.k_len): exact."""
         nz = [None] * len(self.conv_spec)
         res = [None] * len(self.conv_spec)
+        lim = None
         if nz_last is not None:
             # nz[i][b]: frames of layer i that anything reads; res[i][r][b]: live rows of residue class r of layer i's input gradient
             lim = K.conv_row_limits(nz_last.to(torch.int32).contiguous(), self.conv_spec, x.shape[1])
@@ -67,7 +68,10 @@ class ConvFeatureExtractionModel(nn.Module):
                 res[i] = lim[i, 1:1 + st_]
         l0 = self.conv_layers[0]
         dim, k, stride = self.conv_spec[0]
-        y = CF.conv0_gn_gelu(x, getattr(l0, "0").weight, getattr(l0, "2").weight, getattr(l0, "2").bias, stride)
+        # layer 0 writes only the frames layer 1's live tiles read, its backward reads only the frames that carry gradient
+        y = CF.conv0_gn_gelu(x, getattr(l0, "0").weight, getattr(l0, "2").weight, getattr(l0, "2").bias, stride,
+                             write_limit=lim[0, 1] if lim is not None and len(self.conv_spec) > 1 else None,
+                             grad_limit=nz[0])
         z = None
         n = len(self.conv_spec)
         for i in range(1, n):

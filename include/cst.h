@@ -28,6 +28,10 @@
 extern "C" {
 #endif
 
+/* Bumps on any change of a signature or a descriptor layout (3: cst_gemm_desc.m_len, cst_attn_desc.seq_offsets, workspaces of the
+ * fixed-order reductions).  cst_version() returns the value the library was built with; chimera-st_amd/lib.py refuses a mismatch. */
+#define CST_ABI_VERSION 3
+
 typedef enum { CST_F32 = 0, CST_BF16 = 1 } cst_dtype;
 
 typedef enum {
@@ -221,22 +225,29 @@ int cst_attn_bwd(const cst_attn_desc* d, cst_stream stream);
  *                        each clamped to the layer's frame count
  *     out[i][1 + r][b] = max(0, ceil((nz_{i-1}[b] - r) / stride_i)) for i >= 1, r < stride_i: the live rows of residue class r of
  *                        layer i's INPUT gradient (the windowed dX GEMMs of functional.conv1d_cl)
+ *     out[0][1][b]     = frames of layer 0 that layer 1's live 256-row output tiles read: min(len_0, ceil(nz_1 / 256) 256 stride_1 +
+ *                        k_1) — what cst_conv0_gn_gelu_fwd has to write (L >= 2)
  * L <= 8, strides <= 8. */
 int cst_conv_row_limits(const int32_t* nz_last, const int32_t* k, const int32_t* stride, int L, int64_t S, int32_t* out, int64_t B,
                         int smax, cst_stream stream);
 /* workspace: cst_conv0_fwd_workspace() bytes — per-block partial moments, added up in a fixed order (no atomics: the statistics,
  * and with them the whole forward pass, are bit-reproducible run to run). */
 int64_t cst_conv0_fwd_workspace(int64_t B, int64_t S, int k, int stride);
+/* frame_limit (optional, int32 [B]): forward — frames t >= frame_limit[b] of utterance b are read by nobody (cst_conv_row_limits
+ * out[0][1]: behind the rows the next layer's live 256-row tiles reach) and are neither computed nor written (y keeps whatever the
+ * buffer held there; the GroupNorm statistics still cover all L frames, as the reference's do over the zero-padded audio);
+ * backward — dy is exactly zero from frame frame_limit[b] on (cst_conv_row_limits out[0][0]) and those frames are not read.
+ * NULL = every frame. */
 int cst_conv0_gn_gelu_fwd(const float* wav, const void* w, const void* gamma, const void* beta,
-                          void* y, float* mean, float* rstd, float* gram, float* workspace, int64_t B, int64_t S,
-                          int64_t C, int k, int stride, float eps, int dtype, cst_stream stream);
+                          void* y, float* mean, float* rstd, float* gram, float* workspace, const int32_t* frame_limit, int64_t B,
+                          int64_t S, int64_t C, int k, int stride, float eps, int dtype, cst_stream stream);
 /* dw [C,k], dgamma [C], dbeta [C] are fp32 and overwritten.
  * workspace: cst_conv0_bwd_workspace() bytes — per-block partial sums [B][blocks][k+2][C] + their fixed-order reduction
  * (no atomics: bit-reproducible gradients). */
 int64_t cst_conv0_bwd_workspace(int64_t B, int64_t S, int64_t C, int k, int stride);
 int cst_conv0_gn_gelu_bwd(const void* dy, const float* wav, const void* w, const void* gamma,
                           const void* beta, const float* mean, const float* rstd, const float* gram,
-                          float* dw, float* dgamma, float* dbeta, float* workspace,
+                          float* dw, float* dgamma, float* dbeta, float* workspace, const int32_t* frame_limit,
                           int64_t B, int64_t S, int64_t C, int k, int stride, int dtype,
                           cst_stream stream);
 

@@ -333,6 +333,51 @@ def test_conv0_gn_gelu(K, dt, B, S, C):
 
 
 @pytest.mark.parametrize("dt", DT)
+def test_conv0_frame_limits_are_exact(K, dt):
+    """cst_conv0_gn_gelu_fwd/bwd with frame_limit: forward writes exactly the frames below the limit (same bits as the unlimited call)
+    and leaves the rest of the buffer untouched; backward with a dy that is zero from the limit on gives the same bits as reading
+    every frame.  cst_conv_row_limits supplies the two limits from the real-frame counts behind the last conv layer."""
+    k, L = K
+    kk, st, B, S, C = 10, 5, 3, 16000, 512
+    wav = (0.1 * torch.randn(B, S, generator=torch.Generator().manual_seed(40))).cuda()
+    w = rnd(C, kk, dt=dt, seed=41, scale=0.5)
+    g, b = (1 + 0.1 * torch.randn(C)).to(dt).cuda(), (0.1 * torch.randn(C)).to(dt).cuda()
+    spec = [(512, 10, 5), (512, 3, 2), (512, 3, 2), (512, 2, 2)]
+    lens = [S]
+    for (_, kq, sq) in spec:
+        lens.append((lens[-1] - kq) // sq + 1)
+    nz_last = torch.tensor([lens[-1], lens[-1] // 3, 0], dtype=torch.int32, device="cuda")
+    lim = k.conv_row_limits(nz_last, spec, S)
+    # the recursion by hand
+    for bi in range(B):
+        cur = int(nz_last[bi])
+        for i in range(len(spec) - 1, 0, -1):
+            cur = min(cur, lens[i + 1])
+            assert int(lim[i, 0, bi]) == cur
+            for r in range(spec[i][2]):
+                below = (cur - 1) * spec[i][2] + spec[i][1] if cur > 0 else 0
+                assert int(lim[i, 1 + r, bi]) == max(0, -(-(min(below, lens[i]) - r) // spec[i][2]))
+            cur = (cur - 1) * spec[i][2] + spec[i][1] if cur > 0 else 0
+        assert int(lim[0, 0, bi]) == min(cur, lens[1])
+        assert int(lim[0, 1, bi]) == min(lens[1], -(-int(lim[1, 0, bi]) // 256) * 256 * spec[1][2] + spec[1][1])
+    y_full, mean, rstd, gram = k.conv0_fwd(wav, w, g, b, kk, st)
+    wl, gl = lim[0, 1].contiguous(), lim[0, 0].contiguous()
+    k.workspace  # noqa: B018 (the limited call below re-uses the same scratch)
+    y_lim, mean2, rstd2, gram2 = k.conv0_fwd(wav, w, g, b, kk, st, frame_limit=wl)
+    assert torch.equal(mean, mean2) and torch.equal(rstd, rstd2) and torch.equal(gram, gram2)
+    for bi in range(B):
+        n = int(wl[bi])
+        assert torch.equal(y_lim[bi, :n], y_full[bi, :n])
+    dy = rnd(B, y_full.shape[1], C, dt=dt, seed=42)
+    for bi in range(B):
+        dy[bi, int(gl[bi]):] = 0
+    ref = k.conv0_bwd(dy, wav, w, g, b, mean, rstd, gram, kk, st)
+    got = k.conv0_bwd(dy, wav, w, g, b, mean, rstd, gram, kk, st, frame_limit=gl)
+    for a_, b_ in zip(got, ref):
+        assert torch.equal(a_, b_)
+
+
+@pytest.mark.parametrize("dt", DT)
 def test_elementwise(K, dt):
     k, L = K
     z = rnd(77, 128, dt=dt, seed=50)

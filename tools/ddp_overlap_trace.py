@@ -173,7 +173,12 @@ def main():
     ap.add_argument("--timeout", type=int, default=900)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "ddp_trace"))
     ap.add_argument("--parse", default=None, help="only analyse the traces under this directory")
+    ap.add_argument("--collective-pattern", action="append", default=[],
+                    help="extra kernel-name substring to count as a collective (a 1-rank RCCL all-reduce is an "
+                         "__amd_rocclr_copyBuffer, not an ncclDevKernel)")
     args = ap.parse_args()
+    global COLLECTIVE
+    COLLECTIVE = tuple(COLLECTIVE) + tuple(args.collective_pattern)
     if args.parse:
         report(args.parse)
         return 0
