@@ -141,24 +141,26 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
     p.sa0 = kp->sa0; p.sa1 = kp->sa1; p.sb0 = kp->sb0; p.sb1 = kp->sb1; p.sc0 = kp->sc0; p.sc1 = kp->sc1;
     p.sbias0 = kp->sbias0; p.sbias1 = kp->sbias1; p.A = kp->A; p.B = kp->B; p.bias = kp->bias;
     p.splits = kp->splits; p.tiles_m = kp->tiles_m; p.tiles_n = kp->tiles_n;
-    const int z = v / ntiles;
+    auto fdiv = [](int n, unsigned long long magic) { return (int)(((unsigned long long)(unsigned)n * magic) >> 40); };
+    const int z = kp->nz > 1 ? fdiv(v, kp->magic_ntiles) : 0;
     int id = v - z * ntiles;
     {
-      const int q = ntiles / 8, r = ntiles % 8, xcd = id % 8, loc = id / 8;
+      const int q = ntiles >> 3, r = ntiles & 7, xcd = id & 7, loc = id >> 3;
       id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    const int GROUP_M = kp->group_m;
-    const int per_group = GROUP_M * p.tiles_n;
-    const int grp = id / per_group, rem = id % per_group;
+    const int GROUP_M = kp->group_m, per_group = kp->per_group, gshift = kp->group_shift;
+    const int grp = fdiv(id, kp->magic_per_group), rem = id - grp * per_group;
     const int gm0 = grp * GROUP_M;
     const int gsz = (p.tiles_m - gm0 < GROUP_M) ? (p.tiles_m - gm0) : GROUP_M;
-    const int tm = gm0 + rem % gsz, tn = rem / gsz;
+    int tm, tn;
+    if (gsz == GROUP_M && gshift >= 0) { tm = gm0 + (rem & (GROUP_M - 1)); tn = rem >> gshift; }
+    else { tm = gm0 + rem % gsz; tn = rem / gsz; }  // the last, partial group of a launch
     m0 = (int64_t)tm * BM;
     n0 = (int64_t)tn * BN;
     zcur = z;
-    const int split = z % p.splits;
-    const int64_t bidx = z / p.splits;
-    const int64_t b0 = bidx / p.batch1, b1 = bidx % p.batch1;
+    const int split = p.splits > 1 ? z % p.splits : 0;
+    const int64_t bidx = p.splits > 1 ? z / p.splits : z;
+    const int64_t b0 = p.batch1 > 1 ? bidx / p.batch1 : bidx, b1 = p.batch1 > 1 ? bidx % p.batch1 : 0;
     const T* A = (const T*)p.A + b0 * p.sa0 + b1 * p.sa1;
     const T* B = (const T*)p.B + b0 * p.sb0 + b1 * p.sb1;
     cofs = b0 * p.sc0 + b1 * p.sc1;
@@ -742,6 +744,16 @@ int launch8p(GemmParams p, int64_t nbatch, hipStream_t s) {
   p.tiles_n = (int)cst_ceil_div(p.N, BN);
   p.nz = (int)(nbatch * p.splits);
   const int64_t total = (int64_t)p.tiles_m * p.tiles_n * p.nz;
+  {
+    const int64_t ntl = (int64_t)p.tiles_m * p.tiles_n;
+    p.per_group = p.group_m * p.tiles_n;
+    if (total * ntl >= (1ll << 40) || total * (int64_t)p.per_group >= (1ll << 40)) { cst_set_error("cst_gemm (8-phase): too many work items"); return CST_ERR_BAD_ARG; }
+    p.magic_ntiles = ((1ull << 40) / (unsigned long long)ntl) + 1ull;
+    p.magic_per_group = ((1ull << 40) / (unsigned long long)p.per_group) + 1ull;
+    p.group_shift = -1;
+    for (int sft = 0; sft < 16; ++sft)
+      if ((1 << sft) == p.group_m) p.group_shift = sft;
+  }
   static const int ncu = [] {
     int dev = 0, n = 256;
     (void)hipGetDevice(&dev);

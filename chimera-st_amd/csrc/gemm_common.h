@@ -27,6 +27,10 @@ struct GemmParams {
   int tiles_m, tiles_n;
   int nz;  // persistent kernels: number of (batch, split) slices
   int group_m;      // gemm8p: m tiles per group of the tile walk (the patch of tiles an XCD works on concurrently)
+  // gemm8p: the item -> tile map runs once per work item on the CU's one scalar unit for all eight waves; its divisions by launch
+  // constants are multiplications by these (q = (n * magic) >> 40, exact for n * d < 2^40)
+  unsigned long long magic_ntiles, magic_per_group;
+  int per_group, group_shift;  // group_m * tiles_n; log2(group_m) or -1 if group_m is not a power of two
   int split_order;  // gemm_kernel, split-K unbatched: XCD-contiguous (split, tile) item order (see the kernel)
   int* sched;       // gemm8p: 16 zeroed ints of scheduling state (8 per-XCD item counters, 1 exit counter), nullptr = static walk
   const uint32_t* m_live; uint32_t m_epoch;  // rows of A in blocks of 64: an output tile with no live block skips its K loop
