@@ -417,6 +417,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
     }
     const bool has_next = v < total;
     if (has_next) {
+      // the claim for the item after the one set up here (published in the epilogue, read back after that item's K loop) goes out
+      // FIRST: the compiler waits for its return value right away (it has to park it across the epilogue), and here that wait covers
+      // only the atomic's own round trip — behind the four DMA below it also covered their arrival (1.6 k cycles of wave 0, for which
+      // the other seven waves then waited at the epilogue's first barrier)
+      claim_issue();
       setup(v);
       CST_STAMP(5);
       const int Sn = 4 * nt;
@@ -425,7 +430,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
       if (2 < Sn) stage(I2{}, I0{}, 0);
       if (3 < Sn) stage(I3{}, I0{}, 0);
       CST_STAMP(6);
-      claim_issue();  // the item after the one set up here; published in the epilogue, read back after that item's K loop
     }
 
     CST_STAMP(3);
