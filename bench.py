@@ -110,12 +110,14 @@ def dominant_gemm_launch(args, device):
     out = {"kernel": "gemm8p_kernel<k-major, k-major>", "shape": [M, F, D], "epilogue": "bias+gelu+aux_out", "avg_launch_ms": ms,
            "achieved": flops / ms / 1e9, "unit": "TFLOP/s", "frac": flops / ms / 1e9 / PEAK["bf16"],
            "algorithmic_bytes": 2.0 * (M * D + F * D + 2 * M * F), "traffic": None}
-    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_gemm.json")
-    if os.path.exists(pmc):
+    pmc = next((f for f in (os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", n) for n in ("r02_pmc_gemm.json", "r01_pmc_gemm.json"))
+                if os.path.exists(f)), None)
+    if pmc is not None:
         rec = json.load(open(pmc))
         if rec.get("shape") == [47968, F, D] and M == 47968:
             out["traffic"] = rec["traffic_bytes_per_launch"]
             out["traffic_note"] = rec["note"]
+            out["traffic_source"] = {"file": os.path.relpath(pmc, ROOT), "build": rec.get("build", "unrecorded")}
     return out
 
 

@@ -10,14 +10,19 @@ rocprofv3 --kernel-trace --stats -d $O/trace -o trace -- python3 $R/bench.py --s
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_mfma -o pmc -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_mfma.log 2>&1
 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum GRBM_GUI_ACTIVE -d $O/pmc_hbm -o pmc -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_hbm.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/dec_trace -o trace -- python3 $R/bench.py --mode decode > $O/dec_trace.log 2>&1
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum -d $O/pmc_one_ea -o pmc -- python3 $R/tools/gemm_one.py kk 47968 3072 768 3 fc1 > $O/pmc_one_ea.log 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $O/pmc_one_hm -o pmc -- python3 $R/tools/gemm_one.py kk 47968 3072 768 3 fc1 > $O/pmc_one_hm.log 2>&1
 cd $R
 TDB=$(find $O/trace -name '*.db' | head -1); DDB=$(find $O/dec_trace -name '*.db' | head -1)
+python tools/pmc_gemm_one.py $O/pmc_one_ea $O/pmc_one_hm 47968 3072 768 $BUILD > $O/${TAG}_pmc_gemm.json 2> $O/pmc_gemm_one.err
 python tools/kernel_stats.py $TDB 13 90 > $O/${TAG}_kernel_stats.txt 2>&1
 python tools/kernel_stats.py $DDB 1 30 > $O/${TAG}_decode_kernel_stats.txt 2>&1
 python tools/pmc_step_summary.py --trace-db $TDB $O/pmc_mfma $O/pmc_hbm > $O/${TAG}_pmc_step_summary.txt 2>&1
 python tools/pmc_gemm_class.py $O/pmc_hbm 2 $BUILD > $O/${TAG}_pmc_gemm_class.json 2> $O/pmc_gemm_class.err
 grep -h '^{' $O/trace.log > $O/${TAG}_bench_under_trace.json
-rm -rf $O/trace $O/pmc_mfma $O/pmc_hbm $O/dec_trace
+rm -rf $O/trace $O/pmc_mfma $O/pmc_hbm $O/dec_trace $O/pmc_one_ea $O/pmc_one_hm
+# the bench lines below quote the counter files of THIS build
+cp $O/${TAG}_pmc_gemm_class.json $O/${TAG}_pmc_gemm.json $R/profiles/
 python bench.py > $O/${TAG}_bench_s2t.json 2> $O/bench_s2t.err
 python bench.py --model chimera --no-cpu-baseline > $O/${TAG}_bench_chimera.json 2> $O/bench_chimera.err
 python bench.py --dropout 0 --no-cpu-baseline > $O/${TAG}_bench_dropout0.json 2> $O/bench_dropout0.err
