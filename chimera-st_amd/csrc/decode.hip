@@ -552,10 +552,10 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const T* qkv, T* kc,
 // of UNR * KPI positions are issued together and folded into per-query online-softmax state (running max, sum, output); the
 // four waves' states are merged through LDS at the end.  (The first version made three passes — scores to LDS, exp, P V — i.e.
 // twice the dependent memory round trips per wave: 51 us per layer against 37 for the flash kernel on the same shape.)
-template <typename T, int D, int BQ>
-__global__ __launch_bounds__(256, 2) void dec_cross_attn_kernel(const T* q, const T* kx, const T* vx, const uint8_t* kpm, T* out,
+template <typename T, int D, int BQ, int NW>
+__global__ __launch_bounds__(NW * 64, 8 / NW) void dec_cross_attn_kernel(const T* q, const T* kx, const T* vx, const uint8_t* kpm, T* out,
                                                                 const int32_t* stepp, int max_len, int beam, int H, int S, float scale) {
-  constexpr int VEC = DT<T>::VEC, LPK = D / VEC, KPI = 64 / LPK, UNR = 4, NW = 4;
+  constexpr int VEC = DT<T>::VEC, LPK = D / VEC, KPI = 64 / LPK, UNR = 4;
   extern __shared__ float smem[];
   if (*stepp > max_len) return;
   float* sm_m = smem;                    // [NW][BQ]
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256, 2) void dec_cross_attn_kernel(const T* q, cons
   for (int q0 = 0; q0 < beam; q0 += BQ) {
     const int nq = beam - q0 < BQ ? beam - q0 : BQ;
     __syncthreads();
-    for (int i = tid; i < BQ * D; i += 256) {
+    for (int i = tid; i < BQ * D; i += NW * 64) {
       const int qi = i / D, dd = i % D;
       sm_q[i] = qi < nq ? DT<T>::ld(q + ((int64_t)(b * beam + q0 + qi)) * C + head * D + dd) * scale : 0.0f;
     }
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256, 2) void dec_cross_attn_kernel(const T* q, cons
       }
     }
     __syncthreads();
-    for (int i = tid; i < nq * D; i += 256) {
+    for (int i = tid; i < nq * D; i += NW * 64) {
       const int qi = i / D, dd = i % D;
       float M = -INFINITY;
 #pragma unroll
@@ -986,21 +986,26 @@ int cst_dec_cross_attn(const void* q, const void* kx, const void* vx, const uint
   CST_REQUIRE(D == 32 || D == 64, "cst_dec_cross_attn: head dim %lld not in {32,64}", (long long)D);
   CST_REQUIRE(bsz > 0 && beam > 0 && H > 0 && S > 0, "cst_dec_cross_attn: bad shape");
   const int BQ = beam == 1 ? 1 : (beam <= 5 ? 5 : 8);
-  const size_t lds = ((size_t)2 * 4 * BQ + (size_t)4 * BQ * D + (size_t)BQ * D) * sizeof(float);
+  // waves per workgroup = slices the key range is cut into (each wave streams its own keys; more waves = more loads in flight)
+  static const int env_nw = getenv("CST_DEC_CROSS_NW") ? atoi(getenv("CST_DEC_CROSS_NW")) : 0;
+  const int NWv = env_nw == 8 ? 8 : 4;  // 8 measured no faster end to end (and the flash kernel remains the engine's default: 0.198 vs 0.230 s per batch)
+  const size_t lds = ((size_t)2 * NWv * BQ + (size_t)NWv * BQ * D + (size_t)BQ * D) * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   CstProfScope prof(CST_K_ATTN_FWD, s, 4.0 * bsz * beam * H * D * S, 2.0 * bsz * S * H * D * cst_dtype_size(dtype));
-#define CST_DCA(T, DD, QQ)                                                                                                      \
+#define CST_DCA_W(T, DD, QQ, WW)                                                                                                \
   do {                                                                                                                          \
     static bool attr = false;                                                                                                   \
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_cross_attn_kernel<T, DD, QQ>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; } \
-    hipLaunchKernelGGL((dec_cross_attn_kernel<T, DD, QQ>), dim3((unsigned)(bsz * H)), dim3(256), lds, s, (const T*)q, (const T*)kx, (const T*)vx, \
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_cross_attn_kernel<T, DD, QQ, WW>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; } \
+    hipLaunchKernelGGL((dec_cross_attn_kernel<T, DD, QQ, WW>), dim3((unsigned)(bsz * H)), dim3(WW * 64), lds, s, (const T*)q, (const T*)kx, (const T*)vx, \
                        key_padding_mask, (T*)out, step, (int)max_len, (int)beam, (int)H, (int)S, scale);                       \
   } while (0)
+#define CST_DCA(T, DD, QQ) do { if (NWv == 8) CST_DCA_W(T, DD, QQ, 8); else CST_DCA_W(T, DD, QQ, 4); } while (0)
 #define CST_DCA_Q(T, DD) do { if (BQ == 1) CST_DCA(T, DD, 1); else if (BQ == 5) CST_DCA(T, DD, 5); else CST_DCA(T, DD, 8); } while (0)
   if (dtype == CST_BF16) { if (D == 64) CST_DCA_Q(bf16_t, 64); else CST_DCA_Q(bf16_t, 32); }
   else { if (D == 64) CST_DCA_Q(float, 64); else CST_DCA_Q(float, 32); }
 #undef CST_DCA_Q
 #undef CST_DCA
+#undef CST_DCA_W
   return cst_check_launch("cst_dec_cross_attn");
 }
 
