@@ -46,3 +46,19 @@ def test_bench_under_a_process_group():
     d = _run(["--no-cpu-baseline", "--no-roofline"], env=dict(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                                                                 MASTER_PORT="29541", CST_DDP_FORCE="1"))
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
+
+
+def test_bench_decode_line_contract():
+    """--mode decode (BASELINE configs[4]) on a reduced workload: the same one-line contract, an HBM-bound roofline object."""
+    e = dict(os.environ)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "decode", "--steps", "1", "--warmup", "1", "--batch", "4",
+                        "--seconds", "3", "--max-len", "8"], capture_output=True, text=True, timeout=900, env=e, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.strip()]
+    assert lines and lines[-1].startswith("{") and sum(1 for l in lines if l.startswith("{")) == 1
+    d = json.loads(lines[-1])
+    assert d["unit"] == "utterances/s" and d["value"] > 0 and d["n_gpus"] == 1 and d["vs_baseline"] is None and d["dtype"] == "bf16"
+    assert d["config"]["beam"] == 5 and d["config"]["max_len"] == 8 and d["config"]["ms_per_decode_step"] > 0
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert rf["algorithmic_bytes"] > 0 and "53 graph nodes" in rf["kernel"]
