@@ -65,7 +65,9 @@ class BucketedGradAllReduce:
         self.buckets, self.param_bucket = [], {}
         hi = flat_grad.numel()
         cur_lo, cur_hi, members = hi, hi, []
-        for idx in range(len(self.params) - 1, -1, -1):
+        # (by decreasing offset: the storage order equals parameter order except inside the q | k | v groups FlatParamBuffers lays
+        #  out back to back)
+        for idx in sorted(range(len(self.params)), key=lambda i: offsets[i], reverse=True):
             lo = offsets[idx]
             if cur_hi - lo > cap and members:
                 self.buckets.append(dict(lo=cur_lo, hi=cur_hi, members=members))

@@ -428,6 +428,36 @@ def attention_packed(qkv, num_heads, key_padding_mask=None, causal=False, scale=
 
 
 # ------------------------------------------------------------------------------------------------
+# q | k | v parameters as one packed operand
+# ------------------------------------------------------------------------------------------------
+class _StackedRowsFn(torch.autograd.Function):
+    """Three parameters that sit back to back in memory (optim.FlatParamBuffers lays the q, k, v projections of a self-attention
+    module out that way) seen as ONE [3C, ...] tensor: a view, no copy.  backward hands each parameter its row block of the packed
+    gradient (views of the one tensor the dW GEMM wrote)."""
+
+    @staticmethod
+    def forward(ctx, a, b, c):
+        ctx.rows = a.shape[0]
+        return torch.as_strided(a, (3 * a.shape[0],) + tuple(a.shape[1:]), a.stride(), a.storage_offset())
+
+    @staticmethod
+    def backward(ctx, g):
+        r = ctx.rows
+        return g[:r], g[r:2 * r], g[2 * r:]
+
+
+def stacked_rows(a, b, c):
+    """cat((a, b, c), 0) for three equal-shaped parameters; free when they are adjacent in memory."""
+    n = a.numel() * a.element_size()
+    if (not _os.environ.get("CST_NO_QKV_VIEW") and a.shape == b.shape == c.shape and a.is_contiguous() and b.is_contiguous() and c.is_contiguous()
+            and a.data_ptr() + n == b.data_ptr() and b.data_ptr() + n == c.data_ptr()
+            and a.untyped_storage().data_ptr() == c.untyped_storage().data_ptr()):
+        K.STATS["qkv_view"] = K.STATS.get("qkv_view", 0) + 1
+        return _StackedRowsFn.apply(a, b, c)
+    return torch.cat((a, b, c), 0)
+
+
+# ------------------------------------------------------------------------------------------------
 # packed (padding-free) row sets — include/cst.h: cst_rows_pack / cst_rows_unpack
 # ------------------------------------------------------------------------------------------------
 class PackedRows:

@@ -288,8 +288,9 @@ class MultiheadAttention(FairseqIncrementalState, nn.Module):
         if self.self_attention and saved_state is None:
             # packed projection: one [3C, C] GEMM (and one dX / dW GEMM in backward) instead of three; the fused attention
             # kernel reads q | k | v as channel slices of the [B, T, 3C] result and writes dq | dk | dv the same way.
-            w = torch.cat((self.q_proj.weight, self.k_proj.weight, self.v_proj.weight), 0)
-            bqkv = (torch.cat((self.q_proj.bias, self.k_proj.bias, self.v_proj.bias), 0)
+            # (a view of the flat parameter buffer when the trainer laid q | k | v out back to back, a torch.cat otherwise)
+            w = CF.stacked_rows(self.q_proj.weight, self.k_proj.weight, self.v_proj.weight)
+            bqkv = (CF.stacked_rows(self.q_proj.bias, self.k_proj.bias, self.v_proj.bias)
                     if self.q_proj.bias is not None else None)
             resid_b = to_batch_major(resid) if resid is not None else None
             if resid is query and torch.is_grad_enabled() and qb.requires_grad:

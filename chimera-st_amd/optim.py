@@ -19,14 +19,32 @@ ALIGN = 8  # elements: keeps every parameter view 16-byte aligned (bf16) for the
 class FlatParamBuffers:
     """Re-home a model's parameters (and their .grad) as views of two flat tensors."""
 
-    def __init__(self, params):
+    def __init__(self, params, adjacent=None):
+        """`adjacent`: groups of parameters to be laid out back to back, in the given order (the q | k | v projection weights and
+        biases of a self-attention module: the packed [3C, C] projection is then a VIEW of the flat buffer instead of a torch.cat
+        per layer and update).  Only the storage layout changes; `self.params` keeps model.parameters() order, which is the index
+        space of the reference's optimizer state (optim/fairseq_optimizer.py)."""
         self.params = [p for p in params if p.requires_grad]
         assert len(self.params) > 0
         self.dtype, self.device = self.params[0].dtype, self.params[0].device
-        self.offsets, total = [], 0
-        for p in self.params:
+        index = {id(p): i for i, p in enumerate(self.params)}
+        lead, follow = {}, set()
+        for grp in adjacent or []:
+            ids = [index[id(p)] for p in grp if id(p) in index]
+            if len(ids) == len(grp) and all(i not in follow and i not in lead for i in ids):
+                lead[min(ids)] = ids  # the group takes the slot of its first member in parameter order
+                follow.update(i for i in ids if i != min(ids))
+        order = []
+        for i in range(len(self.params)):
+            if i in lead:
+                order.extend(lead[i])
+            elif i not in follow:
+                order.append(i)
+        self.offsets, total = [0] * len(self.params), 0
+        for i in order:
+            p = self.params[i]
             assert p.dtype == self.dtype and p.device == self.device, "all trainable parameters must share dtype/device"
-            self.offsets.append(total)
+            self.offsets[i] = total
             total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
         self.total = total
         self.flat_param = torch.zeros(total, dtype=self.dtype, device=self.device)
@@ -62,6 +80,17 @@ class FlatParamBuffers:
             for i in idxs:
                 if self.params[i].grad is not None:
                     self.params[i].grad = self.grad_views[i]
+
+
+def qkv_groups(model):
+    """Adjacency groups for FlatParamBuffers: the q, k, v projection weights (and biases) of every self-attention module."""
+    groups = []
+    for m in model.modules():
+        if getattr(m, "self_attention", False) and all(hasattr(m, n) for n in ("q_proj", "k_proj", "v_proj")):
+            groups.append([m.q_proj.weight, m.k_proj.weight, m.v_proj.weight])
+            if m.q_proj.bias is not None:
+                groups.append([m.q_proj.bias, m.k_proj.bias, m.v_proj.bias])
+    return groups
 
 
 def inverse_sqrt_lr(num_updates, lr, warmup_updates, warmup_init_lr):

@@ -13,7 +13,7 @@ import torch.distributed as dist
 
 from .distributed import DistributedFairseqModel, all_reduce_stats
 from . import rng
-from .optim import FlatParamBuffers, FusedAdam
+from .optim import FlatParamBuffers, FusedAdam, qkv_groups
 
 
 class Trainer:
@@ -26,7 +26,7 @@ class Trainer:
                                       "bf16 needs no loss scaling (DESIGN.md)")
         model = model.to(device=self.device, dtype=dtype)  # trainer.py:70-78
         self.criterion = criterion.to(self.device)
-        self.buffers = FlatParamBuffers(model.parameters())
+        self.buffers = FlatParamBuffers(model.parameters(), adjacent=qkv_groups(model))
         self.optimizer = FusedAdam.from_args(args, None, buffers=self.buffers)
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0

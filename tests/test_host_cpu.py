@@ -163,6 +163,56 @@ def _ddp_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def test_qkv_parameters_laid_out_back_to_back_are_one_view():
+    """FlatParamBuffers(adjacent=qkv_groups(model)) puts the q | k | v projections of a self-attention module next to each other;
+    functional.stacked_rows then returns the packed [3C, C] operand as a VIEW (no copy) and its backward hands each parameter its
+    block of the packed gradient.  The optimizer-state index space (model.parameters() order) is unchanged."""
+    optim = import_module("chimera-st_amd.optim")
+    CF = import_module("chimera-st_amd.functional")
+    torch.manual_seed(0)
+
+    class Attn(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.self_attention = True
+            # fairseq registration order: k, v, q, out (modules/multihead_attention.py:70-82)
+            self.k_proj, self.v_proj, self.q_proj = torch.nn.Linear(16, 16), torch.nn.Linear(16, 16), torch.nn.Linear(16, 16)
+            self.out_proj = torch.nn.Linear(16, 16)
+
+    net = torch.nn.Sequential(torch.nn.Linear(16, 16), Attn(), torch.nn.Linear(16, 8))
+    before = [p.detach().clone() for p in net.parameters()]
+    buf = optim.FlatParamBuffers(net.parameters(), adjacent=optim.qkv_groups(net))
+    assert [id(p) for p in buf.params] == [id(p) for p in net.parameters()]  # index space untouched
+    for p, b in zip(net.parameters(), before):
+        assert torch.equal(p, b)
+    spans = sorted((o, o + p.numel()) for p, o in zip(buf.params, buf.offsets))
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])) and spans[-1][1] <= buf.total  # disjoint slots
+    a = net[1]
+    w = CF.stacked_rows(a.q_proj.weight, a.k_proj.weight, a.v_proj.weight)
+    bq = CF.stacked_rows(a.q_proj.bias, a.k_proj.bias, a.v_proj.bias)
+    assert w.data_ptr() == a.q_proj.weight.data_ptr() and bq.data_ptr() == a.q_proj.bias.data_ptr()
+    assert torch.equal(w, torch.cat((a.q_proj.weight, a.k_proj.weight, a.v_proj.weight), 0))
+    x = torch.randn(5, 16)
+    (torch.nn.functional.linear(x, w, bq) ** 2).sum().backward()
+    ref = torch.cat((a.q_proj.weight, a.k_proj.weight, a.v_proj.weight), 0).detach().requires_grad_(True)
+    refb = torch.cat((a.q_proj.bias, a.k_proj.bias, a.v_proj.bias), 0).detach().requires_grad_(True)
+    (torch.nn.functional.linear(x, ref, refb) ** 2).sum().backward()
+    got = torch.cat((a.q_proj.weight.grad, a.k_proj.weight.grad, a.v_proj.weight.grad), 0)
+    assert torch.allclose(got, ref.grad) and torch.allclose(torch.cat((a.q_proj.bias.grad, a.k_proj.bias.grad, a.v_proj.bias.grad)), refb.grad)
+    # not adjacent (no buffers): falls back to a copy
+    free = Attn()
+    w2 = CF.stacked_rows(free.q_proj.weight, free.k_proj.weight, free.v_proj.weight)
+    assert w2.data_ptr() != free.q_proj.weight.data_ptr() and w2.shape == (48, 16)
+    # the reducer cuts its buckets by storage position, whatever the parameter order
+    D = import_module("chimera-st_amd.distributed")
+    red = D.BucketedGradAllReduce(buf.params, buf.offsets, buf.flat_grad, None, bucket_cap_mb=1e-3)
+    seen = sorted(i for b in red.buckets for i in b["members"])
+    assert seen == list(range(len(buf.params)))
+    for b in red.buckets:
+        for i in b["members"]:
+            assert b["lo"] <= buf.offsets[i] and buf.offsets[i] + buf.params[i].numel() <= b["hi"]
+
+
 def test_bucketed_all_reduce_gloo_world2():
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
