@@ -285,29 +285,25 @@ class Wav2Vec2Model(nn.Module):
                 if m is not None:
                     heads += list(m.parameters())
             notify_unused_parameters(heads)
-        plan = None
-        if padding_mask is not None and self.encoder.wants_packing(padding_mask):
-            # the packing plan needs two integers on the host (rows in total, longest sequence): read them HERE, before the CNN is
-            # queued — the stream is empty at this point of an update, later it would drain 20 ms of queued convolutions
-            t1 = self.feature_extractor.output_length(source.shape[1])
-            pm = padding_mask
-            extra = pm.size(1) % t1
-            if extra > 0:
-                pm = pm[:, :-extra]
-            plan = CF.plan_packed_rows(pm.view(pm.size(0), t1, -1).all(-1), self.encoder.packing_margin())
-        self.last_plan = plan  # (the caller's own layer stack derives its packing plan from this one's host lengths)
-        nz_last = None
+        # the frame-level padding mask of :543-548 is a function of the sample-level one and the CNN's output length: computed ONCE,
+        # before the CNN is queued (it serves the packing plan, the conv frame limits and the encoder's key mask)
+        frame_mask, plan, nz_last = None, None, None
         if padding_mask is not None:
-            # the frame-level padding mask of :543-548, known before the CNN runs: frames past the last real one get a zero gradient
-            # (they are overwritten with zeros at the encoder input), which bounds every conv layer's weight-gradient reduction
             t1 = self.feature_extractor.output_length(source.shape[1])
             pm = padding_mask
             extra = pm.size(1) % t1
             if extra > 0:
                 pm = pm[:, :-extra]
-            fm = pm.view(pm.size(0), t1, -1).all(-1)
-            pos = torch.arange(1, t1 + 1, device=fm.device, dtype=torch.int32)
-            nz_last = (pos * (~fm)).amax(dim=1).to(torch.int32)
+            frame_mask = pm.view(pm.size(0), t1, -1).all(-1)
+            if self.encoder.wants_packing(padding_mask):
+                # the packing plan needs a few integers on the host (rows in total, longest sequence, lengths): read them HERE — the
+                # stream is empty at this point of an update, later the read would drain 20 ms of queued convolutions
+                plan = CF.plan_packed_rows(frame_mask, self.encoder.packing_margin())
+            # frames past the last real one get a zero gradient (they are overwritten with zeros at the encoder input), which bounds
+            # every conv layer's weight-gradient reduction and the frames the CNN has to compute at all
+            pos = torch.arange(1, t1 + 1, device=frame_mask.device, dtype=torch.int32)
+            nz_last = (pos * (~frame_mask)).amax(dim=1).to(torch.int32)
+        self.last_plan = plan  # (the caller's own layer stack derives its packing plan from this one's host lengths)
         feats = self.feature_extractor(source, nz_last)  # [B, T1, C] channels-last
         if self.feature_grad_mult <= 0:
             feats = feats.detach()
@@ -315,11 +311,8 @@ class Wav2Vec2Model(nn.Module):
             feats = _GradMultiply.apply(feats, self.feature_grad_mult)
         feats = self.layer_norm(feats)  # transpose(1,2) is free in channels-last (:539-540)
         if padding_mask is not None:
-            t1 = feats.size(1)
-            extra = padding_mask.size(1) % t1
-            if extra > 0:
-                padding_mask = padding_mask[:, :-extra]
-            padding_mask = padding_mask.view(padding_mask.size(0), t1, -1).all(-1)
+            assert feats.size(1) == frame_mask.size(1)
+            padding_mask = frame_mask
         if self.post_extract_proj is not None:
             feats = self.post_extract_proj(feats)
         if self.training and self.dropout_input_p > 0:
