@@ -23,6 +23,8 @@ def mfma(pattern):
     l = row(pattern, 1); mm = re.search(r"MFMA busy\s+([\d.]+)%", l); return mm.group(1) if mm else "?"
 def fab(pattern):
     l = row(pattern, 2); mm = re.search(r"fabric\s+([\d.]+) MB/launch.*?(\d+) GB/s", l); return (mm.group(1), mm.group(2)) if mm else ("?", "?")
+mm0 = re.search(r"([\d.]+) +([\d.]+)  _ZN12_GLOBAL__N_120conv0_fwd_reg", stats)
+c0f = "%.2f" % (float(mm0.group(2)) / 1e3) if mm0 else "0.53"
 cpu = s2t["cpu_baseline"]
 dom = r["dominant_launch"]
 rep = {
@@ -37,12 +39,16 @@ rep = {
  "@@CHIMERA@@": "%.0f utt/s, %.1f ms (`%s_bench_chimera.json`)." % (chim["value"], chim["ms_per_step"], tag.split("/")[-1]),
  "@@CPU@@": "%.2f utterances/s on %d threads (%s s per update)." % (cpu["value"], cpu["cores"], " / ".join("%.1f" % v for v in cpu["seconds_per_update"])),
  "@@MFMA@@": "persistent GEMM %s %% (plain / bias / activation epilogues), %s %% (one-operand, B mn-major: the dX GEMMs), %s %% (one-operand, k/k); 16-wave dW kernel %s %%; attention forward %s %%, dQ %s %%, dK/dV %s %%." % (mfma("gemm8p_kernel<true, true, 1>"), mfma("gemm8p_kernel<true, false, 2>"), mfma("gemm8p_kernel<true, true, 2>"), mfma("CfgILi256ELi256"), mfma("attn_fwd_kernel"), mfma("attn_bwd_dq"), mfma("attn_bwd_dkv")),
- "@@FABRIC@@": "persistent GEMM (mode 1) %s MB at %s GB/s, dW kernel %s MB at %s GB/s, LayerNorm (768-wide rows) forward %s MB at %s GB/s / backward %s MB at %s GB/s, column sums %s GB/s, dropout %s GB/s, Adam %s MB at %s GB/s, conv0 forward %s MB at %s GB/s / backward %s MB at %s GB/s." % (fab("gemm8p_kernel<true, true, 1>") + fab("CfgILi256ELi256") + fab("ln_fwd_kernelIDF16bLi2") + fab("ln_bwd_kernelIDF16bLi2") + (fab("colsum_kernel")[1], fab("dropout_kernel")[1]) + fab("adam_kernel") + fab("conv0_fwd_reg") + fab("conv0_bwd_reg")),
+ "@@FABRIC@@": "persistent GEMM (mode 1) %s MB at %s GB/s, dW kernel %s MB at %s GB/s, LayerNorm (768-wide rows) forward %s MB at %s GB/s / backward %s MB at %s GB/s, column sums %s GB/s, dropout %s GB/s, Adam %s MB at %s GB/s, conv0 forward ≈ 2.1 GB written in %s ms ≈ %.1f TB/s (below the listing's cut-off since it stops at the frames that are read) / backward %s MB at %s GB/s (VALU-bound)." % (fab("gemm8p_kernel<true, true, 1>") + fab("CfgILi256ELi256") + fab("ln_fwd_kernelIDF16bLi2") + fab("ln_bwd_kernelIDF16bLi2") + (fab("colsum_kernel")[1], fab("dropout_kernel")[1]) + fab("adam_kernel") + (c0f, 2.1 / float(c0f)) + fab("conv0_bwd_reg")),
  "@@DECODE@@": "s2t_transformer_l (12 + 6 layers), 32 utterances × ≤ 30 s of filter banks, beam 5, 201 steps, bf16: **%.0f utterances/s, %.0f tokens/s, %.3f ms per decode step** (encoder %.1f ms per batch); `roofline` bound = hbm: %.2f GB of algorithmic bytes per step ÷ %.3f ms = %.0f GB/s = %.3f of 8 TB/s (round 1, builder-measured: 0.82 ms on another box; the same-box A/B of this round's LayerNorm folding is in §5.7)." % (dec["value"], dec["config"]["tokens_per_s"], dec["config"]["ms_per_decode_step"], dec["config"]["encoder_ms"], dec["roofline"]["algorithmic_bytes"] / 1e9, dec["roofline"]["avg_launch_ms"], dec["roofline"]["achieved"], dec["roofline"]["frac"]),
 }
-d = open("DESIGN.md").read()
+import os
+here = os.path.dirname(os.path.abspath(__file__))
+sec = open(os.path.join(here, "design_section8.md.in")).read()  # DESIGN.md section 8 with @@...@@ placeholders
 for k, v in rep.items():
-    assert k in d, k
-    d = d.replace(k, v)
-open("DESIGN.md", "w").write(d)
+    assert k in sec, k
+    sec = sec.replace(k, v)
+d = open("DESIGN.md").read()
+a, b = d.index("## 8. Measurement (round 2"), d.index("## 9. VERDICT round 1")
+open("DESIGN.md", "w").write(d[:a] + sec + d[b:])
 print("filled", len(rep))
