@@ -27,4 +27,5 @@ python bench.py > $O/${TAG}_bench_s2t.json 2> $O/bench_s2t.err
 python bench.py --model chimera --no-cpu-baseline > $O/${TAG}_bench_chimera.json 2> $O/bench_chimera.err
 python bench.py --dropout 0 --no-cpu-baseline > $O/${TAG}_bench_dropout0.json 2> $O/bench_dropout0.err
 python bench.py --mode decode > $O/${TAG}_bench_decode.json 2> $O/bench_decode.err
+python bench.py --lengths max --no-cpu-baseline > $O/${TAG}_bench_maxlen.json 2> $O/bench_maxlen.err
 ls -la $O; du -sh $O
