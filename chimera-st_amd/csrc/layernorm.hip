@@ -14,26 +14,74 @@ constexpr int LN_WAVES = 4;      // rows per block iteration
 // backward kernel allocates 160 VGPRs (3 waves per SIMD) for the 768-column rows of wav2vec2 that need 2 vectors (100 VGPRs, 5 waves
 // per SIMD) — a row is only 1.5 KB, so the bytes in flight, i.e. the HBM rate, scale with the resident waves.
 
+// 8 elements of a row in storage form
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> {
+  u32x4 r;
+  __device__ __forceinline__ void load(const bf16_t* p) { r = *reinterpret_cast<const u32x4*>(p); }
+  __device__ __forceinline__ void unpack(float (&v)[8]) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(r[i] << 16); v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
+  }
+};
+template <> struct Raw8<float> {
+  float f[8];
+  __device__ __forceinline__ void load(const float* p) { load8(p, f); }
+  __device__ __forceinline__ void unpack(float (&v)[8]) const {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = f[i];
+  }
+};
+
 template <typename T, int NV>
 __global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(const T* x, const T* res, const T* gamma, const T* beta,
                                                               T* y, T* sum_out, float* mean, float* rstd,
                                                               int64_t rows, int cols, float eps) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = cols / 8;
-  for (int64_t row = (int64_t)blockIdx.x * LN_WAVES + wave; row < rows; row += (int64_t)gridDim.x * LN_WAVES) {
+  // gamma / beta stay in registers in their storage form for the whole grid-stride loop; the NEXT row's loads are issued before this
+  // row's statistics (a row is 1-2 KB: one row per wave in flight left the memory pipe idle during the two wave reductions)
+  Raw8<T> gq[NV], bq[NV], nx[NV], nr[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (lane + 64 * i < nvec) { gq[i].load(gamma + (lane + 64 * i) * 8); bq[i].load(beta + (lane + 64 * i) * 8); }
+  const int64_t row0 = (int64_t)blockIdx.x * LN_WAVES + wave, rstep = (int64_t)gridDim.x * LN_WAVES;
+  if (row0 < rows) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + 64 * i < nvec) {
+        nx[i].load(x + row0 * cols + (lane + 64 * i) * 8);
+        if (res) nr[i].load(res + row0 * cols + (lane + 64 * i) * 8);
+      }
+  }
+  for (int64_t row = row0; row < rows; row += rstep) {
     float v[NV][8];
     float s = 0.0f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int vi = lane + 64 * i;
       if (vi < nvec) {
-        load8(x + row * cols + vi * 8, v[i]);
+        nx[i].unpack(v[i]);
         if (res) {
           float r[8];
-          load8(res + row * cols + vi * 8, r);
+          nr[i].unpack(r);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[i][e] += r[e];
         }
+      }
+    }
+    if (row + rstep < rows) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < nvec) {
+          nx[i].load(x + (row + rstep) * cols + (lane + 64 * i) * 8);
+          if (res) nr[i].load(res + (row + rstep) * cols + (lane + 64 * i) * 8);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int vi = lane + 64 * i;
+      if (vi < nvec) {
         if (sum_out) store8(sum_out + row * cols + vi * 8, v[i]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) s += v[i][e];
@@ -53,8 +101,8 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(const T* x, const
       const int vi = lane + 64 * i;
       if (vi < nvec) {
         float g[8], b[8], o[8];
-        load8(gamma + vi * 8, g);
-        load8(beta + vi * 8, b);
+        gq[i].unpack(g);
+        bq[i].unpack(b);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mu) * rs * g[e] + b[e];
         store8(y + row * cols + vi * 8, o);
@@ -63,25 +111,6 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(const T* x, const
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
   }
 }
-
-// 8 elements of a row in storage form
-template <typename T> struct Raw8;
-template <> struct Raw8<bf16_t> {
-  u32x4 r;
-  __device__ __forceinline__ void load(const bf16_t* p) { r = *reinterpret_cast<const u32x4*>(p); }
-  __device__ __forceinline__ void unpack(float (&v)[8]) const {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(r[i] << 16); v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
-  }
-};
-template <> struct Raw8<float> {
-  float f[8];
-  __device__ __forceinline__ void load(const float* p) { load8(p, f); }
-  __device__ __forceinline__ void unpack(float (&v)[8]) const {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = f[i];
-  }
-};
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma;  partial dgamma/dbeta per block.
 template <typename T, int NV>
