@@ -631,6 +631,36 @@ __global__ void splitk_reduce_kernel(GemmParams p) {
   const int64_t cofs = b0 * p.sc0 + b1 * p.sc1;
   const int64_t bofs = b0 * p.sbias0 + b1 * p.sbias1;
   const float* ws = p.ws + bidx * p.splits * total;
+  if (p.vec_epi && (p.N % 8) == 0) {
+    // 8 consecutive columns per thread: 16-byte loads, four splits' loads in flight, ONE row/column division per 8 elements, the vector
+    // epilogue.  The slabs are added in split order, as in the scalar loop below (same bits).
+    const int64_t total8 = total >> 3;
+    for (int64_t i8 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i8 < total8; i8 += (int64_t)gridDim.x * blockDim.x) {
+      const float* src = ws + i8 * 8;
+      float v[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+      int sp = 0;
+      for (; sp + 4 <= p.splits; sp += 4) {
+        f32x4 a[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          a[u][0] = *reinterpret_cast<const f32x4*>(src + (int64_t)(sp + u) * total);
+          a[u][1] = *reinterpret_cast<const f32x4*>(src + (int64_t)(sp + u) * total + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] += a[u][0][e]; v[4 + e] += a[u][1][e]; }
+      }
+      for (; sp < p.splits; ++sp) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(src + (int64_t)sp * total), a1 = *reinterpret_cast<const f32x4*>(src + (int64_t)sp * total + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += a0[e]; v[4 + e] += a1[e]; }
+      }
+      const int64_t i = i8 * 8, row = i / p.N;
+      epilogue_store8<T>(p, cofs, bofs, row, i - row * p.N, v);
+    }
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     float v = 0.0f;
     for (int s = 0; s < p.splits; ++s) v += ws[s * total + i];
@@ -907,7 +937,8 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
   if (rc != CST_OK) return rc;
   if (p.splits > 1) {
     const int64_t total = d->M * d->N;
-    int blocks = (int)(cst_ceil_div(total, 256) < 2048 ? cst_ceil_div(total, 256) : 2048);
+    const int64_t work = (p.vec_epi && d->N % 8 == 0) ? total / 8 : total;  // items the reduce kernel's threads walk
+    int blocks = (int)(cst_ceil_div(work, 256) < 2048 ? cst_ceil_div(work, 256) : 2048);
     dim3 grid(blocks, (unsigned)nbatch);
     if (d->dtype == CST_BF16) hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(splitk_reduce_kernel<float>, grid, dim3(256), 0, s, p);
