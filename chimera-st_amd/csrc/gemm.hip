@@ -917,6 +917,7 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
   // act'(aux_in) epilogues: taken since the operand vectors are requested in one burst ahead of the epilogue passes (gemm8p.hip)
   static const bool dact_8p = getenv("CST_GEMM_8P_NO_DACT") == nullptr;
   static const bool no_skinny = getenv("CST_GEMM_NO_SKINNY") != nullptr;
+  static const int64_t skinny_tiles = getenv("CST_GEMM_SKINNY_TILES") ? atoll(getenv("CST_GEMM_SKINNY_TILES")) : 256;  // measured: 256 -0.3 ms per update, 512 no better than 0
   static const bool no_narrow = getenv("CST_GEMM_NO_NARROW") != nullptr;
   if (!no_narrow && !seg && !large && ak && bk && d->N <= 64 && d->M > 256) {
     rc = d->dtype == CST_BF16 ? launch_glds<bf16_t, true, true, CfgNarrowN, 2>(p, d->M, d->N, nbatch, s)
@@ -924,7 +925,10 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
   } else if (!no_narrow && !seg && !large && !ak && !bk && d->M <= 64 && d->N > 256) {
     rc = d->dtype == CST_BF16 ? launch<bf16_t, false, false, false, CfgNarrowM>(p, d->M, d->N, nbatch, s)
                               : launch<float, false, false, false, CfgNarrowM>(p, d->M, d->N, nbatch, s);
-  } else if (!no_skinny && ak && bk && !seg && d->M <= 256 && nbatch == 1 && p.splits == 1) {
+  } else if (!no_skinny && ak && bk && !seg && nbatch == 1 && p.splits == 1 &&
+             (d->M <= 256 || (!large && cst_ceil_div(d->M, 128) * cst_ceil_div(d->N, 128) < skinny_tiles))) {
+    // (mid-size problems too — decoder-sized Linear layers: fewer than one 128 x 128 tile per CU leaves CUs idle; 64 x 64 tiles
+    //  quadruple the workgroups)
     rc = d->dtype == CST_BF16 ? launch_glds<bf16_t, true, true, CfgSkinny, 4>(p, d->M, d->N, nbatch, s)
                               : launch_glds<float, true, true, CfgSkinny, 4>(p, d->M, d->N, nbatch, s);
   } else if (d->dtype == CST_BF16 && !seg && !no_8p && (ak || all_8p || force_8p) && (!d->dact || (dact_8p && !d->resid && !d->aux_out) || all_8p || force_8p) && (large || force_8p) && cst_gemm8p_supported(p, ak, bk, nbatch))
