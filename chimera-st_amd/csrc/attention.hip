@@ -311,24 +311,30 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_fwd_ke
 // to dQ, dK and dV (dP = dO V^T = 0, delta = 0 -> dS = P (0 - 0) = 0): the backward kernels stop at the last live tile.
 template <typename T, int D>
 __global__ __launch_bounds__(64) void attn_delta_kernel(AttnParams p) {
+  // D / 8 lanes per query row (16 bytes each: a load instruction fetches whole 128-byte head rows of 64 / (D / 8) queries), the dot
+  // product is finished by a butterfly over those lanes
+  constexpr int LPR = D / 8, RPI = 64 / LPR;
   const int64_t b = blockIdx.z, h = blockIdx.y;
   const int qt = blockIdx.x, lane = threadIdx.x;
-  const int64_t q = (int64_t)qt * 64 + lane;
+  const int rl = lane / LPR, c8 = (lane % LPR) * 8;
   bool nz = false;
   const SeqView sv = seq_view(p, b);
-  if (q < sv.tq) {
-    const T* o = (const T*)p.O + (p.seq_off ? sv.row0 * p.o_st : b * p.o_sb) + h * p.o_sh + q * p.o_st;
-    const T* g = (const T*)p.dO + (p.seq_off ? sv.row0 * p.do_st : b * p.do_sb) + h * p.do_sh + q * p.do_st;
-    float acc = 0.0f;
+  const T* obase = (const T*)p.O + (p.seq_off ? sv.row0 * p.o_st : b * p.o_sb) + h * p.o_sh + c8;
+  const T* gbase = (const T*)p.dO + (p.seq_off ? sv.row0 * p.do_st : b * p.do_sb) + h * p.do_sh + c8;
 #pragma unroll
-    for (int d = 0; d < D; d += 8) {
+  for (int it = 0; it < 64 / RPI; ++it) {
+    const int64_t q = (int64_t)qt * 64 + it * RPI + rl;
+    float acc = 0.0f;
+    if (q < sv.tq) {
       float a[8], c[8];
-      load8(o + d, a);
-      load8(g + d, c);
+      load8(obase + q * p.o_st, a);
+      load8(gbase + q * p.do_st, c);
 #pragma unroll
       for (int e = 0; e < 8; ++e) { acc += a[e] * c[e]; nz = nz || c[e] != 0.0f; }
     }
-    p.delta[(b * p.H + h) * p.Tq + q] = acc;
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    if (q < sv.tq && (lane % LPR) == 0) p.delta[(b * p.H + h) * p.Tq + q] = acc;
   }
   const unsigned long long m = __ballot(nz);
   if (p.q_flags && lane == 0) p.q_flags[(b * p.H + h) * ((p.Tq + 63) / 64) + qt] = m != 0ull ? 1 : 0;
