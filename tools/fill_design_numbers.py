@@ -6,7 +6,7 @@ def J(name):
     for l in open("%s_%s.json" % (tag, name)):
         if l.startswith("{"):
             return json.loads(l)
-s2t, chim, d0, dec = J("bench_s2t"), J("bench_chimera"), J("bench_dropout0"), J("bench_decode")
+s2t, chim, d0, dec, mx = J("bench_s2t"), J("bench_chimera"), J("bench_dropout0"), J("bench_decode"), J("bench_maxlen")
 r = s2t["roofline"]; pc = r["per_class_ms"]
 stats = open("%s_kernel_stats.txt" % tag).read()
 m = re.search(r"= (\d+) launches per update; kernel time ([\d.]+) ms", stats)
@@ -35,6 +35,7 @@ rep = {
  "@@ROOF@@": "%.0f TFLOP/s of 2500 (`frac` %.3f) over %d launches, average %.3f ms." % (r["achieved"], r["frac"], r["launches"], r["avg_launch_ms"]),
  "@@TRAFFIC@@": "%.0f MB against %.0f MB algorithmic = %.2f × (round 1: 372 vs 247 MB = 1.5 ×)." % (r["traffic"] / 1e6, r["algorithmic_bytes"] / 1e6, r["traffic"] / r["algorithmic_bytes"]) if r.get("traffic") else "n/a",
  "@@DOM@@": "%.3f ms, %.0f TF/s (`frac` %.3f), fabric traffic %.0f MB vs %.0f MB algorithmic." % (dom["avg_launch_ms"], dom["achieved"], dom["frac"], dom["traffic"] / 1e6, dom["algorithmic_bytes"] / 1e6),
+ "@@MAXLEN@@": "%.0f utt/s, %.1f ms per update; GEMM class %.1f ms = %.0f TFLOP/s (`frac` %.3f) over the full 44 TFLOP, attention %.1f + %.1f ms (`%s_bench_maxlen.json`)." % (mx["value"], mx["ms_per_step"], mx["roofline"]["per_class_ms"]["gemm"], mx["roofline"]["achieved"], mx["roofline"]["frac"], mx["roofline"]["per_class_ms"]["attn_fwd"], mx["roofline"]["per_class_ms"]["attn_bwd"], tag.split("/")[-1]),
  "@@D0@@": "%.0f utt/s, %.1f ms (`%s_bench_dropout0.json`)." % (d0["value"], d0["ms_per_step"], tag.split("/")[-1]),
  "@@CHIMERA@@": "%.0f utt/s, %.1f ms (`%s_bench_chimera.json`)." % (chim["value"], chim["ms_per_step"], tag.split("/")[-1]),
  "@@CPU@@": "%.2f utterances/s on %d threads (%s s per update)." % (cpu["value"], cpu["cores"], " / ".join("%.1f" % v for v in cpu["seconds_per_update"])),
