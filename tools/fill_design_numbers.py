@@ -25,6 +25,13 @@ def fab(pattern):
     l = row(pattern, 2); mm = re.search(r"fabric\s+([\d.]+) MB/launch.*?(\d+) GB/s", l); return (mm.group(1), mm.group(2)) if mm else ("?", "?")
 mm0 = re.search(r"([\d.]+) +([\d.]+)  _ZN12_GLOBAL__N_120conv0_fwd_reg", stats)
 c0f = "%.2f" % (float(mm0.group(2)) / 1e3) if mm0 else "0.53"
+gn = gt = rt = 0.0
+for line in stats.splitlines():
+    mm1 = re.match(r"\s*([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+(.*)", line)
+    if mm1 and "gemm" in mm1.group(4) and "splitk_reduce" not in mm1.group(4):
+        gn += float(mm1.group(1)); gt += float(mm1.group(2))
+    elif mm1 and "splitk_reduce" in mm1.group(4):
+        rt += float(mm1.group(2))
 cpu = s2t["cpu_baseline"]
 dom = r["dominant_launch"]
 rep = {
@@ -33,6 +40,7 @@ rep = {
  "@@CONV0@@": "%.1f" % pc["conv0"], "@@EW@@": "%.1f" % pc["elementwise"], "@@OPT@@": "%.2f" % (pc["optim"] + pc["loss"]),
  "@@LAUNCHES@@": "%d" % launches,
  "@@ROOF@@": "%.0f TFLOP/s of 2500 (`frac` %.3f) over %d launches, average %.3f ms." % (r["achieved"], r["frac"], r["launches"], r["avg_launch_ms"]),
+ "@@TRACEGEMM@@": "%.0f GEMM launches per update, %.1f ms + %.1f ms of split-K reduces, which sit inside the same event pairs, = %.1f ms against %.1f ms from the event table (the box ran %.0f %% slower under the tracer)." % (gn, gt, rt, gt + rt, pc["gemm"], 100.0 * (J("bench_under_trace")["ms_per_step"] / s2t["ms_per_step"] - 1.0)),
  "@@TRAFFIC@@": "%.0f MB against %.0f MB algorithmic = %.2f × (round 1: 372 vs 247 MB = 1.5 ×)." % (r["traffic"] / 1e6, r["algorithmic_bytes"] / 1e6, r["traffic"] / r["algorithmic_bytes"]) if r.get("traffic") else "n/a",
  "@@DOM@@": "%.3f ms, %.0f TF/s (`frac` %.3f), fabric traffic %.0f MB vs %.0f MB algorithmic." % (dom["avg_launch_ms"], dom["achieved"], dom["frac"], dom["traffic"] / 1e6, dom["algorithmic_bytes"] / 1e6),
  "@@MAXLEN@@": "%.0f utt/s, %.1f ms per update; GEMM class %.1f ms = %.0f TFLOP/s (`frac` %.3f) over the full 44 TFLOP, attention %.1f + %.1f ms (`%s_bench_maxlen.json`)." % (mx["value"], mx["ms_per_step"], mx["roofline"]["per_class_ms"]["gemm"], mx["roofline"]["achieved"], mx["roofline"]["frac"], mx["roofline"]["per_class_ms"]["attn_fwd"], mx["roofline"]["per_class_ms"]["attn_bwd"], tag.split("/")[-1]),
