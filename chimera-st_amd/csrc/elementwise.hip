@@ -70,10 +70,27 @@ __global__ void act_fwd_kernel(const T* x, T* y, int64_t n8, int act) {
 // block = 256 threads = 16 row-lanes x 16 column vectors (128 columns): each half-wave reads a 256-B row segment, 4 row
 // loads in flight per thread; LDS combine over the 16 row-lanes; one fp32 atomic per column per block (<= ~200 blocks per
 // column, so the atomics are not the bottleneck).
-template <typename T, bool PART = false>
+// DROP: x is first multiplied by its dropout factors (FairseqDropout backward: the same mask as forward, element index = r * cols + c),
+// the masked rows are written to xd in the storage dtype, and the column sums are taken over those STORED values — the same bits as
+// cst_dropout followed by cst_colsum_typed, in one pass over the gradient instead of three.
+template <typename T, bool PART = false, bool DROP = false>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* x, int64_t ldx, float* out, int64_t rows, int64_t cols, int64_t rows_per,
-                                                     const uint32_t* row_live = nullptr, uint32_t epoch = 0) {
+                                                     const uint32_t* row_live = nullptr, uint32_t epoch = 0, T* xd = nullptr,
+                                                     uint32_t dkey = 0, uint32_t dthr = 0, float dscale = 1.0f) {
   __shared__ float red[16][16 * 8 + 1];
+  auto masked = [&](float (&v)[8], int64_t r, int64_t c0) {  // mask, round to storage, store; v returns the stored values
+    cst_drop8(v, dkey, (uint64_t)(r * cols + c0), dthr, dscale);
+    store8(xd + r * ldx + c0, v);
+    if (sizeof(T) == 2) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = bf16_bits_to_f32(f32_to_bf16_bits(v[e]));
+    } else {
+      // fp32: the stored value is the rounded product; keep the compiler from contracting x * factor into the sums below (an fma
+      // would add the unrounded product and differ from dropout-then-colsum in the last bit)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(v[e]));
+    }
+  };
   const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
   const int64_t cv = (int64_t)blockIdx.x * 16 + cl;
   const bool ok = cv * 8 < cols;
@@ -85,18 +102,27 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* x, int64_t ldx, fl
     for (; r + 48 < r1; r += 64) {
       // rows_per is a multiple of 64 when stamps are given: this iteration is exactly the 64-row tile (r - g) / 64; a tile whose
       // stamp is not this epoch holds only zero rows and adds nothing
-      if (row_live && row_live[(r - g) >> 6] != epoch) continue;
+      if (row_live && row_live[(r - g) >> 6] != epoch) {
+        if (DROP) {  // an all-zero tile stays all zero under the mask
+          float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          store8(xd + r * ldx + cv * 8, z); store8(xd + (r + 16) * ldx + cv * 8, z);
+          store8(xd + (r + 32) * ldx + cv * 8, z); store8(xd + (r + 48) * ldx + cv * 8, z);
+        }
+        continue;
+      }
       float v0[8], v1[8], v2[8], v3[8];
       load8(x + r * ldx + cv * 8, v0);
       load8(x + (r + 16) * ldx + cv * 8, v1);
       load8(x + (r + 32) * ldx + cv * 8, v2);
       load8(x + (r + 48) * ldx + cv * 8, v3);
+      if (DROP) { masked(v0, r, cv * 8); masked(v1, r + 16, cv * 8); masked(v2, r + 32, cv * 8); masked(v3, r + 48, cv * 8); }
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] += (v0[e] + v1[e]) + (v2[e] + v3[e]);
     }
     for (; r < r1; r += 16) {
       float v[8];
       load8(x + r * ldx + cv * 8, v);
+      if (DROP) masked(v, r, cv * 8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] += v[e];
     }
@@ -356,6 +382,28 @@ static int colsum_typed_impl(const void* x, int64_t ldx, void* out, void* worksp
   if (out_dtype == CST_BF16) hipLaunchKernelGGL(colsum_reduce_kernel<bf16_t>, rgrid, dim3(1024), 0, s, (const float*)part, (bf16_t*)out, (int)nchunks, cols);
   else hipLaunchKernelGGL(colsum_reduce_kernel<float>, rgrid, dim3(1024), 0, s, (const float*)part, (float*)out, (int)nchunks, cols);
   return cst_check_launch("cst_colsum_typed");
+}
+
+extern "C" int cst_dropout_colsum(const void* x, void* xd, void* out, void* workspace, int64_t rows, int64_t cols, int dtype, int out_dtype,
+                                  float p, uint32_t key, const uint32_t* row_live, uint32_t epoch, cst_stream stream) {
+  CST_REQUIRE(x && xd && out && workspace && rows > 0 && cols > 0 && cols % 8 == 0, "cst_dropout_colsum: cols must be a multiple of 8");
+  CST_REQUIRE((dtype == CST_F32 || dtype == CST_BF16) && (out_dtype == CST_F32 || out_dtype == CST_BF16), "cst_dropout_colsum: bad dtype");
+  CST_REQUIRE(p > 0.0f && p < 1.0f, "cst_dropout_colsum: p must be in (0, 1)");
+  CST_REQUIRE(!row_live || epoch != 0, "cst_dropout_colsum: stamps need a non-zero epoch");
+  hipStream_t s = (hipStream_t)stream;
+  CstProfScope prof(CST_K_ELEMENTWISE, s, 0.0, 2.0 * (double)rows * cols * cst_dtype_size(dtype));
+  int64_t cblocks, nchunks, rows_per;
+  colsum_grid(rows, cols, cblocks, nchunks, rows_per);
+  dim3 grid((unsigned)cblocks, (unsigned)nchunks);
+  float* part = (float*)workspace;
+  const uint32_t thr = cst_drop_thr16(p);
+  const float scale = 1.0f / (1.0f - p);
+  if (dtype == CST_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t, true, true>), grid, dim3(256), 0, s, (const bf16_t*)x, cols, part, rows, cols, rows_per, row_live, epoch, (bf16_t*)xd, key, thr, scale);
+  else hipLaunchKernelGGL((colsum_kernel<float, true, true>), grid, dim3(256), 0, s, (const float*)x, cols, part, rows, cols, rows_per, row_live, epoch, (float*)xd, key, thr, scale);
+  const dim3 rgrid((unsigned)cst_ceil_div(cols, 16));
+  if (out_dtype == CST_BF16) hipLaunchKernelGGL(colsum_reduce_kernel<bf16_t>, rgrid, dim3(1024), 0, s, (const float*)part, (bf16_t*)out, (int)nchunks, cols);
+  else hipLaunchKernelGGL(colsum_reduce_kernel<float>, rgrid, dim3(1024), 0, s, (const float*)part, (float*)out, (int)nchunks, cols);
+  return cst_check_launch("cst_dropout_colsum");
 }
 
 extern "C" int cst_colsum_typed(const void* x, int64_t ldx, void* out, void* workspace, int64_t rows, int64_t cols, int dtype,

@@ -101,8 +101,13 @@ def _linear_backward(ctx, dy, dxp):
         dyp = torch.zeros(M, Np, dtype=dy2.dtype, device=dy2.device)
         dyp[:, :N] = dy2
         dy2 = dyp
+    db_fused = None
     if ctx.drop[0] > 0.0:  # gradient of the dropped branch: the same mask, regenerated
-        dy2 = K.dropout(dy2 if dy2.is_contiguous() else dy2.contiguous(), *ctx.drop)
+        dyc = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        if ctx.act == L.ACT_NONE and ctx.has_bias and ctx.needs_input_grad[2] and Np == N and N % 8 == 0 and not _os.environ.get("CST_NO_DROP_COLSUM"):
+            dy2, db_fused = K.dropout_colsum(dyc, ctx.drop[0], ctx.drop[1], w.dtype, live)  # mask + bias gradient in one pass
+        else:
+            dy2 = K.dropout(dyc, *ctx.drop)
     dz = K.act_bwd(dy2, z, ctx.act) if ctx.act != L.ACT_NONE else dy2
     dx = dw = db = dres = None
     if ctx.needs_input_grad[0]:
@@ -117,7 +122,7 @@ def _linear_backward(ctx, dy, dxp):
         K.gemm(dz, x2, dw, Np, Kd, M, a_kmajor=0, b_kmajor=0, lda=Np, ldb=Kd, ldc=Kd, split_k=-1, k_live=live)
         dw = dw[:N]
     if ctx.has_bias and ctx.needs_input_grad[2]:
-        db = K.colsum(dz, w.dtype, live)[:N]
+        db = db_fused if db_fused is not None else K.colsum(dz, w.dtype, live)[:N]
     if ctx.has_resid and ctx.needs_input_grad[3]:
         dres = dy
     return dx, dw, db, dres, None, None, None
@@ -185,8 +190,13 @@ class _FFNFn(torch.autograd.Function):
         dy2 = _flat2d(dy)
         live = _tiles_of(dy, M)  # zero rows of dy are zero rows of dy2 (mask) and of dz1 (row-wise GEMM, act', mask)
         p_act, key_act, p_out, key_out = ctx.drop
+        db2_fused = None
         if p_out > 0.0:  # d(fc2 output) = dy * mask_out
-            dy2 = K.dropout(dy2 if dy2.is_contiguous() else dy2.contiguous(), p_out, key_out)
+            dyc = dy2 if dy2.is_contiguous() else dy2.contiguous()
+            if has_b2 and ctx.needs_input_grad[4] and dout % 8 == 0 and not _os.environ.get("CST_NO_DROP_COLSUM"):
+                dy2, db2_fused = K.dropout_colsum(dyc, p_out, key_out, w2.dtype, live)  # mask + fc2 bias gradient in one pass
+            else:
+                dy2 = K.dropout(dyc, p_out, key_out)
         dz1 = torch.empty(M, F_, dtype=dy2.dtype, device=dy2.device)
         K.gemm(dy2, w2, dz1, M, F_, dout, a_kmajor=1, b_kmajor=0, lda=dout, ldb=F_, ldc=F_, dact=act, aux_in=z1, ld_aux_in=F_, split_k=1,
                drop_p=p_act, drop_key=key_act, m_live=live)
@@ -195,7 +205,7 @@ class _FFNFn(torch.autograd.Function):
             dw2 = torch.empty(dout, F_, dtype=w2.dtype, device=w2.device)
             K.gemm(dy2, h, dw2, dout, F_, M, a_kmajor=0, b_kmajor=0, lda=dout, ldb=F_, ldc=F_, split_k=-1, k_live=live)
         if has_b2 and ctx.needs_input_grad[4]:
-            db2 = K.colsum(dy2, w2.dtype, live)
+            db2 = db2_fused if db2_fused is not None else K.colsum(dy2, w2.dtype, live)
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, d, dtype=x2.dtype, device=x2.device)
             K.gemm(dz1, w1, dx, M, d, F_, a_kmajor=1, b_kmajor=0, lda=F_, ldb=d, ldc=d, split_k=1,

@@ -336,6 +336,22 @@ def colsum(x, out_dtype=torch.float32, live=None):
     return out
 
 
+def dropout_colsum(x, p, key, out_dtype=torch.float32, live=None):
+    """(x * mask / (1 - p), column sums of that) in one pass (cst_dropout_colsum): the masked gradient of a dropped Linear output and
+    its bias gradient.  Same bits as dropout() followed by colsum()."""
+    x = _2d(x)
+    assert x.is_contiguous()
+    rows, cols = x.shape
+    lib = L.load()
+    xd = torch.empty_like(x)
+    out = torch.empty(cols, dtype=out_dtype, device=x.device)
+    ws = workspace(lib.cst_colsum_workspace(rows, cols), x.device)
+    L.check(lib.cst_dropout_colsum(L.ptr(x), L.ptr(xd), L.ptr(out), L.ptr(ws), rows, cols, L.dtype_code(x.dtype), L.dtype_code(out_dtype),
+                                   float(p), int(key) & 0xFFFFFFFF, L.ptr(live[0]) if live is not None else None,
+                                   live[1] if live is not None else 0, L.stream_ptr()), "cst_dropout_colsum")
+    return xd, out
+
+
 def colsum_atomic(x):
     """cst_colsum: the atomics version (fp32 output), kept in the ABI."""
     x = _2d(x)

@@ -119,6 +119,7 @@ SYMBOLS = [
     ("cst_rows_unpack", c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_int, c_int, c_p]),
     ("cst_dec_linear", c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_p, c_i64, c_int, c_p]),
     ("cst_dec_ln_linear", c_int, [c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_p, c_i64, c_int, c_p]),
+    ("cst_dropout_colsum", c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_int, c_int, c_f, ctypes.c_uint32, c_p, ctypes.c_uint32, c_p]),
     ("cst_conv_row_limits", c_int, [c_p, c_p, c_p, c_int, c_i64, c_p, c_i64, c_int, c_p]),
     ("cst_dropout_scale", c_int, [c_p, c_p, c_i64, c_f, c_f, ctypes.c_uint32, c_int, c_p]),
     ("cst_embed_pos_fwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_f, c_i64, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_f, ctypes.c_uint32, c_int, c_p]),

@@ -263,6 +263,13 @@ int cst_act_bwd(const void* dy, const void* z, void* dx, int64_t n, int act, int
 int cst_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, cst_stream stream);
 /* out[c] = sum_r x[r, c]  (bias gradients); out fp32 [cols], overwritten */
 int cst_colsum(const void* x, int64_t ldx, float* out, int64_t rows, int64_t cols, int dtype, cst_stream stream);
+/* Gradient of `residual + dropout(linear(x))` on its way into the Linear's backward, in ONE pass: xd = x * keep(key, index) / (1 - p)
+ * (FairseqDropout backward, modules/fairseq_dropout.py:20-37: the mask of the forward call, element index = r * cols + c) stored in
+ * `dtype`, and out[c] = sum_r xd[r][c] (the bias gradient) over the STORED values — the same bits as cst_dropout followed by
+ * cst_colsum_typed.  x, xd contiguous [rows, cols]; workspace: cst_colsum_workspace(rows, cols) bytes; row_live / epoch as in
+ * cst_colsum_typed_live (optional): all-zero 64-row tiles are written as zeros without being read. */
+int cst_dropout_colsum(const void* x, void* xd, void* out, void* workspace, int64_t rows, int64_t cols, int dtype, int out_dtype,
+                       float p, uint32_t key, const uint32_t* row_live, uint32_t epoch, cst_stream stream);
 /* the same sums without atomics: row-chunk partials in `workspace` (cst_colsum_workspace bytes), reduced in a fixed order and
  * written in `out_dtype` (the bias parameter's dtype) — deterministic, no zero-fill and no conversion launch around it */
 int64_t cst_colsum_workspace(int64_t rows, int64_t cols);

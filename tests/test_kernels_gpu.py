@@ -378,6 +378,34 @@ def test_conv0_frame_limits_are_exact(K, dt):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("rows,cols", [(47968, 768), (4128, 512), (333, 64)])
+def test_dropout_colsum_equals_dropout_then_colsum(K, dt, rows, cols):
+    """cst_dropout_colsum: the masked gradient and its column sums in one pass, bit-equal to cst_dropout followed by
+    cst_colsum_typed (the sums are taken over the values as stored); with live-tile stamps, dead tiles come back as zeros."""
+    k, L = K
+    x = rnd(rows, cols, dt=dt, seed=60)
+    p, key = 0.1, 0x1234567
+    xd, db = k.dropout_colsum(x, p, key, dt)
+    ref = k.dropout(x, p, key)
+    assert torch.equal(xd, ref)
+    assert torch.equal(db, k.colsum(ref, dt))
+    # stamps: rows of every second 64-row tile are zero and marked dead
+    x2 = x.clone()
+    ntile = (rows + 63) // 64
+    stamps = torch.zeros(ntile, dtype=torch.int32, device="cuda")
+    epoch = 7
+    for t in range(ntile):
+        if t % 2 == 0:
+            stamps[t] = epoch
+        else:
+            x2[t * 64:(t + 1) * 64] = 0
+    xd2, db2 = k.dropout_colsum(x2, p, key, dt, (stamps, epoch))
+    ref2 = k.dropout(x2, p, key)
+    assert torch.equal(xd2, ref2)
+    assert torch.equal(db2, k.colsum(ref2, dt, (stamps, epoch)))
+
+
+@pytest.mark.parametrize("dt", DT)
 def test_elementwise(K, dt):
     k, L = K
     z = rnd(77, 128, dt=dt, seed=50)
