@@ -204,6 +204,43 @@ def test_against_oracle_fresh_inputs():
     assert_close(mem, ref["memory_audio"].numpy(), 1e-3, "memory (fresh)")
 
 
+@pytest.mark.parametrize("kind", ["s2t", "chimera"])
+@pytest.mark.parametrize("lengths", [[9000, 400], [6400, 6400, 720, 410], [400]])
+def test_extremely_ragged_batches_against_oracle(lengths, kind):
+    """s2t model (both layer stacks packed, CNN frame limits on) on batches whose short utterances are shorter than the reach of the
+    positional convolution — one or two wav2vec2 frames against a few dozen, or a single one-frame utterance: loss, logits and every
+    gradient against the oracle (CPU fp32)."""
+    from oracle import chimera_oracle as O
+    import parity_util as PU
+    g = load_golden("s2t_w2v2_tiny.npz" if kind == "s2t" else "chimera_tiny.npz")
+    model, task, args = build_from_golden(g, kind, torch.float32)
+    tasks = import_module("chimera-st_amd.tasks")
+    crit_mod = import_module("chimera-st_amd.criterions")
+    n = len(lengths)
+    sample = tasks.synthetic_sample(task.target_dictionary, n, lengths, [5, 9, 3, 7][:n], [4, 7, 2, 6][:n], seed=13)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    if kind == "s2t":
+        ref, rgrads = PU.run_oracle(O.lsce_criterion, sd, sample, golden_cfg(g))
+        crit = crit_mod.LabelSmoothedCrossEntropyCriterion(task, False, 0.1)
+    else:  # (the memory attention reads every padded frame of the encoder output: quirk Q1)
+        ref, rgrads = PU.run_oracle(O.triplet_criterion, sd, sample, golden_cfg(g))
+        crit = crit_mod.TripletSTMTContrastiveCriterion(task, False, 0.1, [1.0, 1.0, 1.0], 0.1)
+    model.train()
+    model.zero_grad()
+    loss, ss, log = crit(model, to_cuda(sample))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref["loss"].detach())) <= 1e-4 * abs(float(ref["loss"].detach())) + 1e-3
+    if kind == "s2t":
+        logits, _ = model(**to_cuda(sample)["net_input"])
+        assert PU.max_abs_rel(logits, ref["logits"]) <= 1e-3
+    else:
+        (logits, _), mem = model.forward_with_internal(**to_cuda(sample)["net_input"])
+        assert PU.max_abs_rel(logits, ref["st_logits"]) <= 1e-3 and PU.max_abs_rel(mem, ref["memory_audio"]) <= 1e-3
+    got = {k: p.grad for k, p in model.named_parameters()}
+    ncmp, worst, excused = PU.assert_grads_close_fp32(got, rgrads, ref["relu_min_abs"])
+    assert ncmp > 50, ncmp
+
+
 def test_dropout_training_step_consistency():
     """Every dropout site on (p = 0.2: GEMM epilogues, attention probabilities, feature / embedding dropouts): the masks are a
     function of (seed, site ordinal, element), so (a) the same seed reproduces the loss and the gradients, (b) another seed does
