@@ -77,6 +77,34 @@ def test_two_updates_match_reference_optimizer():
         assert_close(p, g["param_after/" + name], 1e-4, "param " + name)
 
 
+@pytest.mark.parametrize("kind,fixture", [("chimera", "chimera_tiny.npz"), ("s2t", "s2t_w2v2_tiny.npz")])
+def test_gradient_accumulation_equals_one_batch(kind, fixture):
+    """update_freq = 2 on the same micro-batch twice (trainer.py:479-500: no_sync on the first, accumulate, normalise by the summed
+    sample size) against one micro-batch: every gradient doubles exactly, the sample size doubles, so the update must be THE SAME BITS
+    (fp32).  Exercises autograd's accumulation into the gradients the backward kernels handed over (views of the packed q | k | v
+    gradient among them) and the flat-buffer gather behind it."""
+    g0 = load_golden(fixture)
+    crit_mod = import_module("chimera-st_amd.criterions")
+    Trainer = import_module("chimera-st_amd.trainer").Trainer
+    targs = Namespace(bf16=False, lr=[1e-3], adam_betas="(0.9, 0.98)", adam_eps=1e-8, weight_decay=0.01, clip_norm=0.05,
+                      warmup_updates=4, warmup_init_lr=1e-7, seed=1)
+    results = []
+    for copies in (1, 2):
+        model, task, args = build_from_golden(g0, kind, torch.float32)
+        crit = (crit_mod.TripletSTMTContrastiveCriterion(task, False, 0.1, [1.0, 1.0, 1.0], 0.1) if kind == "chimera"
+                else crit_mod.LabelSmoothedCrossEntropyCriterion(task, False, 0.1))
+        tr = Trainer(targs, task, model, crit, device="cuda")
+        sample = golden_sample(g0)
+        outs = [tr.train_step([sample] * copies) for _ in range(2)]
+        results.append((outs, {n: p.detach().clone() for n, p in tr.get_model().named_parameters()}))
+    (o1, p1), (o2, p2) = results
+    for a, b in zip(o1, o2):
+        assert b["sample_size"] == 2 * a["sample_size"]
+        assert a["gnorm"] == pytest.approx(b["gnorm"], rel=1e-6)
+    for n in p1:
+        assert torch.equal(p1[n], p2[n]), n
+
+
 def test_bf16_trainer_runs_and_decreases_loss():
     g0 = load_golden("chimera_tiny.npz")
     model, task, args = build_from_golden(g0, "chimera", torch.float32)
