@@ -17,6 +17,8 @@
 // dtype: bf16 (v_mfma_f32_32x32x16_bf16, P rounded to bf16 like the reference's fp16/bf16 path) or
 // f32 (v_mfma_f32_32x32x2_f32, exact-fp32 products) from one source via Frag<T>.
 #include "cst_common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -44,6 +46,7 @@ struct AttnParams {
   // kept for their outputs).  Tq / Tk then hold the LONGEST segment: grid size and the strides of lse / delta / q_flags / the dropout
   // index space — so a packed call regenerates exactly the masks of the padded call it replaces.
   const int32_t* seq_off;
+  const unsigned long long* kpm_bits; int64_t kpm_bits_stride;  // optional: key_padding_mask as one 64-bit word per 64-key tile (bit k: key 64 j + k masked)
 };
 
 // per-sequence view of the problem: row offset, number of query rows, number of keys
@@ -160,8 +163,9 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_fwd_ke
   // attention dropout (modules/multihead_attention.py:359): element (b,h,q,k) of the probability tensor has index
   // ((b*H + h)*Tq + q) * Tkp + k with Tkp = Tk rounded up to even, so one mask word serves keys (2j, 2j+1) of a query
   const uint32_t dkey2 = cst_drop_key2(p.drop_key);
-  const uint32_t hp = (uint32_t)((p.Tk + 1) >> 1);
-  const uint32_t rowpair = (uint32_t)((b * p.H + h) * p.Tq + q) * hp;
+  const int thr_s = (int)p.drop_thr - 32768;  // the mask halves are compared as signed 16-bit numbers (cst_common.h)
+  const uint32_t rho = (uint32_t)((b * p.H + h) * p.Tq + q);
+  const uint32_t R1 = DROP ? cst_adrop_row1(p.drop_key, dkey2, rho) : 0u, R2 = DROP ? cst_adrop_row2(p.drop_key, dkey2, rho) : 0u;
 
   Frag<T> fq[D / 16];
   load_row_frags<T, D>(fq, Qg, p.q_st, q, sv.tq, lane);
@@ -257,16 +261,16 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_fwd_ke
       l_run = l_run * alpha + (ls0 + ls1);
       m_run = m_new;
       if (DROP) {  // dropped probabilities leave the PV product; the row sum (normaliser) keeps them
-        const uint32_t base = rowpair + (uint32_t)((j0 >> 1) + 2 * hi);
+        const uint32_t base = (uint32_t)((j0 >> 1) + 2 * hi);  // key pair index of registers (0, 1) of this half-wave
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
           for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-              const uint32_t bits = cst_drop_bits24(p.drop_key, dkey2, base + ks * 16 + 4 * g + t);
-              s[ks][4 * g + 2 * t] = (bits & 0xffffU) >= p.drop_thr ? s[ks][4 * g + 2 * t] : 0.0f;
-              s[ks][4 * g + 2 * t + 1] = (bits >> 16) >= p.drop_thr ? s[ks][4 * g + 2 * t + 1] : 0.0f;
+              const uint32_t bits = cst_adrop_word(R1, R2, cst_adrop_col(p.drop_key, dkey2, base + ks * 16 + 4 * g + t));
+              s[ks][4 * g + 2 * t] = cst_adrop_keep(bits, 0, thr_s) ? s[ks][4 * g + 2 * t] : 0.0f;
+              s[ks][4 * g + 2 * t + 1] = cst_adrop_keep(bits, 1, thr_s) ? s[ks][4 * g + 2 * t + 1] : 0.0f;
             }
       }
     }
@@ -362,8 +366,9 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_bwd_dq
   const int cshift = sv.tk - sv.tq;
   const float c2 = p.scale * 1.4426950408889634f;
   const uint32_t dkey2 = cst_drop_key2(p.drop_key);
-  const uint32_t hp = (uint32_t)((p.Tk + 1) >> 1);
-  const uint32_t rowpair = (uint32_t)((b * p.H + h) * p.Tq + q) * hp;
+  const int thr_s = (int)p.drop_thr - 32768;  // the mask halves are compared as signed 16-bit numbers (cst_common.h)
+  const uint32_t rho = (uint32_t)((b * p.H + h) * p.Tq + q);
+  const uint32_t R1 = DROP ? cst_adrop_row1(p.drop_key, dkey2, rho) : 0u, R2 = DROP ? cst_adrop_row2(p.drop_key, dkey2, rho) : 0u;
 
   {
     int* sh_qend = reinterpret_cast<int*>(sMask + 2);
@@ -444,14 +449,14 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_bwd_dq
         mma16(dp, fv, fdo[kk]);   // dP^T[key][q] = V dO^T
       }
       if (DROP) {  // dP = (dO V^T) * keep / (1 - p): the same mask words as the forward pass
-        const uint32_t base = rowpair + (uint32_t)((j0 >> 1) + 2 * hi) + ks * 16;
+        const uint32_t base = (uint32_t)((j0 >> 1) + 2 * hi) + ks * 16;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
-            const uint32_t bits = cst_drop_bits24(p.drop_key, dkey2, base + 4 * g + t);
-            dp[4 * g + 2 * t] = (bits & 0xffffU) >= p.drop_thr ? dp[4 * g + 2 * t] * p.drop_scale : 0.0f;
-            dp[4 * g + 2 * t + 1] = (bits >> 16) >= p.drop_thr ? dp[4 * g + 2 * t + 1] * p.drop_scale : 0.0f;
+            const uint32_t bits = cst_adrop_word(R1, R2, cst_adrop_col(p.drop_key, dkey2, base + 4 * g + t));
+            dp[4 * g + 2 * t] = cst_adrop_keep(bits, 0, thr_s) ? dp[4 * g + 2 * t] * p.drop_scale : 0.0f;
+            dp[4 * g + 2 * t + 1] = cst_adrop_keep(bits, 1, thr_s) ? dp[4 * g + 2 * t + 1] * p.drop_scale : 0.0f;
           }
       }
 #pragma unroll
@@ -514,9 +519,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnParams p) 
   // here a lane owns one key and its registers run over queries, so every element needs its own mask word (the word of the
   // key pair (key & ~1, key | 1) in that query's row); this lane's half of the word is `dsh`
   const uint32_t dkey2 = cst_drop_key2(p.drop_key);
-  const uint32_t hp = (uint32_t)((p.Tk + 1) >> 1);
+  const int thr_s = (int)p.drop_thr - 32768;  // the mask halves are compared as signed 16-bit numbers (cst_common.h)
   const uint32_t dsh = (uint32_t)(key & 1) * 16;
-  const uint32_t rowpair0 = (uint32_t)((b * p.H + h) * p.Tq) * hp + (uint32_t)(key >> 1) + (uint32_t)(4 * hi) * hp;
+  const uint32_t rho0 = (uint32_t)((b * p.H + h) * p.Tq) + (uint32_t)(4 * hi);
+  const uint32_t ccol = DROP ? cst_adrop_col(p.drop_key, dkey2, (uint32_t)(key >> 1)) : 0u;
 
   if (p.kv_len && k_blk0 >= p.kv_len[b]) {  // every key of this block is padding: dK = dV = 0 (workgroup-uniform exit)
     if (key < krows) {
@@ -603,11 +609,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnParams p) 
         for (int j = 0; j < 8; ++j) {
           const int r0 = 2 * j;  // query rows of registers r0 and r0 + 1 differ by one
           const uint32_t qrow = (uint32_t)((int)i0 + qs * 32 + (r0 & 3) + 8 * (r0 >> 2)) + odd;
-          const uint32_t mine = cst_drop_bits24(p.drop_key, dkey2, rowpair0 + qrow * hp);
+          const uint32_t mine = cst_adrop_word(cst_adrop_row1(p.drop_key, dkey2, rho0 + qrow), cst_adrop_row2(p.drop_key, dkey2, rho0 + qrow), ccol);
           const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
           const uint32_t w0 = odd ? other : mine, w1 = odd ? mine : other;
-          keepbits |= (((w0 >> dsh) & 0xffffU) >= p.drop_thr ? 1u : 0u) << r0;
-          keepbits |= (((w1 >> dsh) & 0xffffU) >= p.drop_thr ? 1u : 0u) << (r0 + 1);
+          keepbits |= (cst_adrop_keep(w0 >> dsh, 0, thr_s) ? 1u : 0u) << r0;
+          keepbits |= (cst_adrop_keep(w1 >> dsh, 0, thr_s) ? 1u : 0u) << (r0 + 1);
         }
       }
 #pragma unroll
@@ -666,6 +672,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnParams p) 
   }
 }
 
+#include "attention_fast.inc"
+
 int fill_params(const cst_attn_desc* d, AttnParams& p, bool bwd) {
   CST_REQUIRE(d, "cst_attn: null descriptor");
   CST_REQUIRE(d->dtype == CST_F32 || d->dtype == CST_BF16, "cst_attn: bad dtype %d", d->dtype);
@@ -686,7 +694,7 @@ int fill_params(const cst_attn_desc* d, AttnParams& p, bool bwd) {
   p.lse = d->lse; p.kpm = d->key_padding_mask; p.kpm_stride = d->kpm_stride;
   p.causal = d->causal; p.scale = d->scale;
   CST_REQUIRE(d->drop_p >= 0.0f && d->drop_p < 1.0f, "cst_attn: drop_p must be in [0, 1)");
-  CST_REQUIRE(d->drop_p == 0.0f || (double)d->B * d->H * d->Tq * ((d->Tk + 1) / 2) < 4294967296.0, "cst_attn: dropout index space exceeds 2^33 elements");
+  CST_REQUIRE(d->drop_p == 0.0f || (double)d->B * d->H * d->Tq < 4294967296.0, "cst_attn: dropout row space exceeds 2^32 rows");
   p.drop_thr = d->drop_p > 0.0f ? cst_drop_thr16(d->drop_p) : 0u;
   p.drop_key = d->drop_key;
   p.drop_scale = d->drop_p > 0.0f ? 1.0f / (1.0f - d->drop_p) : 1.0f;
@@ -698,6 +706,8 @@ int fill_params(const cst_attn_desc* d, AttnParams& p, bool bwd) {
   p.delta = d->delta;
   p.kv_len = d->kv_len;
   p.seq_off = d->seq_offsets;
+  p.kpm_bits = (const unsigned long long*)d->kpm_bits;
+  p.kpm_bits_stride = (d->Tk + 63) / 64;
   if (p.seq_off) {
     CST_REQUIRE(d->Tq == d->Tk && d->key_padding_mask == nullptr, "cst_attn: packed sequences are self-attention (Tq == Tk = longest segment) without a key padding mask (kv_len gives the keys per sequence)");
     CST_REQUIRE(d->q_st == d->k_st && d->q_st == d->v_st, "cst_attn: packed Q/K/V must share one row stride");
@@ -726,6 +736,20 @@ double attn_flops(const cst_attn_desc* d, double gemms) {
   return gemms * 2.0 * pairs * (double)d->D * (double)d->B * (double)d->H;
 }
 
+// the DMA-staged kernels cover the hot configuration: bf16, head dim 64, no causal mask, key masks as packed tile words (or none)
+bool attn_fast_ok(const cst_attn_desc* d) {
+  static const bool off = getenv("CST_ATTN_GENERIC") != nullptr;  // test / A-B hook: the generic kernels for everything
+  return !off && d->dtype == CST_BF16 && d->D == 64 && !d->causal && (d->key_padding_mask == nullptr || d->kpm_bits != nullptr) &&
+         d->Tk <= 65536 && (int64_t)d->Tk * d->k_st < (1ll << 29) && (int64_t)d->Tq * d->q_st < (1ll << 29) && (int64_t)d->Tk * d->v_st < (1ll << 29) &&
+         d->o_st % 8 == 0 && d->o_sh % 8 == 0 && d->o_sb % 8 == 0 && (uintptr_t)d->O % 16 == 0;
+}
+bool attn_fast_bwd_ok(const cst_attn_desc* d) {
+  const int64_t st[] = {d->dq_sb, d->dq_sh, d->dq_st, d->dk_sb, d->dk_sh, d->dk_st, d->dv_sb, d->dv_sh, d->dv_st};
+  for (int64_t x : st) if (x % 8) return false;
+  return attn_fast_ok(d) && d->bwd_ws != nullptr && (uintptr_t)d->dQ % 16 == 0 && (uintptr_t)d->dK % 16 == 0 && (uintptr_t)d->dV % 16 == 0 &&
+         (uintptr_t)d->bwd_ws % 16 == 0 && (int64_t)d->Tq * d->do_st < (1ll << 29);
+}
+
 }  // namespace
 
 extern "C" int cst_attn_fwd(const cst_attn_desc* d, cst_stream stream) {
@@ -733,6 +757,14 @@ extern "C" int cst_attn_fwd(const cst_attn_desc* d, cst_stream stream) {
   int rc = fill_params(d, p, false);
   if (rc != CST_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
+  if (attn_fast_ok(d)) {
+    CstProfScope prof(CST_K_ATTN_FWD, s, attn_flops(d, 2.0), 0.0);
+    const unsigned nblk = (unsigned)(cst_ceil_div(d->Tq, 128) * d->H * d->B);
+    const size_t lds = 2 * FA_SLOT + 128 * (size_t)cst_ceil_div(d->Tk, 64);
+    if (p.drop_thr) hipLaunchKernelGGL((fa_fwd_kernel<true>), dim3(nblk), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((fa_fwd_kernel<false>), dim3(nblk), dim3(256), lds, s, p);
+    return cst_check_launch("cst_attn_fwd");
+  }
   dim3 grid((unsigned)cst_ceil_div(d->Tq, NW * QB), (unsigned)d->H, (unsigned)d->B);
   CstProfScope prof(CST_K_ATTN_FWD, s, attn_flops(d, 2.0), 0.0);
 #define CST_FWD1(T, DD, DR) do { const size_t lds = attn_lds_bytes<T, DD>(); attn_set_lds(reinterpret_cast<const void*>(&attn_fwd_kernel<T, DD, DR>)); \
@@ -745,12 +777,32 @@ extern "C" int cst_attn_fwd(const cst_attn_desc* d, cst_stream stream) {
   return cst_check_launch("cst_attn_fwd");
 }
 
+extern "C" int64_t cst_attn_bwd_workspace(const cst_attn_desc* d) {
+  if (!d) return 0;
+  return (int64_t)d->B * d->H * 2 * cst_ceil_div(d->Tq, 64) * 64 * (int64_t)sizeof(float);
+}
+
 extern "C" int cst_attn_bwd(const cst_attn_desc* d, cst_stream stream) {
   AttnParams p;
   int rc = fill_params(d, p, true);
   if (rc != CST_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
   CstProfScope prof(CST_K_ATTN_BWD, s, attn_flops(d, 5.0), 0.0);
+  if (attn_fast_bwd_ok(d)) {
+    const int64_t Tq64 = cst_ceil_div(d->Tq, 64) * 64;
+    float* ws = (float*)d->bwd_ws;
+    hipLaunchKernelGGL(fa_delta_kernel, dim3((unsigned)(Tq64 / 64), (unsigned)d->H, (unsigned)d->B), dim3(64), 0, s, p, ws, Tq64);
+    const unsigned nq = (unsigned)(cst_ceil_div(d->Tq, 128) * d->H * d->B), nk = (unsigned)(cst_ceil_div(d->Tk, 128) * d->H * d->B);
+    const size_t lds_q = 2 * FA_SLOT + 128 * (size_t)cst_ceil_div(d->Tk, 64), lds_k = 2 * (FA_SLOT + FA_STATS);
+    if (p.drop_thr) {
+      hipLaunchKernelGGL((fa_dq_kernel<true>), dim3(nq), dim3(256), lds_q, s, p, (const float*)ws, Tq64);
+      hipLaunchKernelGGL((fa_dkv_kernel<true>), dim3(nk), dim3(256), lds_k, s, p, (const float*)ws, Tq64);
+    } else {
+      hipLaunchKernelGGL((fa_dq_kernel<false>), dim3(nq), dim3(256), lds_q, s, p, (const float*)ws, Tq64);
+      hipLaunchKernelGGL((fa_dkv_kernel<false>), dim3(nk), dim3(256), lds_k, s, p, (const float*)ws, Tq64);
+    }
+    return cst_check_launch("cst_attn_bwd");
+  }
   dim3 gq((unsigned)cst_ceil_div(d->Tq, NW * QB), (unsigned)d->H, (unsigned)d->B);
   dim3 gk((unsigned)cst_ceil_div(d->Tk, NW * QB), (unsigned)d->H, (unsigned)d->B);
 #define CST_BWD1(T, DD, DR)                                                                                \

@@ -147,6 +147,29 @@ __device__ __forceinline__ uint32_t cst_drop_bits24(uint32_t key, uint32_t key2,
   uint32_t w = __umul24(t, 0x85EBCBU) + key2;
   return w ^ (w >> 13);
 }
+// Attention-probability dropout of the DMA-staged attention kernels (attention_fast.inc): a SEPARABLE mask.  The 16 mask words a
+// 32 x 64 score tile needs per lane cost more VALU issue than the tile's 16 MFMAs when every word is a full hash of its index
+// (measured: 270 of 390 VALU instructions per tile), and the dK/dV kernel — where a lane owns a key and its registers run over
+// queries — needs a different word per element.  Here
+//   R1(rho), R2(rho)  two strong hashes of the probability ROW rho = (b*H + h)*Tq + q        (once per lane, or per staged query)
+//   C(kp)             a strong hash of the key PAIR index kp = k >> 1                           (a per-workgroup LDS table / once per lane)
+//   x = (R1 ^ C) & 0xffffff;  t = x * 0x9E3779;  t ^= t >> 15;  w = (t & 0xffffff) * 0x85EBCB + R2                      (mod 2^32)
+//   keep(rho, k) = int16(16-bit half (k & 1 ? high : low) of w)  >=  thr16 - 32768        (the halves are compared as SIGNED numbers: the
+//                  forward kernel builds the keep mask of a packed bf16 pair with v_pk_sub_i16 (saturating) + v_pk_ashrrev_i16 + v_and)
+// i.e. 5 full-rate operations per element PAIR in every layout, and the mask of (row, key) does not depend on tiling, so packed and
+// padded calls and all three kernels draw the same masks.  The xorshift between the two multiplies matters: with one multiply, key
+// pairs whose C values differ in a few high (or low) bits get masks that are shifted copies of each other (column correlation up to
+// 1.0 in the numpy twin); with it, max |correlation| over 1500 columns / 1500 rows is at the iid level (0.07 / 0.14 on 6000 x 1500).
+// Numpy twin: rng.keep_mask_attn_numpy.
+__device__ __forceinline__ uint32_t cst_adrop_row1(uint32_t key, uint32_t key2, uint32_t rho) { return cst_drop_bits32(key, key2, rho); }
+__device__ __forceinline__ uint32_t cst_adrop_row2(uint32_t key, uint32_t key2, uint32_t rho) { return cst_drop_bits32(key2 ^ 0xA511E9B3U, key, rho); }
+__device__ __forceinline__ uint32_t cst_adrop_col(uint32_t key, uint32_t key2, uint32_t kp) { return cst_drop_bits32(key ^ 0x68E31DA4U, key2, kp); }
+__device__ __forceinline__ uint32_t cst_adrop_word(uint32_t r1, uint32_t r2, uint32_t c) {
+  uint32_t t = __umul24(r1 ^ c, 0x9E3779U);
+  t ^= t >> 15;
+  return __umul24(t, 0x85EBCBU) + r2;
+}
+__device__ __forceinline__ bool cst_adrop_keep(uint32_t w, int odd, int thr_s) { return (int)(short)(odd ? (w >> 16) : (w & 0xffffU)) >= thr_s; }
 // multiply 8 consecutive elements starting at the (even) element index idx0 by their dropout factors
 __device__ __forceinline__ void cst_drop8(float (&v)[8], uint32_t key, uint64_t idx0, uint32_t thr16, float scale) {
 #pragma unroll

@@ -185,8 +185,13 @@ def attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, layout_q="bt", layout_k
     if kpm is not None:
         assert kpm.dtype == torch.uint8 and kpm.stride(1) == 1 and kpm.shape == (B, Tk)
         d.key_padding_mask, d.kpm_stride = kpm.data_ptr(), kpm.stride(0)
+        bits = kpm_bits(kpm)
+        d.kpm_bits = bits.data_ptr()
+        d._kpm_bits_owner = bits
     else:
         d.key_padding_mask, d.kpm_stride = None, 0
+        d.kpm_bits = None
+    d.bwd_ws = None
     d.causal, d.scale = int(causal), scale
     d.drop_p, d.drop_key = float(drop_p), int(drop_key) & 0xFFFFFFFF
     if kv_len is not None:
@@ -196,6 +201,28 @@ def attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, layout_q="bt", layout_k
     else:
         d.kv_len = None
     return d
+
+
+_KPM_BITS = []  # [(uint8 mask (kept alive), version, int64 words)]: one padding mask serves every layer of a pass
+
+
+def kpm_bits(kpm):
+    """uint8 [B, Tk] key padding mask -> int64 [B, ceil(Tk/64)]: bit k of word j = key 64 j + k is masked (bits of keys >= Tk set).
+    cst_attn_desc.kpm_bits: the DMA-staged attention kernels read one mask word per key tile from scalar registers."""
+    for src, ver, bits in _KPM_BITS:
+        if src is kpm and ver == kpm._version:
+            return bits
+    B, Tk = kpm.shape
+    nw = (Tk + 63) // 64
+    m = kpm != 0
+    if nw * 64 != Tk:
+        m = torch.cat([m, torch.ones(B, nw * 64 - Tk, dtype=torch.bool, device=kpm.device)], 1)
+    w = torch.tensor([1 << i if i < 63 else -(1 << 63) for i in range(64)], dtype=torch.int64, device=kpm.device)
+    bits = (m.view(B, nw, 64).to(torch.int64) * w).sum(-1).contiguous()  # distinct powers of two: the wrapping sum is the OR
+    _KPM_BITS.append((kpm, kpm._version, bits))
+    if len(_KPM_BITS) > 8:
+        _KPM_BITS.pop(0)
+    return bits
 
 
 def attn_fwd(q, k, v, H, D, kpm, causal, scale, layout_q="bt", layout_kv="bt", drop_p=0.0, drop_key=0, kv_len=None):
@@ -234,6 +261,10 @@ def attn_bwd_fill(d, do, dq, dk, dv, delta, D, layout_q="bt", layout_kv="bt"):
     d.q_flags = flags.data_ptr()
     STATS["attn_q_flags"] = STATS.get("attn_q_flags", 0) + 1
     d._q_flags_owner = flags  # the workspace lives as long as the descriptor (i.e. until the launch has been enqueued)
+    # statistics workspace of the DMA-staged backward kernels (cst_attn_desc.bwd_ws)
+    ws = torch.empty(int(L.load().cst_attn_bwd_workspace(ctypes.byref(d))) // 4, dtype=torch.float32, device=do.device)
+    d.bwd_ws = ws.data_ptr()
+    d._bwd_ws_owner = ws
 
 
 def attn_bwd(do, q, k, v, o, lse, H, D, kpm, causal, scale, layout_q="bt", layout_kv="bt", drop_p=0.0, drop_key=0, kv_len=None):

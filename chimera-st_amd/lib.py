@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcst_hip.so")
-ABI_VERSION = 3  # include/cst.h: CST_ABI_VERSION
+ABI_VERSION = 4  # include/cst.h: CST_ABI_VERSION
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
@@ -66,6 +66,8 @@ class AttnDesc(ctypes.Structure):
         ("kv_len", c_p),
         ("q_flags", c_p),
         ("seq_offsets", c_p),
+        ("kpm_bits", c_p),
+        ("bwd_ws", c_p),
     ]
 
 
@@ -98,6 +100,7 @@ SYMBOLS = [
     ("cst_layernorm_bwd_tiles", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_int, c_int, c_p, ctypes.c_uint32, c_p]),
     ("cst_gemm_workspace", c_i64, [ctypes.POINTER(GemmDesc)]),
     ("cst_gemm", c_int, [ctypes.POINTER(GemmDesc), c_p]),
+    ("cst_attn_bwd_workspace", c_i64, [ctypes.POINTER(AttnDesc)]),
     ("cst_attn_fwd", c_int, [ctypes.POINTER(AttnDesc), c_p]),
     ("cst_attn_bwd", c_int, [ctypes.POINTER(AttnDesc), c_p]),
     ("cst_conv0_fwd_workspace", c_i64, [c_i64, c_i64, c_int, c_int]),

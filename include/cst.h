@@ -29,8 +29,9 @@ extern "C" {
 #endif
 
 /* Bumps on any change of a signature or a descriptor layout (3: cst_gemm_desc.m_len, cst_attn_desc.seq_offsets, workspaces of the
- * fixed-order reductions).  cst_version() returns the value the library was built with; chimera-st_amd/lib.py refuses a mismatch. */
-#define CST_ABI_VERSION 3
+ * fixed-order reductions; 4: cst_attn_desc.kpm_bits / bwd_ws, the separable attention-dropout mask).  cst_version() returns the
+ * value the library was built with; chimera-st_amd/lib.py refuses a mismatch. */
+#define CST_ABI_VERSION 4
 
 typedef enum { CST_F32 = 0, CST_BF16 = 1 } cst_dtype;
 
@@ -178,8 +179,9 @@ typedef struct {
   const uint8_t* key_padding_mask; int64_t kpm_stride;
   int causal;
   float scale;
-  float drop_p; uint32_t drop_key;   /* attention dropout (multihead_attention.py:359): P * keep(drop_key, ((b*H+h)*Tq+q)*Tkp + k) / (1-p),
-                                        Tkp = Tk rounded up to even; the backward call must carry the same two values */
+  float drop_p; uint32_t drop_key;   /* attention dropout (multihead_attention.py:359): P * keep(drop_key, row (b*H+h)*Tq + q, key k) / (1-p),
+                                        keep = the separable mask of csrc/cst_common.h (cst_adrop_*; numpy twin rng.keep_mask_attn_numpy);
+                                        the backward call must carry the same two values */
   /* backward only */
   const void* dO; int64_t do_sb, do_sh, do_st;
   void* dQ; int64_t dq_sb, dq_sh, dq_st;
@@ -201,8 +203,17 @@ typedef struct {
    * the longest sequence: it sizes the grid and strides lse / delta / q_flags [B, H, Tq] and the dropout index space, so that a
    * packed call draws exactly the dropout masks of the dense call it replaces.  key_padding_mask must be NULL. */
   const int32_t* seq_offsets;
+  /* optional uint64 [B, ceil(Tk/64)] (NULL = none): key_padding_mask packed one word per 64-key tile (bit k of word j: key 64 j + k is
+   * masked; bits of keys >= Tk set).  With it (or without any key_padding_mask) bf16 / D = 64 / non-causal problems run the DMA-staged
+   * kernels (csrc/attention_fast.inc), which read tile masks from scalar registers; without it a masked problem runs the generic
+   * kernels.  Must describe exactly key_padding_mask. */
+  const uint64_t* kpm_bits;
+  /* optional workspace of cst_attn_bwd, cst_attn_bwd_workspace() bytes (NULL = generic backward kernels): the pre-pass writes
+   * -lse * log2(e) and -delta / dropout-scale per query, padded to whole 64-query tiles, for the DMA-staged dK/dV kernel. */
+  void* bwd_ws;
 } cst_attn_desc;
 
+int64_t cst_attn_bwd_workspace(const cst_attn_desc* d);
 int cst_attn_fwd(const cst_attn_desc* d, cst_stream stream);
 int cst_attn_bwd(const cst_attn_desc* d, cst_stream stream);
 

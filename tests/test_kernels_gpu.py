@@ -751,7 +751,7 @@ def test_gemm_epilogue_dropout(K, dt, big):
 @pytest.mark.parametrize("Tq,Tk,causal", [(100, 100, False), (77, 131, False), (64, 64, True)])
 def test_attention_dropout(K, dt, Tq, Tk, causal):
     """Attention-probability dropout inside the fused kernels, forward and all three gradients, against explicit
-    softmax -> mask -> PV in fp32 with the mask from rng.keep_mask_attn_numpy (index ((b*H+h)*Tq+q)*Tkp + k, Tkp = even(Tk))."""
+    softmax -> mask -> PV in fp32 with the mask from rng.keep_mask_attn_numpy (row (b*H+h)*Tq + q, key k)."""
     k, L = K
     B, H, D = 2, 3, 64
     p, key = 0.2, 4242
@@ -764,9 +764,8 @@ def test_attention_dropout(K, dt, Tq, Tk, causal):
     o, lse = k.attn_fwd(q.detach(), kk.detach(), v.detach(), H, D, kpm, causal, scale, "bt", "bt", p, key)
     do = rnd(B, Tq, H * D, dt=dt, seed=5)
     dq, dk, dv = k.attn_bwd(do, q.detach(), kk.detach(), v.detach(), o, lse, H, D, kpm, causal, scale, "bt", "bt", p, key)
-    Tkp = (Tk + 1) // 2 * 2
     from importlib import import_module
-    keep = torch.from_numpy(import_module("chimera-st_amd.rng").keep_mask_attn_numpy(key, B * H * Tq * Tkp, p)).view(B, H, Tq, Tkp)[..., :Tk].cuda()
+    keep = torch.from_numpy(import_module("chimera-st_amd.rng").keep_mask_attn_numpy(key, B * H * Tq, Tk, p)).view(B, H, Tq, Tk).cuda()
     assert abs(float(keep.float().mean()) - (1 - p)) < 0.02
     qf, kf, vf = (t.detach().float().requires_grad_(True) for t in (q, kk, v))
     qh = qf.view(B, Tq, H, D).transpose(1, 2); kh = kf.view(B, Tk, H, D).transpose(1, 2); vh = vf.view(B, Tk, H, D).transpose(1, 2)
