@@ -760,7 +760,7 @@ extern "C" int cst_attn_fwd(const cst_attn_desc* d, cst_stream stream) {
   if (attn_fast_ok(d)) {
     CstProfScope prof(CST_K_ATTN_FWD, s, attn_flops(d, 2.0), 0.0);
     const unsigned nblk = (unsigned)(cst_ceil_div(d->Tq, 128) * d->H * d->B);
-    const size_t lds = 2 * FA_SLOT + 128 * (size_t)cst_ceil_div(d->Tk, 64);
+    const size_t lds = FA_NSLOT * FA_SLOT + 136 * (size_t)cst_ceil_div(d->Tk, 64);
     if (p.drop_thr) hipLaunchKernelGGL((fa_fwd_kernel<true>), dim3(nblk), dim3(256), lds, s, p);
     else hipLaunchKernelGGL((fa_fwd_kernel<false>), dim3(nblk), dim3(256), lds, s, p);
     return cst_check_launch("cst_attn_fwd");
@@ -793,7 +793,7 @@ extern "C" int cst_attn_bwd(const cst_attn_desc* d, cst_stream stream) {
     float* ws = (float*)d->bwd_ws;
     hipLaunchKernelGGL(fa_delta_kernel, dim3((unsigned)(Tq64 / 64), (unsigned)d->H, (unsigned)d->B), dim3(64), 0, s, p, ws, Tq64);
     const unsigned nq = (unsigned)(cst_ceil_div(d->Tq, 128) * d->H * d->B), nk = (unsigned)(cst_ceil_div(d->Tk, 128) * d->H * d->B);
-    const size_t lds_q = 2 * FA_SLOT + 128 * (size_t)cst_ceil_div(d->Tk, 64), lds_k = 2 * (FA_SLOT + FA_STATS);
+    const size_t lds_q = FA_NSLOT * FA_SLOT + 136 * (size_t)cst_ceil_div(d->Tk, 64), lds_k = FA_NSLOT * (FA_SLOT + FA_STATS);
     if (p.drop_thr) {
       hipLaunchKernelGGL((fa_dq_kernel<true>), dim3(nq), dim3(256), lds_q, s, p, (const float*)ws, Tq64);
       hipLaunchKernelGGL((fa_dkv_kernel<true>), dim3(nk), dim3(256), lds_k, s, p, (const float*)ws, Tq64);

@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
 """Attention kernels at the wav2vec2 encoder shape (B=32, T=1499, 12 heads x 64), with and without probability dropout,
-interleaved rounds in one process.  Usage (GPU box): python tools/bench_attn.py [rounds]"""
+interleaved rounds in one process.  Usage (GPU box): [ATT_B=.. ATT_T=.. ATT_SCALE=..] python tools/bench_attn.py [rounds]"""
 import importlib, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 K = importlib.import_module("chimera-st_amd.kernels")
 L = importlib.import_module("chimera-st_amd.lib")
-B, T, H, D = 32, 1499, 12, 64
+B, T, H, D = int(os.environ.get("ATT_B", 32)), int(os.environ.get("ATT_T", 1499)), 12, 64
+SC = float(os.environ.get("ATT_SCALE", 1.0))  # data scale: 0 = all-zero operands (clock / power probe)
 dt = torch.bfloat16
-q = torch.randn(B, T, H * D, device="cuda").to(dt); k = torch.randn_like(q); v = torch.randn_like(q)
-do = torch.randn_like(q)
+q = (SC * torch.randn(B, T, H * D, device="cuda")).to(dt); k = (SC * torch.randn(B, T, H * D, device="cuda")).to(dt); v = (SC * torch.randn(B, T, H * D, device="cuda")).to(dt)
+do = (SC * torch.randn(B, T, H * D, device="cuda")).to(dt)
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 fl = 4.0 * B * H * T * T * D
 

@@ -388,13 +388,13 @@ __global__ __launch_bounds__(256, WPS) void probe_stg(float* out, long long* cyc
 }
 
 template <int STG, bool CINIT, int XV, int WPS>
-void run_stg(const char* name, float* out, long long* cyc, int ntiles, const bf16_t* kv) {
+void run_stg(const char* name, float* out, long long* cyc, int ntiles, const bf16_t* kv, int rounds = 1) {
   const size_t lds = STG == 1 ? 4 * TILE * 2 : (STG == 2 ? 4 * 8192 : 6 * 8192);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_stg<STG, CINIT, XV, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
   int occ = 0;
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, probe_stg<STG, CINIT, XV, WPS>, 256, lds);
-  for (int W = 1; W <= occ && W <= 4; ++W) {
-    const int grid = 256 * W;
+  for (int W = (rounds > 1 ? occ : 1); W <= occ && W <= 4; ++W) {
+    const int grid = 256 * W * rounds;
     hipLaunchKernelGGL((probe_stg<STG, CINIT, XV, WPS>), dim3(grid), dim3(256), lds, 0, out, cyc, 48, 0.18f, kv, 96);
     (void)hipDeviceSynchronize();
     hipEvent_t e0, e1;
@@ -439,8 +439,8 @@ void run(const char* name, float* out, long long* cyc, int iters) {
 
 int main(int argc, char** argv) {
   float* out; long long* cyc;
-  (void)hipMalloc(&out, 1024 * 256 * 4);
-  (void)hipMallocManaged(&cyc, 1024 * 8);
+  (void)hipMalloc(&out, 8192 * 256 * 4);
+  (void)hipMallocManaged(&cyc, 8192 * 8);
   const int iters = 2048;
   const int which = argc > 1 ? atoi(argv[1]) : 3;
   if (which & 1) {
@@ -469,6 +469,15 @@ int main(int argc, char** argv) {
     run_stg<2, true, 0, 4>("LDS-DMA 2 slots, C-init (<=128 VGPR)", out, cyc, iters, kv);
     run_stg<1, false, 8, 3>("reg-staged, eager, +8 int/pair", out, cyc, iters, kv);
     run_stg<3, true, 4, 3>("LDS-DMA 3 slots, C-init, +4 int/pair", out, cyc, iters, kv);
+  }
+  if (which & 4) {  // short workgroups in several rounds, as the real launch has them (24 tiles, 6 rounds of 768 workgroups)
+    const size_t n = (size_t)8 * 1536 * GROW;
+    bf16_t* kv; (void)hipMalloc(&kv, n * 2);
+    (void)hipMemset(kv, 0x3c, n * 2);
+    run_stg<2, true, 0, 3>("DMA 2 slots C-init, 24 tiles x 6 rounds", out, cyc, 24, kv, 6);
+    run_stg<2, true, 0, 3>("DMA 2 slots C-init, 24 tiles x 1 round", out, cyc, 24, kv, 1);
+    run_stg<2, true, 0, 3>("DMA 2 slots C-init, 96 tiles x 6 rounds", out, cyc, 96, kv, 6);
+    run_stg<2, true, 0, 3>("DMA 2 slots C-init, 2048 tiles x 1 round", out, cyc, 2048, kv, 1);
   }
   return 0;
 }
