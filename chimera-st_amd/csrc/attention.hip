@@ -738,7 +738,7 @@ double attn_flops(const cst_attn_desc* d, double gemms) {
 
 // the DMA-staged kernels cover the hot configuration: bf16, head dim 64, no causal mask, key masks as packed tile words (or none)
 bool attn_fast_ok(const cst_attn_desc* d) {
-  static const bool off = getenv("CST_ATTN_GENERIC") != nullptr;  // test / A-B hook: the generic kernels for everything
+  const bool off = getenv("CST_ATTN_GENERIC") != nullptr;  // test / A-B hook (read per call: tools toggle it in-process): the generic kernels for everything
   return !off && d->dtype == CST_BF16 && d->D == 64 && !d->causal && (d->key_padding_mask == nullptr || d->kpm_bits != nullptr) &&
          d->Tk <= 65536 && (int64_t)d->Tk * d->k_st < (1ll << 29) && (int64_t)d->Tq * d->q_st < (1ll << 29) && (int64_t)d->Tk * d->v_st < (1ll << 29) &&
          d->o_st % 8 == 0 && d->o_sh % 8 == 0 && d->o_sb % 8 == 0 && (uintptr_t)d->O % 16 == 0;
@@ -759,7 +759,7 @@ extern "C" int cst_attn_fwd(const cst_attn_desc* d, cst_stream stream) {
   hipStream_t s = (hipStream_t)stream;
   if (attn_fast_ok(d)) {
     CstProfScope prof(CST_K_ATTN_FWD, s, attn_flops(d, 2.0), 0.0);
-    const unsigned nblk = (unsigned)(cst_ceil_div(d->Tq, 128) * d->H * d->B);
+    const unsigned nblk = fa_grid(d->Tq, d->B, d->H);
     const size_t lds = FA_NSLOT * FA_SLOT + 136 * (size_t)cst_ceil_div(d->Tk, 64);
     if (p.drop_thr) hipLaunchKernelGGL((fa_fwd_kernel<true>), dim3(nblk), dim3(256), lds, s, p);
     else hipLaunchKernelGGL((fa_fwd_kernel<false>), dim3(nblk), dim3(256), lds, s, p);
@@ -792,7 +792,7 @@ extern "C" int cst_attn_bwd(const cst_attn_desc* d, cst_stream stream) {
     const int64_t Tq64 = cst_ceil_div(d->Tq, 64) * 64;
     float* ws = (float*)d->bwd_ws;
     hipLaunchKernelGGL(fa_delta_kernel, dim3((unsigned)(Tq64 / 64), (unsigned)d->H, (unsigned)d->B), dim3(64), 0, s, p, ws, Tq64);
-    const unsigned nq = (unsigned)(cst_ceil_div(d->Tq, 128) * d->H * d->B), nk = (unsigned)(cst_ceil_div(d->Tk, 128) * d->H * d->B);
+    const unsigned nq = fa_grid(d->Tq, d->B, d->H), nk = fa_grid(d->Tk, d->B, d->H);
     const size_t lds_q = FA_NSLOT * FA_SLOT + 136 * (size_t)cst_ceil_div(d->Tk, 64), lds_k = FA_NSLOT * (FA_SLOT + FA_STATS);
     if (p.drop_thr) {
       hipLaunchKernelGGL((fa_dq_kernel<true>), dim3(nq), dim3(256), lds_q, s, p, (const float*)ws, Tq64);
