@@ -128,6 +128,9 @@ def train_main(argv=None):
             if out is None:  # a rank ran out of memory: every rank dropped this update (trainer.py:564-570)
                 _log(rank, event="oom_skipped_update", epoch=epoch, num_updates=trainer.num_updates)
                 continue
+            if out.get("overflow"):  # NaN / Inf gradients: every rank dropped this update (trainer.py:629-646)
+                _log(rank, event="nonfinite_gradient_skipped_update", epoch=epoch, num_updates=trainer.num_updates)
+                continue
             for k, v in out.items():
                 agg[k] = agg.get(k, 0.0) + (v if k not in ("lr", "gnorm") else 0.0)
             if trainer.num_updates % max(args.log_interval, 1) == 0:
@@ -140,6 +143,8 @@ def train_main(argv=None):
                 break
         if group and trainer.num_updates < max_update:  # the epoch's tail group is a (smaller) update of its own (iterators.py GroupedIterator)
             out = trainer.train_step(group)
+            if out is not None and out.get("overflow"):
+                out = None
             for k, v in (out or {}).items():
                 agg[k] = agg.get(k, 0.0) + (v if k not in ("lr", "gnorm") else 0.0)
         ss = max(agg.get("sample_size", 1.0), 1.0)

@@ -71,6 +71,12 @@ class LabelSmoothedCrossEntropyCriterion(FairseqCriterion):
     def logging_outputs_can_be_summed() -> bool:
         return True
 
+    @staticmethod
+    def logging_keys():
+        """The keys of logging_output, known without running a batch: a rank that runs out of memory in its FIRST update still has to
+        build the all-reduced statistics vector in the other ranks' layout (trainer.py:564-570)."""
+        return ("loss", "nll_loss", "ntokens", "nsentences", "sample_size")
+
 
 @register_criterion("triplet_st_mt_contrastive")
 class TripletSTMTContrastiveCriterion(LabelSmoothedCrossEntropyCriterion):
@@ -146,3 +152,8 @@ class TripletSTMTContrastiveCriterion(LabelSmoothedCrossEntropyCriterion):
     @staticmethod
     def logging_outputs_can_be_summed() -> bool:
         return True
+
+    @staticmethod
+    def logging_keys():
+        return ("loss", "nll_loss", "st_loss", "st_nll_loss", "mt_loss", "mt_nll_loss", "contrastive_loss", "ntokens", "nsentences",
+                "sample_size")

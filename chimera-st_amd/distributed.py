@@ -81,6 +81,8 @@ class BucketedGradAllReduce:
                 self.param_bucket[idx] = b
         self.enabled = True
         self.last_early, self.last_missing = 0, []
+        self.late_params = []
+        self._offsets = list(offsets)
         self._hooks = []
         self._index = {id(p): idx for idx, p in enumerate(self.params)}
         for idx, p in enumerate(self.params):
@@ -107,7 +109,7 @@ class BucketedGradAllReduce:
         self._works = []
         self._skipped = set()
         self._fired = set()
-        self._late = set()  # buckets whose all-reduce went out before one of their gradients existed (re-reduced in finish)
+        self._late = set()  # parameters whose bucket's all-reduce went out before their gradient existed (reduced again, alone)
 
     def _make_hook(self, idx):
         def hook(param):
@@ -116,11 +118,20 @@ class BucketedGradAllReduce:
             b = self.param_bucket[idx]
             again = idx in self._fired  # a second backward pass through the same parameter accumulates into its gradient
             self._fired.add(idx)
-            if idx in self._skipped or again:
-                # reported unused by one forward pass (layerdrop) but used by another pass of the same update, or hit twice: it was
-                # already counted.  If its bucket has left, that all-reduce carried a stale gradient: reduce the bucket again.
+            if again:
+                # Not supported once the bucket has left: after the launch p.grad IS the flat-buffer slice the asynchronous
+                # all-reduce is writing (gather_grads re-points it), so autograd's in-place accumulation of a second gradient
+                # races with the collective and the slice already holds the mean.  Accumulate under no_sync() instead
+                # (update_freq micro-batches do exactly that: only the last backward runs with the reducer enabled).
                 if b < self._next:
-                    self._late.add(b)
+                    raise RuntimeError("gradient of parameter %d arrived a second time after its bucket's all-reduce was launched: "
+                                       "run every backward pass but the last one under DistributedFairseqModel.no_sync()" % idx)
+                return
+            if idx in self._skipped:
+                # reported unused by the forward pass (layerdrop) but it took part after all: it was already counted.  If its
+                # bucket has left, that all-reduce carried zeros for it: this parameter is reduced again, alone (late_reduce)
+                if b < self._next:
+                    self._late.add(idx)
                 return
             self._pending[b] -= 1
             if self._pending[b] == 0:
@@ -142,8 +153,26 @@ class BucketedGradAllReduce:
             self._launch(self._next)
             self._next += 1
 
+    def late_reduce(self, indices):
+        """All-reduce the gradients of `indices` (parameters whose bucket left without them) on their own.  EVERY rank calls this
+        with the SAME list: the trainer agrees on it through the statistics all-reduce (a rank that lost its forward pass to an
+        out-of-memory error has no late parameters of its own, and an update that is going to be dropped skips the call).  Only
+        the late parameter's slice is touched, so the members of its bucket that were already averaged are not divided again."""
+        works = []
+        for idx in indices:
+            if self.gather is not None:
+                self.gather([idx])
+            p = self.params[idx]
+            g = self.flat_grad[self._offsets[idx]:self._offsets[idx] + p.numel()]
+            g.div_(self.world)
+            works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        for w in works:
+            w.wait()
+
     def finish(self):
-        """Launch whatever has not been reduced yet (parameters without gradient stay zero) and wait for everything."""
+        """Launch whatever has not been reduced yet (parameters without gradient stay zero) and wait for everything.  Leaves the
+        parameters that need a second, rank-agreed reduction in `late_params` (see late_reduce)."""
+        self.late_params = []
         if self.active and self.enabled:
             # overlap bookkeeping of the update that just ended: buckets launched from hooks, parameters nobody accounted for
             self.last_early = self._next
@@ -153,14 +182,8 @@ class BucketedGradAllReduce:
                 self._next += 1
             for w in self._works:
                 w.wait()
-            if self._late:
-                # every rank runs the same forward passes in the same order, so `_late` is the same set everywhere.  The stale
-                # reduction is discarded: the bucket is re-gathered from the (now complete) local gradients and reduced again.
-                self._works = []
-                for b in sorted(self._late):
-                    self._launch(b)
-                for w in self._works:
-                    w.wait()
+            self._works = []
+            self.late_params = sorted(self._late)
         self.reset()
 
 

@@ -37,7 +37,16 @@ class Trainer:
         self.num_updates = 0
         self.dtype = dtype
         self._dummy_batch = None
-        self._log_keys = None
+        # layout of the all-reduced statistics vector: fixed by the criterion, not by the first batch — a rank that runs out of
+        # memory before it ever completed an update must still be able to build the vector the other ranks are reducing
+        keys = getattr(self.criterion, "logging_keys", None)
+        self._log_keys = sorted(keys()) if keys is not None else None
+        assert self._log_keys is not None or not self.ddp, "data-parallel training needs criterion.logging_keys()"
+        # non-finite gradients: skip the update on every rank; give up after this many in a row (the reference's DynamicLossScaler
+        # halves the scale from 2^7 down to min_loss_scale = 1e-4 before raising FloatingPointError: 20 consecutive overflows,
+        # optim/dynamic_loss_scaler.py:42-70)
+        self.nonfinite_tolerance = int(getattr(args, "nonfinite_tolerance", 20))
+        self._nonfinite_run = 0
 
     def get_model(self):
         return self._model
@@ -109,17 +118,23 @@ class Trainer:
             self.model.all_reduce()  # waits for the overlapped bucket reductions; launches the stragglers
         else:
             self.buffers.gather_grads()  # one multi-tensor copy of every autograd-owned gradient into the flat buffer
-        # logging scalars + sample_size + OOM flag + one gradient-norm slot per rank: ONE fp64 device vector, one small
-        # all-reduce, one host read
-        if logs:
+        # logging scalars + sample_size + OOM flag + late-gradient count + one gradient-norm slot per rank: ONE fp64 device vector,
+        # one small all-reduce, one host read
+        if self._log_keys is None:
+            assert logs, "out of memory before any update completed and the criterion does not declare logging_keys()"
             self._log_keys = sorted(logs[0].keys())
         keys = self._log_keys
-        assert keys is not None, "out of memory before any update completed: no logging layout to all-reduce"
         zero = torch.zeros((), dtype=torch.float64, device=self.device)
         stats = [sum((torch.as_tensor(l[k], dtype=torch.float64, device=self.device) for l in logs), zero) for k in keys]
-        slots = torch.zeros(self.world, dtype=torch.float64, device=self.device)
-        slots[self.rank] = self.optimizer.grad_sumsq()[0].double()
-        vec = torch.cat([torch.stack(stats), torch.tensor([float(ooms)], dtype=torch.float64, device=self.device), slots])
+        late = list(self.model.reducer.late_params) if self.ddp else []
+
+        def norm_slots():
+            slots = torch.zeros(self.world, dtype=torch.float64, device=self.device)
+            slots[self.rank] = self.optimizer.grad_sumsq()[0].double()
+            return slots
+
+        vec = torch.cat([torch.stack(stats), torch.tensor([float(ooms), float(len(late))], dtype=torch.float64, device=self.device),
+                         norm_slots()])
         if self.ddp:
             dist.all_reduce(vec)
         vals = vec.tolist()  # the step's only host sync
@@ -127,8 +142,33 @@ class Trainer:
         if vals[len(keys)] != 0:  # some rank lost this update's gradients: nobody steps (trainer.py:564-570)
             self.optimizer.zero_grad()
             return None
-        sumsq = vals[len(keys) + 1:]
-        self._check_grad_norms(sumsq)
+        sumsq = vals[len(keys) + 2:]
+        self.last_late_count = int(vals[len(keys) + 1])  # diagnostics: late gradients seen by all ranks in this update
+        if vals[len(keys) + 1] != 0:
+            # some rank saw a gradient arrive after its bucket had been reduced (a parameter reported unused that took part after
+            # all).  Rare; every rank takes this branch together: agree on the parameter set (element-wise MAX of a 0/1 mask),
+            # reduce those parameters again and exchange the norms of the corrected gradients.
+            mask = torch.zeros(len(self.buffers.params), dtype=torch.int32, device=self.device)
+            if late:
+                mask[torch.tensor(late, device=self.device)] = 1
+            dist.all_reduce(mask, op=dist.ReduceOp.MAX)
+            self.model.reducer.late_reduce([i for i, m in enumerate(mask.tolist()) if m])
+            slots = norm_slots()
+            dist.all_reduce(slots)
+            sumsq = slots.tolist()
+        self._check_grad_norms(sumsq)  # raises when the replicas disagree (a mix of finite and non-finite norms included)
+        if not all(math.isfinite(v) for v in sumsq):
+            # NaN / Inf in the reduced gradient (every rank holds the same vector, so every rank is here): drop the update, as the
+            # reference does on an fp16 overflow (trainer.py:629-646, optim/fp16_optimizer.py:182); master weights and both Adam
+            # moments stay untouched.  A persistent condition is an error (optim/dynamic_loss_scaler.py:58-66).
+            self.optimizer.zero_grad()
+            self._nonfinite_run += 1
+            if self._nonfinite_run > self.nonfinite_tolerance:
+                raise FloatingPointError("gradients are NaN/Inf in %d consecutive updates (update %d): giving up"
+                                         % (self._nonfinite_run, self.num_updates))
+            out.update(overflow=1.0, gnorm=float("nan"), lr=self.optimizer.get_lr())
+            return out
+        self._nonfinite_run = 0
         multiply = self.world / out["sample_size"] if out["sample_size"] > 0 else 0.0
         out["gnorm"] = self.optimizer.step(multiply=multiply, gnorm=math.sqrt(sumsq[self.rank]) * multiply)
         self.num_updates += 1
@@ -139,9 +179,9 @@ class Trainer:
         """trainer.py:1045-1077 — replicas all-reduce the same buckets in the same order, so their gradient norms must agree to
         rounding; anything else (a rank that skipped a bucket, mixed hardware, a corrupted buffer) is fatal."""
         norms = [math.sqrt(v) if v >= 0 and math.isfinite(v) else float("nan") for v in sumsq]
-        if len(norms) < 2 or not all(math.isfinite(n) for n in norms):
-            return  # a non-finite norm is the overflow / NaN path's business (every rank sees the same vector)
-        if max(abs(n - norms[0]) for n in norms) / (norms[0] + 1e-6) < 1e-6:
+        if len(norms) < 2 or not any(math.isfinite(n) for n in norms):
+            return  # the reference's predicate: all-non-finite is the overflow path's business, a mix of finite and not is fatal
+        if all(math.isfinite(n) for n in norms) and max(abs(n - norms[0]) for n in norms) / (norms[0] + 1e-6) < 1e-6:
             return
         detail = "\n".join("rank {:3d} = {:.8f}".format(r, n) for r, n in enumerate(norms))
         raise RuntimeError("Fatal error: gradients are inconsistent between workers.\n" + "-" * 80 +

@@ -118,6 +118,38 @@ def test_bf16_trainer_runs_and_decreases_loss():
     assert all(np.isfinite(losses)) and losses[-1] < 0.8 * losses[0]
 
 
+def test_nonfinite_gradient_skips_the_update_and_leaves_the_optimizer_untouched():
+    """A batch that produces Inf / NaN gradients (trainer.py:629-646, optim/dynamic_loss_scaler.py:42-70): the update is dropped — fp32
+    master weights, both Adam moments, the bf16 parameters and the update counter are bit-unchanged — the next clean batch trains on,
+    and a persistent condition raises FloatingPointError."""
+    g0 = load_golden("chimera_tiny.npz")
+    model, task, args = build_from_golden(g0, "chimera", torch.float32)
+    crit = import_module("chimera-st_amd.criterions").TripletSTMTContrastiveCriterion(task, False, 0.1, [1.0, 1.0, 1.0], 0.1)
+    Trainer = import_module("chimera-st_amd.trainer").Trainer
+    targs = Namespace(bf16=True, lr=[2e-3], adam_betas="(0.9, 0.98)", adam_eps=1e-8, weight_decay=0.0, clip_norm=1.0,
+                      warmup_updates=1, warmup_init_lr=2e-3, seed=1, nonfinite_tolerance=2)
+    tr = Trainer(targs, task, model, crit, device="cuda")
+    sample = golden_sample(g0)
+    assert np.isfinite(tr.train_step([sample])["loss"])
+    opt = tr.optimizer
+    before = [t.clone() for t in (opt.master, opt.exp_avg, opt.exp_avg_sq, tr.buffers.flat_param)]
+    bad = {k: (dict(v) if isinstance(v, dict) else v) for k, v in sample.items()}
+    wav = bad["net_input"]["src_tokens"].clone().float()
+    wav[0, 100] = float("inf")
+    bad["net_input"]["src_tokens"] = wav
+    out = tr.train_step([bad])
+    assert out is not None and out["overflow"] == 1.0 and np.isnan(out["gnorm"]) and tr.num_updates == 1 and opt.num_updates == 1
+    for a, b in zip(before, (opt.master, opt.exp_avg, opt.exp_avg_sq, tr.buffers.flat_param)):
+        assert torch.equal(a, b)
+    assert float(tr.buffers.flat_grad.float().abs().max()) == 0.0  # the poisoned gradient is gone
+    good = tr.train_step([sample])
+    assert np.isfinite(good["loss"]) and np.isfinite(good["gnorm"]) and tr.num_updates == 2
+    with pytest.raises(FloatingPointError):
+        for _ in range(4):
+            tr.train_step([bad])
+    assert tr.num_updates == 2
+
+
 def _resume_trainer(path, arg_overrides=None):
     CU = import_module("chimera-st_amd.checkpoint_utils")
     (model,), args, task = CU.load_model_ensemble_and_task([path], arg_overrides=arg_overrides)

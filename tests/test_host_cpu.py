@@ -2,6 +2,7 @@
 synthetic batches, schedules, positional tables vs the oracle, flat parameter buffers, state-dict key compatibility
 with the reference fixtures, and the world_size-2 gloo path of the bucketed gradient all-reduce."""
 import ast
+import math
 import os
 import socket
 from argparse import Namespace
@@ -261,9 +262,15 @@ class _ToyCriterion(torch.nn.Module):
         if self.fail_next:
             self.fail_next = False
             raise RuntimeError("HIP out of memory. Tried to allocate 20.00 GiB (injected by the test)")
+        if getattr(self, "report_unused", None) is not None:  # what wav2vec2 layerdrop does for a skipped layer — wrongly, here
+            import_module("chimera-st_amd.distributed").notify_unused_parameters(self.report_unused)
         loss = model(sample["x"]).pow(2).sum()
         n = sample["x"].shape[0]
         return loss, n, {"loss": loss.detach(), "sample_size": n, "ntokens": n, "nsentences": n}
+
+    @staticmethod
+    def logging_keys():
+        return ("loss", "sample_size", "ntokens", "nsentences")
 
 
 def _cpu_trainer(rank):
@@ -294,9 +301,50 @@ def _guard_worker(rank, world, port, q, mode):
     g = torch.Generator().manual_seed(100 + rank)
     batch = lambda: {"x": torch.randn(5, 6, generator=g)}
     out = {"rank": rank}
+    if mode == "oom_first":  # out of memory in the very FIRST update of rank 1: it has never seen a logging output
+        if rank == 1:
+            tr.criterion.fail_next = True
+        out["first_none"] = tr.train_step([batch()]) is None and tr.num_updates == 0
     o1 = tr.train_step([batch()])
     out["step1"] = (o1["sample_size"], o1["gnorm"], tr.buffers.flat_param.clone().numpy())
-    if mode == "oom":
+    if mode == "nonfinite":
+        tr.nonfinite_tolerance = 2
+        before = tr.buffers.flat_param.clone()
+        bad = batch()
+        if rank == 1:
+            bad["x"][0, 0] = float("inf")  # one rank's batch blows up; the all-reduced gradient is non-finite everywhere
+        o2 = tr.train_step([bad])
+        out["skipped"] = bool(o2 is not None and o2.get("overflow") == 1.0 and math.isnan(o2["gnorm"]))
+        out["unchanged"] = bool(torch.equal(before, tr.buffers.flat_param)) and tr.num_updates == 1
+        o3 = tr.train_step([batch()])  # a clean update goes through and resets the run counter
+        out["step3"] = (o3["sample_size"], tr.buffers.flat_param.clone().numpy(), tr.num_updates)
+        raised = None
+        try:
+            for _ in range(4):
+                b = batch()
+                b["x"][0, 0] = float("nan")
+                tr.train_step([b])
+        except FloatingPointError as e:
+            raised = str(e)
+        out["raised"] = raised
+        out["updates_at_raise"] = tr.num_updates
+    elif mode in ("late", "late_oom"):
+        # a parameter reported unused that takes part after all: its bucket may leave without its gradient; the ranks agree on the
+        # late set through the statistics vector and reduce it again.  late_oom: rank 1 loses its pass (no late set of its own).
+        w0 = tr.get_model()[0].weight
+        tr.criterion.report_unused = [w0]
+        if mode == "late_oom" and rank == 1:
+            tr.criterion.fail_next = True
+        xs = batch()
+        o2 = tr.train_step([xs])
+        tr.criterion.report_unused = None
+        out["step2_none"] = o2 is None
+        out["x"] = xs["x"].numpy()
+        out["param"] = tr.buffers.flat_param.clone().numpy()
+        out["updates"] = tr.num_updates
+        out["late_count"] = getattr(tr, "last_late_count", None)
+        out["offsets"] = list(tr.buffers.offsets)
+    elif mode == "oom":
         before = tr.buffers.flat_param.clone()
         if rank == 1:
             tr.criterion.fail_next = True  # rank 1 loses its forward pass; rank 0 completes a normal backward
@@ -323,7 +371,7 @@ def _guard_worker(rank, world, port, q, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["oom", "diverge"])
+@pytest.mark.parametrize("mode", ["oom", "oom_first", "diverge", "nonfinite", "late", "late_oom"])
 def test_trainer_oom_flag_and_grad_norm_check_gloo_world2(mode):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
@@ -343,6 +391,36 @@ def test_trainer_oom_flag_and_grad_norm_check_gloo_world2(mode):
             assert r["step2_none"] and r["unchanged"], r  # BOTH ranks dropped the update although only rank 1 failed
             assert r["step3"][0] == 10.0 and r["step3"][2] == 2
         np.testing.assert_array_equal(res[0]["step3"][1], res[1]["step3"][1])
+    elif mode == "oom_first":
+        assert all(r["first_none"] for r in res)  # nobody hung in a collective, nobody stepped
+    elif mode == "nonfinite":
+        for r in res:
+            assert r["skipped"] and r["unchanged"], r  # inf on ONE rank: every rank skipped, parameters bit-unchanged
+            assert r["step3"][0] == 10.0 and r["step3"][2] == 2
+            assert r["raised"] is not None and "consecutive" in r["raised"] and r["updates_at_raise"] == 2  # tolerance 2 -> third one raises
+        np.testing.assert_array_equal(res[0]["step3"][1], res[1]["step3"][1])
+    elif mode == "late":
+        # the update equals plain SGD on the mean gradient of the two batches, the late parameter included
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(6, 40), torch.nn.ReLU(), torch.nn.Linear(40, 4))
+        flat0, offs = res[0]["step1"][2], res[0]["offsets"]
+        params = list(net.parameters())
+        with torch.no_grad():
+            for p_, o in zip(params, offs):
+                p_.copy_(torch.from_numpy(flat0[o:o + p_.numel()]).view(p_.shape))
+        sum(net(torch.from_numpy(r["x"])).pow(2).sum() for r in res).backward()
+        for p_, o in zip(params, offs):  # SGD stand-in: param -= lr * (world / sample_size) * mean gradient
+            want = (p_ - 1e-2 * (2 / 10.0) * p_.grad / 2).detach().reshape(-1).numpy()
+            np.testing.assert_allclose(res[0]["param"][o:o + p_.numel()], want, rtol=1e-5, atol=1e-6)
+        for r in res:
+            assert not r["step2_none"] and r["updates"] == 2
+            assert r["late_count"] == 2, r["late_count"]  # both ranks saw the gradient arrive after its bucket had left
+        np.testing.assert_array_equal(res[0]["param"], res[1]["param"])
+        assert not np.array_equal(res[0]["param"], res[0]["step1"][2])
+    elif mode == "late_oom":
+        for r in res:
+            assert r["step2_none"] and r["updates"] == 1  # dropped together, no deadlock on mismatched late sets
+        np.testing.assert_array_equal(res[0]["param"], res[1]["param"])
     else:
         for r in res:  # every rank sees every rank's norm in the all-reduced vector: all of them stop
             assert r["raised"] is not None and "gradients are inconsistent between workers" in r["raised"] and "rank   1" in r["raised"]
