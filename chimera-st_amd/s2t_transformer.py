@@ -33,6 +33,14 @@ class Conv1dSubsampler(nn.Module):
             conv.kernel_size = k
             self.conv_layers.append(conv)
 
+    def input_reach(self):
+        """How many input frames past the last real one the last real OUTPUT frame reads: r <- r * stride + (k - 1 - pad) from the
+        last layer to the first (k = 5, stride 2, pad 2, two layers: 6)."""
+        r = 0
+        for conv in reversed(self.conv_layers):
+            r = 2 * r + (conv.kernel_size - 1 - conv.kernel_size // 2)
+        return r
+
     def get_out_seq_lens_tensor(self, in_seq_lens_tensor):
         out = in_seq_lens_tensor.clone()
         for _ in range(self.n_layers):

@@ -97,6 +97,8 @@ class S2T_W2V2_TransformerEncoder(FairseqEncoder):
         self.padding_idx = 1
         self.subsample = Conv1dSubsampler(self.w2v_args.encoder_embed_dim, args.conv_channels, args.encoder_embed_dim,
                                           [int(k) for k in args.conv_kernel_sizes.split(",")])
+        if not self.wav2vec_model.encoder.padding_rows_consumed:
+            self.wav2vec_model.encoder.padding_rows_read = self.subsample.input_reach()
         self.embed_positions = PositionalEmbedding(args.max_source_positions, args.encoder_embed_dim, self.padding_idx)
         self.transformer_layers = nn.ModuleList([TransformerEncoderLayer(args) for _ in range(args.encoder_layers)])
         self.layer_norm = LayerNorm(args.encoder_embed_dim) if args.encoder_normalize_before else None

@@ -182,9 +182,20 @@ class TransformerEncoder(nn.Module):
     # every later layer masks the padding); the Chimera memory attends every padded frame (quirk Q1), so there the padded stack
     # stays whenever a dropout is active.
     padding_rows_consumed = True
+    # how many frames past an utterance's end the consumer reads when it does not consume the padding rows (s2t encoder: the reach of
+    # its Conv1dSubsampler, 6 frames for two k = 5 / stride 2 layers).  None = unknown: keep the positional convolution's reach.
+    padding_rows_read = None
 
     def packing_margin(self):
-        return self.conv_pos // 2
+        """Padding frames kept per utterance in front of the one representative row.  Bit-identity with the padded stack on EVERY
+        frame needs the positional convolution's reach (conv_pos // 2: behind it all padding frames are one and the same vector);
+        a consumer that reads only `padding_rows_read` frames past the end needs only those computed exactly — the frames behind
+        them are then copies of a row nobody reads (forward bits of every frame that IS read, and every gradient, are unchanged:
+        rows do not interact except through attention, whose keys are the real frames).  6 % fewer rows at the bench's lengths."""
+        reach = self.conv_pos // 2
+        if not self.padding_rows_consumed and self.padding_rows_read is not None:
+            reach = min(reach, int(self.padding_rows_read))
+        return reach
 
     def wants_packing(self, padding_mask):
         if padding_mask is None or os.environ.get("CST_NO_PACK"):

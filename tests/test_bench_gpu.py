@@ -38,12 +38,18 @@ def test_bench_line_contract():
     assert r["unit"] in ("TFLOP/s", "GB/s") and r["launches"] > 0 and r["avg_launch_ms"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == "utterances/s" and c["sample"]
+    assert c["reference_equivalent"]["value"] > c["value"] and c["reference_equivalent"]["source"].startswith("profiles/")
+    assert d["config"]["h2d"]["included_in_value"] is False and d["config"]["h2d"]["value_with_h2d"] > 0
+    # the default 1-GPU run also carries BASELINE configs 4 (Chimera) and 5 (beam-search decode) measured on the same box
+    x = d["extra"]
+    assert x["chimera"]["value"] > 0 and x["chimera"]["unit"] == "utterances/s" and x["chimera"]["roofline"]["frac"] > 0
+    assert x["decode"]["value"] > 0 and x["decode"]["ms_per_decode_step"] > 0 and x["decode"]["roofline"]["bound"] == "hbm"
 
 
 def test_bench_under_a_process_group():
     """The N > 1 launch path on the one configuration a 1-GPU box offers: a 1-rank RCCL group with the collective path forced on
     (RANK / WORLD_SIZE / MASTER_* from the environment, as torch.distributed.run sets them)."""
-    d = _run(["--no-cpu-baseline", "--no-roofline"], env=dict(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+    d = _run(["--no-cpu-baseline", "--no-roofline", "--no-extra"], env=dict(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                                                                 MASTER_PORT="29541", CST_DDP_FORCE="1"))
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
 

@@ -6,9 +6,9 @@ TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${TAG}_prof; mkdir -p $O
 BUILD=${2:-unrecorded}
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O/trace -o trace -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $O/trace.log 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_mfma -o pmc -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_mfma.log 2>&1
-rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum GRBM_GUI_ACTIVE -d $O/pmc_hbm -o pmc -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_hbm.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/trace -o trace -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-extra > $O/trace.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_mfma -o pmc -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-extra > $O/pmc_mfma.log 2>&1
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum GRBM_GUI_ACTIVE -d $O/pmc_hbm -o pmc -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-extra > $O/pmc_hbm.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/dec_trace -o trace -- python3 $R/bench.py --mode decode > $O/dec_trace.log 2>&1
 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum -d $O/pmc_one_ea -o pmc -- python3 $R/tools/gemm_one.py kk 47968 3072 768 3 fc1 > $O/pmc_one_ea.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $O/pmc_one_hm -o pmc -- python3 $R/tools/gemm_one.py kk 47968 3072 768 3 fc1 > $O/pmc_one_hm.log 2>&1
@@ -24,8 +24,8 @@ rm -rf $O/trace $O/pmc_mfma $O/pmc_hbm $O/dec_trace $O/pmc_one_ea $O/pmc_one_hm
 # the bench lines below quote the counter files of THIS build
 cp $O/${TAG}_pmc_gemm_class.json $O/${TAG}_pmc_gemm.json $R/profiles/
 python bench.py > $O/${TAG}_bench_s2t.json 2> $O/bench_s2t.err
-python bench.py --model chimera --no-cpu-baseline > $O/${TAG}_bench_chimera.json 2> $O/bench_chimera.err
-python bench.py --dropout 0 --no-cpu-baseline > $O/${TAG}_bench_dropout0.json 2> $O/bench_dropout0.err
+python bench.py --model chimera --no-cpu-baseline --no-extra > $O/${TAG}_bench_chimera.json 2> $O/bench_chimera.err
+python bench.py --dropout 0 --no-cpu-baseline --no-extra > $O/${TAG}_bench_dropout0.json 2> $O/bench_dropout0.err
 python bench.py --mode decode > $O/${TAG}_bench_decode.json 2> $O/bench_decode.err
-python bench.py --lengths max --no-cpu-baseline > $O/${TAG}_bench_maxlen.json 2> $O/bench_maxlen.err
+python bench.py --lengths max --no-cpu-baseline --no-extra > $O/${TAG}_bench_maxlen.json 2> $O/bench_maxlen.err
 ls -la $O; du -sh $O
