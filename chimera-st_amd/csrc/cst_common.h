@@ -16,6 +16,7 @@ struct CstProfScope {
   int cls; hipStream_t s; int slot;
   CstProfScope(int cls, hipStream_t s, double flops, double bytes);
   ~CstProfScope();
+  void tag(const char* fmt, ...);  // free-form description of this launch (shape, kernel family) for cst_prof_dump; no-op when off
 };
 int cst_check_launch(const char* what);
 bool cst_prof_is_on();  // the hipEvent profiling table of bench.py's roofline step is recording

@@ -27,6 +27,7 @@ int cst_check_launch(const char* what) {
 struct ProfRec {
   hipEvent_t start, stop;
   double flops, bytes;
+  char tag[96];
 };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
@@ -38,12 +39,22 @@ CstProfScope::CstProfScope(int cls_, hipStream_t s_, double flops, double bytes)
   ProfRec r;
   r.flops = flops;
   r.bytes = bytes;
+  r.tag[0] = 0;
   if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
   (void)hipEventRecord(r.start, s);
   g_prof[cls].push_back(r);
   slot = (int)g_prof[cls].size() - 1;
 }
 bool cst_prof_is_on() { return g_prof_on; }
+
+void CstProfScope::tag(const char* fmt, ...) {
+  if (slot < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_prof[cls][slot].tag, sizeof(g_prof[cls][slot].tag), fmt, ap);
+  va_end(ap);
+}
 
 CstProfScope::~CstProfScope() {
   if (slot < 0) return;
@@ -93,6 +104,25 @@ int64_t cst_prof_query(int cls, double* total_ms, double* flops, double* bytes) 
   if (flops) *flops = fl;
   if (bytes) *bytes = by;
   return (int64_t)g_prof[cls].size();
+}
+
+/* one text line per recorded launch of the class, in launch order: "<ms> <flops> <bytes> <tag>\n"; returns the bytes needed
+ * (including the terminating 0) — call with cap = 0 to size the buffer */
+int64_t cst_prof_dump(int cls, char* buf, int64_t cap) {
+  if (cls < 0 || cls >= CST_K_NUM) return -1;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  int64_t need = 1, at = 0;
+  for (auto& r : g_prof[cls]) {
+    (void)hipEventSynchronize(r.stop);
+    float t = 0;
+    (void)hipEventElapsedTime(&t, r.start, r.stop);
+    char line[192];
+    const int n = snprintf(line, sizeof(line), "%.6f %.6g %.6g %s\n", t, r.flops, r.bytes, r.tag);
+    need += n;
+    if (buf && at + n < cap) { memcpy(buf + at, line, (size_t)n); at += n; }
+  }
+  if (buf && cap > 0) buf[at < cap ? at : cap - 1] = 0;
+  return need;
 }
 
 }  // extern "C"

@@ -938,6 +938,10 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
 #undef CST_GEMM_DISPATCH
 #undef CST_GEMM_LAYOUT
 #undef CST_GLDS_LAYOUT
+  if (cst_prof_is_on())
+    prof.tag("M=%lld N=%lld K=%lld b=%lld a%c b%c split=%d%s%s%s%s%s%s%s", (long long)d->M, (long long)d->N, (long long)d->K, (long long)nbatch, ak ? 'k' : 'm',
+             bk ? 'k' : 'm', p.splits, d->bias ? " bias" : "", d->act ? " act" : "", d->aux_out ? " aux_out" : "", d->dact ? " dact" : "",
+             d->resid ? " resid" : "", d->drop_p > 0 ? " drop" : "", (d->k_live || d->m_live || d->k_len || d->m_len) ? " live" : "");
   if (rc != CST_OK) return rc;
   if (p.splits > 1) {
     const int64_t total = d->M * d->N;

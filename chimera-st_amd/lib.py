@@ -100,6 +100,7 @@ SYMBOLS = [
     ("cst_layernorm_bwd_tiles", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_int, c_int, c_p, ctypes.c_uint32, c_p]),
     ("cst_gemm_workspace", c_i64, [ctypes.POINTER(GemmDesc)]),
     ("cst_gemm", c_int, [ctypes.POINTER(GemmDesc), c_p]),
+    ("cst_prof_dump", c_i64, [c_int, ctypes.c_char_p, c_i64]),
     ("cst_attn_bwd_workspace", c_i64, [ctypes.POINTER(AttnDesc)]),
     ("cst_attn_fwd", c_int, [ctypes.POINTER(AttnDesc), c_p]),
     ("cst_attn_bwd", c_int, [ctypes.POINTER(AttnDesc), c_p]),
@@ -217,4 +218,17 @@ def prof_query():
         ms, fl, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         n = lib.cst_prof_query(i, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by))
         out[name] = dict(launches=int(n), ms=ms.value, flops=fl.value, bytes=by.value)
+    return out
+
+
+def prof_dump(cls):
+    """Per-launch records of one kernel class of the profiling table: [(ms, flops, bytes, tag)] in launch order."""
+    lib = load()
+    n = lib.cst_prof_dump(cls, None, 0)
+    buf = ctypes.create_string_buffer(int(n) + 16)
+    lib.cst_prof_dump(cls, buf, len(buf))
+    out = []
+    for line in buf.value.decode().splitlines():
+        ms, fl, by, *tag = line.split(" ", 3)
+        out.append((float(ms), float(fl), float(by), tag[0] if tag else ""))
     return out

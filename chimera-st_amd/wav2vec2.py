@@ -193,7 +193,9 @@ class TransformerEncoder(nn.Module):
         them are then copies of a row nobody reads (forward bits of every frame that IS read, and every gradient, are unchanged:
         rows do not interact except through attention, whose keys are the real frames).  6 % fewer rows at the bench's lengths."""
         reach = self.conv_pos // 2
-        if not self.padding_rows_consumed and self.padding_rows_read is not None:
+        # (CST_NO_PACK_S2T=1 — the consumer's own layer stack runs padded and then computes, and returns, its padding frames from
+        #  ours: that debugging mode reproduces the reference on every frame, so it keeps the full reach)
+        if not self.padding_rows_consumed and self.padding_rows_read is not None and not os.environ.get("CST_NO_PACK_S2T"):
             reach = min(reach, int(self.padding_rows_read))
         return reach
 

@@ -60,6 +60,9 @@ typedef enum {
 void cst_prof_enable(int on);     /* clears the table when switching on */
 /* synchronises the recorded events; returns launches; outputs total ms / flops / bytes */
 int64_t cst_prof_query(int kernel_class, double* total_ms, double* flops, double* bytes);
+/* per-launch records of a class as text, one line per launch in launch order: "<ms> <flops> <bytes> <tag>" (tag = the launcher's
+ * description: kernel family and shape).  Returns the bytes needed including the terminating 0 (call with cap = 0 to size buf). */
+int64_t cst_prof_dump(int kernel_class, char* buf, int64_t cap);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm (eps, affine) — replaces torch.nn.LayerNorm at fairseq/modules/layer_norm.py:30-35
