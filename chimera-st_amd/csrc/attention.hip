@@ -165,7 +165,8 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_fwd_ke
   const uint32_t dkey2 = cst_drop_key2(p.drop_key);
   const int thr_s = (int)p.drop_thr - 32768;  // the mask halves are compared as signed 16-bit numbers (cst_common.h)
   const uint32_t rho = (uint32_t)((b * p.H + h) * p.Tq + q);
-  const uint32_t R1 = DROP ? cst_adrop_row1(p.drop_key, dkey2, rho) : 0u, R2 = DROP ? cst_adrop_row2(p.drop_key, dkey2, rho) : 0u;
+  cst_i32x4 bsig = {0, 0, 0, 0};  // this lane's query signature (cst_common.h: the mask comes out of an i8 MFMA per 32 x 32 block)
+  if (DROP) bsig = cst_asig_row_frag(p.drop_key, dkey2, rho, hi);
 
   Frag<T> fq[D / 16];
   load_row_frags<T, D>(fq, Qg, p.q_st, q, sv.tq, lane);
@@ -261,17 +262,12 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_fwd_ke
       l_run = l_run * alpha + (ls0 + ls1);
       m_run = m_new;
       if (DROP) {  // dropped probabilities leave the PV product; the row sum (normaliser) keeps them
-        const uint32_t base = (uint32_t)((j0 >> 1) + 2 * hi);  // key pair index of registers (0, 1) of this half-wave
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2; ++ks) {
+          const cst_i32x16 dm = cst_asig_block(cst_asig_key_frag(p.drop_key, dkey2, (uint32_t)((int)j0 + ks * 32 + (lane & 31)), hi), bsig);
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-              const uint32_t bits = cst_adrop_word(R1, R2, cst_adrop_col(p.drop_key, dkey2, base + ks * 16 + 4 * g + t));
-              s[ks][4 * g + 2 * t] = cst_adrop_keep(bits, 0, thr_s) ? s[ks][4 * g + 2 * t] : 0.0f;
-              s[ks][4 * g + 2 * t + 1] = cst_adrop_keep(bits, 1, thr_s) ? s[ks][4 * g + 2 * t + 1] : 0.0f;
-            }
+          for (int r = 0; r < 16; ++r) s[ks][r] = cst_adrop_keep(dm[r], thr_s) ? s[ks][r] : 0.0f;
+        }
       }
     }
 #pragma unroll
@@ -368,7 +364,8 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_bwd_dq
   const uint32_t dkey2 = cst_drop_key2(p.drop_key);
   const int thr_s = (int)p.drop_thr - 32768;  // the mask halves are compared as signed 16-bit numbers (cst_common.h)
   const uint32_t rho = (uint32_t)((b * p.H + h) * p.Tq + q);
-  const uint32_t R1 = DROP ? cst_adrop_row1(p.drop_key, dkey2, rho) : 0u, R2 = DROP ? cst_adrop_row2(p.drop_key, dkey2, rho) : 0u;
+  cst_i32x4 bsig = {0, 0, 0, 0};
+  if (DROP) bsig = cst_asig_row_frag(p.drop_key, dkey2, rho, hi);
 
   {
     int* sh_qend = reinterpret_cast<int*>(sMask + 2);
@@ -448,16 +445,10 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 3 : 2)) void attn_bwd_dq
         mma16(s, fk, fq[kk]);     // S^T[key][q]
         mma16(dp, fv, fdo[kk]);   // dP^T[key][q] = V dO^T
       }
-      if (DROP) {  // dP = (dO V^T) * keep / (1 - p): the same mask words as the forward pass
-        const uint32_t base = (uint32_t)((j0 >> 1) + 2 * hi) + ks * 16;
+      if (DROP) {  // dP = (dO V^T) * keep / (1 - p): the same mask as the forward pass
+        const cst_i32x16 dm = cst_asig_block(cst_asig_key_frag(p.drop_key, dkey2, (uint32_t)((int)j0 + ks * 32 + (lane & 31)), hi), bsig);
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            const uint32_t bits = cst_adrop_word(R1, R2, cst_adrop_col(p.drop_key, dkey2, base + 4 * g + t));
-            dp[4 * g + 2 * t] = cst_adrop_keep(bits, 0, thr_s) ? dp[4 * g + 2 * t] * p.drop_scale : 0.0f;
-            dp[4 * g + 2 * t + 1] = cst_adrop_keep(bits, 1, thr_s) ? dp[4 * g + 2 * t + 1] * p.drop_scale : 0.0f;
-          }
+        for (int r = 0; r < 16; ++r) dp[r] = cst_adrop_keep(dm[r], thr_s) ? dp[r] * p.drop_scale : 0.0f;
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -520,9 +511,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnParams p) 
   // key pair (key & ~1, key | 1) in that query's row); this lane's half of the word is `dsh`
   const uint32_t dkey2 = cst_drop_key2(p.drop_key);
   const int thr_s = (int)p.drop_thr - 32768;  // the mask halves are compared as signed 16-bit numbers (cst_common.h)
-  const uint32_t dsh = (uint32_t)(key & 1) * 16;
-  const uint32_t rho0 = (uint32_t)((b * p.H + h) * p.Tq) + (uint32_t)(4 * hi);
-  const uint32_t ccol = DROP ? cst_adrop_col(p.drop_key, dkey2, (uint32_t)(key >> 1)) : 0u;
+  const uint32_t rho0 = (uint32_t)((b * p.H + h) * p.Tq);
+  cst_i32x4 ksig = {0, 0, 0, 0};  // this lane's key signature
+  if (DROP) ksig = cst_asig_key_frag(p.drop_key, dkey2, (uint32_t)key, hi);
 
   if (p.kv_len && k_blk0 >= p.kv_len[b]) {  // every key of this block is padding: dK = dV = 0 (workgroup-uniform exit)
     if (key < krows) {
@@ -600,21 +591,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnParams p) 
       }
       f32x16 pr;
       const bool diag = p.causal && (k_blk0 + wave * QB + QB - 1 > (int)i0 + qs * 32 + cshift);  // wave-uniform: tile touches the future
-      // dropout: lanes (2i, 2i+1) own keys (k, k+1) = the two halves of ONE mask word per query.  Each lane hashes the words of
-      // half of the register pairs' queries (even lane: registers 2j, odd lane: 2j+1) and the neighbours swap them by DPP.
+      // dropout: rows of the mask block = the 32 queries of this step (their signatures are hashed here, one row per lane)
       uint32_t keepbits = 0;  // bit r: element r of this tile column is kept
       if (DROP) {
-        const uint32_t odd = (uint32_t)lane & 1u;
+        const cst_i32x16 dm = cst_asig_block(cst_asig_row_frag(p.drop_key, dkey2, rho0 + (uint32_t)((int)i0 + qs * 32 + (lane & 31)), hi), ksig);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int r0 = 2 * j;  // query rows of registers r0 and r0 + 1 differ by one
-          const uint32_t qrow = (uint32_t)((int)i0 + qs * 32 + (r0 & 3) + 8 * (r0 >> 2)) + odd;
-          const uint32_t mine = cst_adrop_word(cst_adrop_row1(p.drop_key, dkey2, rho0 + qrow), cst_adrop_row2(p.drop_key, dkey2, rho0 + qrow), ccol);
-          const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
-          const uint32_t w0 = odd ? other : mine, w1 = odd ? mine : other;
-          keepbits |= (cst_adrop_keep(w0 >> dsh, 0, thr_s) ? 1u : 0u) << r0;
-          keepbits |= (cst_adrop_keep(w1 >> dsh, 0, thr_s) ? 1u : 0u) << (r0 + 1);
-        }
+        for (int r = 0; r < 16; ++r) keepbits |= (cst_adrop_keep(dm[r], thr_s) ? 1u : 0u) << r;
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -760,7 +742,7 @@ extern "C" int cst_attn_fwd(const cst_attn_desc* d, cst_stream stream) {
   if (attn_fast_ok(d)) {
     CstProfScope prof(CST_K_ATTN_FWD, s, attn_flops(d, 2.0), 0.0);
     const unsigned nblk = fa_grid(d->Tq, d->B, d->H);
-    const size_t lds = FA_NSLOT * FA_SLOT + 136 * (size_t)cst_ceil_div(d->Tk, 64);
+    const size_t lds = FA_NSLOT * FA_SLOT + 8 * (size_t)cst_ceil_div(d->Tk, 64) + (p.drop_thr ? 4096 : 0);
     if (p.drop_thr) hipLaunchKernelGGL((fa_fwd_kernel<true>), dim3(nblk), dim3(256), lds, s, p);
     else hipLaunchKernelGGL((fa_fwd_kernel<false>), dim3(nblk), dim3(256), lds, s, p);
     return cst_check_launch("cst_attn_fwd");
@@ -793,7 +775,7 @@ extern "C" int cst_attn_bwd(const cst_attn_desc* d, cst_stream stream) {
     float* ws = (float*)d->bwd_ws;
     hipLaunchKernelGGL(fa_delta_kernel, dim3((unsigned)(Tq64 / 64), (unsigned)d->H, (unsigned)d->B), dim3(64), 0, s, p, ws, Tq64);
     const unsigned nq = fa_grid(d->Tq, d->B, d->H), nk = fa_grid(d->Tk, d->B, d->H);
-    const size_t lds_q = FA_NSLOT * FA_SLOT + 136 * (size_t)cst_ceil_div(d->Tk, 64), lds_k = FA_NSLOT * (FA_SLOT + FA_STATS);
+    const size_t lds_q = FA_NSLOT * FA_SLOT + 8 * (size_t)cst_ceil_div(d->Tk, 64) + (p.drop_thr ? 4096 : 0), lds_k = FA_NSLOT * (FA_SLOT + FA_STATS);
     if (p.drop_thr) {
       hipLaunchKernelGGL((fa_dq_kernel<true>), dim3(nq), dim3(256), lds_q, s, p, (const float*)ws, Tq64);
       hipLaunchKernelGGL((fa_dkv_kernel<true>), dim3(nk), dim3(256), lds_k, s, p, (const float*)ws, Tq64);

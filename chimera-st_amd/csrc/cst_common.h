@@ -148,29 +148,45 @@ __device__ __forceinline__ uint32_t cst_drop_bits24(uint32_t key, uint32_t key2,
   uint32_t w = __umul24(t, 0x85EBCBU) + key2;
   return w ^ (w >> 13);
 }
-// Attention-probability dropout of the DMA-staged attention kernels (attention_fast.inc): a SEPARABLE mask.  The 16 mask words a
-// 32 x 64 score tile needs per lane cost more VALU issue than the tile's 16 MFMAs when every word is a full hash of its index
-// (measured: 270 of 390 VALU instructions per tile), and the dK/dV kernel — where a lane owns a key and its registers run over
-// queries — needs a different word per element.  Here
-//   R1(rho), R2(rho)  two strong hashes of the probability ROW rho = (b*H + h)*Tq + q        (once per lane, or per staged query)
-//   C(kp)             a strong hash of the key PAIR index kp = k >> 1                           (a per-workgroup LDS table / once per lane)
-//   x = (R1 ^ C) & 0xffffff;  t = x * 0x9E3779;  t ^= t >> 15;  w = (t & 0xffffff) * 0x85EBCB + R2                      (mod 2^32)
-//   keep(rho, k) = int16(16-bit half (k & 1 ? high : low) of w)  >=  thr16 - 32768        (the halves are compared as SIGNED numbers: the
-//                  forward kernel builds the keep mask of a packed bf16 pair with v_pk_sub_i16 (saturating) + v_pk_ashrrev_i16 + v_and)
-// i.e. 5 full-rate operations per element PAIR in every layout, and the mask of (row, key) does not depend on tiling, so packed and
-// padded calls and all three kernels draw the same masks.  The xorshift between the two multiplies matters: with one multiply, key
-// pairs whose C values differ in a few high (or low) bits get masks that are shifted copies of each other (column correlation up to
-// 1.0 in the numpy twin); with it, max |correlation| over 1500 columns / 1500 rows is at the iid level (0.07 / 0.14 on 6000 x 1500).
-// Numpy twin: rng.keep_mask_attn_numpy.
-__device__ __forceinline__ uint32_t cst_adrop_row1(uint32_t key, uint32_t key2, uint32_t rho) { return cst_drop_bits32(key, key2, rho); }
-__device__ __forceinline__ uint32_t cst_adrop_row2(uint32_t key, uint32_t key2, uint32_t rho) { return cst_drop_bits32(key2 ^ 0xA511E9B3U, key, rho); }
-__device__ __forceinline__ uint32_t cst_adrop_col(uint32_t key, uint32_t key2, uint32_t kp) { return cst_drop_bits32(key ^ 0x68E31DA4U, key2, kp); }
-__device__ __forceinline__ uint32_t cst_adrop_word(uint32_t r1, uint32_t r2, uint32_t c) {
-  uint32_t t = __umul24(r1 ^ c, 0x9E3779U);
-  t ^= t >> 15;
-  return __umul24(t, 0x85EBCBU) + r2;
+// Attention-probability dropout: the mask is generated ON THE MATRIX CORES.  Hashing a mask word per score pair cost more VALU issue
+// than a 32 x 64 score tile's 16 MFMAs (270 of 390 VALU instructions per tile in round 2; a separable hash of round 3 still 4
+// operations per score, 9 in the dK/dV kernel where a lane owns a key), in kernels whose matrix pipe idles two thirds of the time.
+//   every probability ROW rho = (b*H + h)*Tq + q and every KEY k carry a 32-byte signature of pseudo-random int8:
+//     sigB(rho)[4w .. 4w+3] = bytes of  cst_drop_bits32(key, key2, 8 rho + w),   sigA(k)[4w .. 4w+3] = bytes of cst_drop_bits32(key ^ 0x68E31DA4, key2, 8 k + w)
+//   D(rho, k) = sum_i sigA(k)[i] * sigB(rho)[i]     (int32; ONE v_mfma_i32_32x32x32_i8 yields it for a whole 32 x 32 score block,
+//                                                     in the accumulator layout the scores themselves have)
+//   keep(rho, k)  <=>  int16((D << 2) & 0xffff) >= thr16 - 32768        (the low 14 bits of D: sigma(D) = 31 k, so D mod 2^14 is uniform
+//                                                     to 1e-30, while D mod 2^16 carries a 2.5 % ripple — measured in the numpy twin)
+// For a fixed key-signature table the decisions of two rows are independent (independent sigB), and those of two keys of one row are
+// a pair of dot products of one random vector with two fixed ones — the classic pairwise-independent family.  Numpy twin:
+// rng.keep_mask_attn_numpy (max |column correlation| 0.07, rows 0.14 on 6000 x 1500 = the iid level; drop rate 0.1000).
+// Cost per score: fast forward 2 packed operations (+ 2 MFMAs per 64-key tile), dQ 3, dK/dV 4; signatures are hashed once per lane
+// (the operand a lane owns) and once per tile and thread (the staged operand: 2 words each).
+__device__ __forceinline__ uint32_t cst_asig_row(uint32_t key, uint32_t key2, uint32_t rho, int w) { return cst_drop_bits32(key, key2, 8u * rho + (uint32_t)w); }
+__device__ __forceinline__ uint32_t cst_asig_key(uint32_t key, uint32_t key2, uint32_t k, int w) { return cst_drop_bits32(key ^ 0x68E31DA4U, key2, 8u * k + (uint32_t)w); }
+typedef int cst_i32x4 __attribute__((ext_vector_type(4)));
+typedef int cst_i32x16 __attribute__((ext_vector_type(16)));
+// the 16 signature bytes a lane supplies to the i8 MFMA: words 4 hi .. 4 hi + 3 (hi = lane >> 5 = the k half)
+__device__ __forceinline__ cst_i32x4 cst_asig_row_frag(uint32_t key, uint32_t key2, uint32_t rho, int hi) {
+  cst_i32x4 f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) f[w] = (int)cst_asig_row(key, key2, rho, 4 * hi + w);
+  return f;
 }
-__device__ __forceinline__ bool cst_adrop_keep(uint32_t w, int odd, int thr_s) { return (int)(short)(odd ? (w >> 16) : (w & 0xffffU)) >= thr_s; }
+__device__ __forceinline__ cst_i32x4 cst_asig_key_frag(uint32_t key, uint32_t key2, uint32_t k, int hi) {
+  cst_i32x4 f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) f[w] = (int)cst_asig_key(key, key2, k, 4 * hi + w);
+  return f;
+}
+// D of a 32 x 32 block: rows = the operand passed first
+__device__ __forceinline__ cst_i32x16 cst_asig_block(const cst_i32x4& rows, const cst_i32x4& cols) {
+  cst_i32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0;
+  return __builtin_amdgcn_mfma_i32_32x32x32_i8(rows, cols, z, 0, 0, 0);
+}
+__device__ __forceinline__ bool cst_adrop_keep(int D, int thr_s) { return (int)(short)((unsigned)D << 2) >= thr_s; }
 // multiply 8 consecutive elements starting at the (even) element index idx0 by their dropout factors
 __device__ __forceinline__ void cst_drop8(float (&v)[8], uint32_t key, uint64_t idx0, uint32_t thr16, float scale) {
 #pragma unroll

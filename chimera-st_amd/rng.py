@@ -72,27 +72,21 @@ def _bits32(key, key2, idx):
     return x ^ (x >> u(13))
 
 
+def _signatures(key, key2, n):
+    """[n, 32] int8 signatures: bytes (little endian) of the 8 words cst_drop_bits32(key, key2, 8 i + w)."""
+    idx = np.arange(n, dtype=np.uint64)[:, None] * np.uint64(8) + np.arange(8, dtype=np.uint64)[None, :]
+    return _bits32(key, key2, idx).astype(np.uint32).view(np.int8).reshape(n, 32)
+
+
 def keep_mask_attn_numpy(key, rows, Tk, p):
-    """Keep mask [rows, Tk] of an attention-probability dropout site (csrc/cst_common.h: cst_adrop_* — the SEPARABLE mask all
-    attention kernels evaluate): row rho = (b*H + h)*Tq + q of the probability tensor, key k.
-      R1, R2 = two hashes of rho;  C = a hash of the key pair k >> 1;  x = (R1 ^ C) & 0xffffff;  t = x * 0x9E3779;  t ^= t >> 15;
-      w = (t & 0xffffff) * 0x85EBCB + R2;  keep = int16(half (k & 1 ? high : low) of w) >= round(p * 65536) - 32768."""
-    u = np.uint64
+    """Keep mask [rows, Tk] of an attention-probability dropout site (csrc/cst_common.h, cst_asig_*: the mask every attention kernel
+    takes from an i8 MFMA): row rho = (b*H + h)*Tq + q of the probability tensor and key k carry 32-byte int8 signatures,
+      D = sigA(k) . sigB(rho)  (int32),   keep = int16((D << 2) & 0xffff) >= round(p * 65536) - 32768   (the low 14 bits of D)."""
     key = int(key) & _M32
     key2 = (key * 0x2C1B3C6D + 0x297A2D39) & _M32
-    rho = np.arange(rows, dtype=np.uint64)
-    r1 = _bits32(key, key2, rho)
-    r2 = _bits32(key2 ^ 0xA511E9B3, key, rho)
-    kp = np.arange((Tk + 1) // 2, dtype=np.uint64)
-    c = _bits32(key ^ 0x68E31DA4, key2, kp)
-    x = (r1[:, None] ^ c[None, :]) & u(0xFFFFFF)
-    t = (x * u(0x9E3779)) & u(_M32)
-    t ^= t >> u(15)
-    w = ((t & u(0xFFFFFF)) * u(0x85EBCB) + r2[:, None]) & u(_M32)
-    thr = int(p * 65536.0 + 0.5)
-    lo = (w & u(0xFFFF)) ^ u(0x8000)   # signed compare of the half == unsigned compare with the sign bit flipped
-    hi = (w >> u(16)) ^ u(0x8000)
-    keep = np.empty((rows, 2 * len(kp)), dtype=bool)
-    keep[:, 0::2] = lo >= u(thr)
-    keep[:, 1::2] = hi >= u(thr)
-    return keep[:, :Tk]
+    a = _signatures(key ^ 0x68E31DA4, key2, Tk).astype(np.int32)
+    b = _signatures(key, key2, rows).astype(np.int32)
+    d = b @ a.T
+    h = ((d.astype(np.int64) << 2) & 0xFFFF)
+    h = np.where(h >= 32768, h - 65536, h)
+    return h >= int(p * 65536.0 + 0.5) - 32768
