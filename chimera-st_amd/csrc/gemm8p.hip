@@ -737,6 +737,8 @@ int* sched_slot() {
   return r + 16 * (next[dev].fetch_add(1, std::memory_order_relaxed) % SLOTS);
 }
 
+std::atomic<int> g_reserved_cus{[] { const char* e = getenv("CST_GEMM_RESERVE_CUS"); return e ? atoi(e) : 0; }()};
+
 template <bool AK, bool BKM, int MODE>
 int launch8p(GemmParams p, int64_t nbatch, hipStream_t s) {
   static bool attr_set = false;
@@ -765,17 +767,27 @@ int launch8p(GemmParams p, int64_t nbatch, hipStream_t s) {
     if (const char* e = getenv("CST_GEMM8P_CUS")) n = atoi(e);  // experiments: persistent workgroups on a part of the chip only
     return n > 0 ? n : 256;
   }();
-  dim3 grid((unsigned)(total < ncu ? total : ncu), 1, 1);
+  // CUs left to a concurrent stream (the gradient all-reduce of a data-parallel backward: cst_gemm_reserve_cus / CST_GEMM_RESERVE_CUS):
+  // a persistent grid one workgroup per CU otherwise holds the whole chip for the length of a launch.  Multiples of 8 keep the
+  // per-XCD work claims on.
+  const int avail = ncu - g_reserved_cus.load(std::memory_order_relaxed) > 8 ? ncu - g_reserved_cus.load(std::memory_order_relaxed) : 8;
+  dim3 grid((unsigned)(total < avail ? total : avail), 1, 1);
   static const bool static_walk = getenv("CST_GEMM8P_STATIC") != nullptr;
   // (not under stream capture: a captured launch would pin one slot of the ring for every replay of the graph)
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   const bool capturing = hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
-  p.sched = (!static_walk && !capturing && total > ncu && grid.x % 8 == 0) ? sched_slot() : nullptr;
+  p.sched = (!static_walk && !capturing && total > avail && grid.x % 8 == 0) ? sched_slot() : nullptr;
   hipLaunchKernelGGL((gemm8p_kernel<AK, BKM, MODE>), grid, dim3(NTHREADS), LDS_BYTES + 1024 + 64, s, p);
   return cst_check_launch("cst_gemm (8-phase)");
 }
 
 }  // namespace
+
+extern "C" int cst_gemm_reserve_cus(int n) {
+  const int old = g_reserved_cus.load();
+  if (n >= 0) g_reserved_cus.store(n > 248 ? 248 : n);
+  return old;
+}
 
 // The per-lane DMA offsets are 32-bit byte offsets from the tile's first element and must stay below the descriptors' 2 GiB.
 bool cst_gemm8p_supported(const cstg::GemmParams& p, bool ak, bool bk, int64_t nbatch) {

@@ -80,6 +80,10 @@ class BucketedGradAllReduce:
             for idx in bk["members"]:
                 self.param_bucket[idx] = b
         self.enabled = True
+        # CUs the persistent GEMMs leave to the all-reduce kernels while buckets are in flight (first-8-GPU-run knob; 0 = off):
+        # --ddp-reserve-cus / CST_DDP_RESERVE_CUS.  Bucket size: --bucket-cap-mb / CST_BUCKET_CAP_MB.
+        self.reserve_cus = int(os.environ.get("CST_DDP_RESERVE_CUS", "0"))
+        self._reserved = False
         self.last_early, self.last_missing = 0, []
         self.late_params = []
         self._offsets = list(offsets)
@@ -146,7 +150,17 @@ class BucketedGradAllReduce:
             self.gather(bk["members"])
         g = self.flat_grad[bk["lo"]:bk["hi"]]
         g.div_(self.world)
+        if self.reserve_cus > 0 and not self._reserved:  # from the first bucket in flight until finish()
+            self._set_reserved(True)
         self._works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def _set_reserved(self, on):
+        try:
+            from . import lib as L
+            L.load().cst_gemm_reserve_cus(self.reserve_cus if on else 0)
+            self._reserved = on
+        except Exception:  # CPU-only hosts (the gloo tests): there is no persistent GEMM to shrink
+            self._reserved = False
 
     def _launch_ready(self):
         while self._next < len(self.buckets) and self._ready[self._next]:
@@ -183,6 +197,8 @@ class BucketedGradAllReduce:
             for w in self._works:
                 w.wait()
             self._works = []
+            if self._reserved:
+                self._set_reserved(False)
             self.late_params = sorted(self._late)
         self.reset()
 
@@ -195,8 +211,10 @@ class DistributedFairseqModel(torch.nn.Module):
         super().__init__()
         self.module = model
         self.reducer = BucketedGradAllReduce(buffers.params, buffers.offsets, buffers.flat_grad, process_group,
-                                             getattr(args, "bucket_cap_mb", 64) if args is not None else 64,
+                                             float(os.environ.get("CST_BUCKET_CAP_MB", 0)) or (getattr(args, "bucket_cap_mb", 64) if args is not None else 64),
                                              gather=getattr(buffers, "gather_grads", None))
+        if args is not None and getattr(args, "ddp_reserve_cus", None) is not None:
+            self.reducer.reserve_cus = int(args.ddp_reserve_cus)
 
     def __getattr__(self, name):
         try:

@@ -75,7 +75,6 @@ def parse_args_and_arch(argv, extra_defaults=None):
     """Two-pass argparse like fairseq/options.py:77-209: discover --arch/--task/--criterion, add their
     add_args, re-parse, then let the arch function fill defaults (ARCH_CONFIG_REGISTRY[arch](args))."""
     base = argparse.ArgumentParser(add_help=False, allow_abbrev=False)
-    base.add_argument("data", nargs="?", default=None)
     base.add_argument("--arch", "-a", required=True)
     base.add_argument("--task", default="speech_to_text")
     base.add_argument("--criterion", default="label_smoothed_cross_entropy")
@@ -86,8 +85,10 @@ def parse_args_and_arch(argv, extra_defaults=None):
     # getattr(args, name, default) sees only what the user actually passed
     model_group = parser.add_argument_group("Model-specific configuration", argument_default=argparse.SUPPRESS)
     ARCH_MODEL_REGISTRY[known.arch].add_args(model_group)
-    TASK_REGISTRY[known.task].add_args(parser)
+    TASK_REGISTRY[known.task].add_args(parser)  # (the positional `data` belongs to the task, tasks/speech_to_text.py:27)
     CRITERION_REGISTRY[known.criterion].add_args(parser)
+    if not any(a.dest == "data" for a in parser._actions):
+        parser.add_argument("data", nargs="?", default=None)
     if extra_defaults:
         parser.set_defaults(**extra_defaults)
     args = parser.parse_args(argv)
@@ -119,6 +120,10 @@ def add_common_args(parser):
     g.add_argument("--ddp-backend", default="no_c10d")
     g.add_argument("--distributed-world-size", type=int, default=1)
     g.add_argument("--bucket-cap-mb", type=int, default=25)
+    g.add_argument("--ddp-reserve-cus", type=int, default=None, help="CUs the persistent GEMMs leave to the gradient all-reduce while "
+                   "buckets are in flight under the backward pass (distributed.BucketedGradAllReduce.reserve_cus)")
+    g.add_argument("--nonfinite-tolerance", type=int, default=20, help="consecutive updates with NaN / Inf gradients that are skipped "
+                   "before FloatingPointError (the reference's DynamicLossScaler gives up after ~20 halvings)")
     g.add_argument("--num-workers", type=int, default=1)
     g.add_argument("--save-dir", default="checkpoints")
     g.add_argument("--tensorboard-logdir", default=None)

@@ -119,6 +119,7 @@ class SpeechToTextTask(FairseqTask):
 
     @staticmethod
     def add_args(parser):
+        parser.add_argument("data", nargs="?", default=None, help="manifest root path")  # tasks/speech_to_text.py:27 (optional here: synthetic data)
         parser.add_argument("--config-yaml", type=str, default="config.yaml")
         parser.add_argument("--normalize", action="store_true")
         parser.add_argument("--max-source-positions", default=6000, type=int, metavar="N")

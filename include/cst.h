@@ -157,6 +157,11 @@ typedef struct {
 } cst_gemm_desc;
 
 int64_t cst_gemm_workspace(const cst_gemm_desc* d);
+/* Persistent GEMM launches use (CUs - n) workgroups from now on (n < 0: query only); returns the previous value.  The data-parallel
+ * reducer sets it while bucket all-reduces are in flight under the backward pass, so that the RCCL kernels on the side stream find free
+ * CUs instead of waiting for a launch boundary (legacy_distributed_data_parallel.py has no overlap to protect).  Initial value:
+ * environment variable CST_GEMM_RESERVE_CUS (default 0). */
+int cst_gemm_reserve_cus(int n);
 int cst_gemm(const cst_gemm_desc* d, cst_stream stream);
 
 /* ------------------------------------------------------------------------------------------

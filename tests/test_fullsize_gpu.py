@@ -61,13 +61,13 @@ def test_full_size_update_properties():
 # ragged utterances (10 s and 6 s) so that every exact-skipping path of the HIP kernels is live (padded key tiles, dead query
 # tiles, dead token blocks of the weight-gradient GEMMs, the CNN frame bound), the SAME parameters on both sides.
 # ---------------------------------------------------------------------------------------------------------------------
-def _build_full(model, dtype):
+def _build_full(model, dtype, samples=(160000, 96000)):
     sys.path.insert(0, ROOT)
     import bench
     load_pkg()
-    args = Namespace(batch=2, seconds=10.0, lengths="uniform", dtype=dtype, model=model, dropout=0.0, layerdrop=0.0)
+    args = Namespace(batch=2, seconds=max(samples) / 16000.0, lengths="uniform", dtype=dtype, model=model, dropout=0.0, layerdrop=0.0)
     trainer, task, tasks, ns = bench.build(args, torch.device("cuda", 0))
-    sample = tasks.synthetic_sample(task.target_dictionary, 2, [160000, 96000], [37, 21], [20, 33], seed=3)
+    sample = tasks.synthetic_sample(task.target_dictionary, 2, list(samples), [37, 21], [20, 33], seed=3)
     return trainer, task, ns, sample, bench.oracle_cfg(ns)
 
 
@@ -91,16 +91,19 @@ def _hip_forward_backward(trainer, sample, chimera):
     return float(loss), log, logits.float().cpu(), (memory.float().cpu() if memory is not None else None), grads, stats
 
 
-@pytest.mark.parametrize("model", ["s2t_w2v2", "chimera"])
-def test_full_dimension_fp32_parity_with_oracle(model):
+@pytest.mark.parametrize("model,samples", [("s2t_w2v2", (160000, 96000)), ("chimera", (160000, 96000)), ("s2t_w2v2", (480000, 272000))],
+                         ids=["s2t_w2v2", "chimera", "s2t_w2v2-30s"])
+def test_full_dimension_fp32_parity_with_oracle(model, samples):
     """fp32 storage: loss <= 1e-4 relative, logits / memory / EVERY parameter gradient <= 1e-3 * max(1, |ref|max)
     (BASELINE north_star: 'logits/grads within 1e-3'), no exemptions.  The random parameters are first moved off the ReLU
-    kink (parity_util.detie: a pre-activation within rounding of 0 makes the gradient itself ill-defined)."""
+    kink (parity_util.detie: a pre-activation within rounding of 0 makes the gradient itself ill-defined).
+    The 30 s + 17 s case is the shape bench.py runs: T1 = 1499 wav2vec2 frames (24 key tiles per sequence, packed row offsets
+    beyond 2 k, the positional convolution and the subsampler at their full reach)."""
     from oracle import chimera_oracle as O
     from parity_util import assert_grads_close_fp32, cpu_sample, max_abs_rel, run_oracle
     from parity_util import detie
     chimera = model == "chimera"
-    trainer, task, ns, sample, cfg = _build_full(model, "f32")
+    trainer, task, ns, sample, cfg = _build_full(model, "f32", samples)
     fn = O.triplet_criterion if chimera else O.lsce_criterion
     sd, moved = detie(fn, {k: v.detach().cpu() for k, v in trainer.get_model().state_dict().items()}, cpu_sample(sample), cfg)
     trainer.get_model().load_state_dict(sd)  # the same tensors on both sides; no ReLU pre-activation within 1e-4 of the kink

@@ -988,3 +988,23 @@ def test_attention_packed_rows_equal_the_padded_call_bit_for_bit(K, dt, p):
         nb = int(offh[b + 1] - offh[b])
         sl = slice(int(offh[b]), int(offh[b + 1]))
         assert torch.equal(pdqkv[0, sl], dqkv2[b, :nb]), "gradient rows of sequence %d" % b
+
+
+def test_gemm_reserved_cus_is_a_pure_speed_switch(K):
+    """cst_gemm_reserve_cus (CUs the persistent GEMM leaves to a concurrent all-reduce): a smaller persistent grid walks the same work
+    items — identical bits — and the call returns the previous setting."""
+    k, L = K
+    lib = L.load()
+    M, N, Kd = 4096, 768, 1024
+    A, B = rnd(M, Kd, dt=torch.bfloat16, seed=1), rnd(N, Kd, dt=torch.bfloat16, seed=2)
+    bias = rnd(N, dt=torch.bfloat16, seed=3)
+    outs = []
+    assert lib.cst_gemm_reserve_cus(-1) == 0
+    for n in (0, 64, 200):
+        prev = lib.cst_gemm_reserve_cus(n)
+        C = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        k.gemm(A, B, C, M, N, Kd, a_kmajor=1, b_kmajor=1, lda=Kd, ldb=Kd, ldc=N, bias=bias, act=L.ACT_GELU)
+        outs.append(C)
+        assert lib.cst_gemm_reserve_cus(-1) == n and prev in (0, 64)
+    lib.cst_gemm_reserve_cus(0)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
