@@ -481,3 +481,130 @@ extern "C" int cst_rows_unpack(const void* src, const int32_t* seq_off, void* ds
   else hipLaunchKernelGGL(rows_unpack_kernel<float>, grid, dim3(256), 0, s, (const float*)src, seq_off, (float*)dst, (int)T, (int)C, tail_broadcast);
   return cst_check_launch("cst_rows_unpack");
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// weight normalisation along the last dimension (nn.utils.weight_norm(conv, dim=2) of the wav2vec2 positional convolution,
+// models/wav2vec/wav2vec2.py:773-779): v [R, C] (R = C_out * C_in / groups, C = kernel width: one norm per kernel tap), g [C]:
+//   w[r, c] = v[r, c] * g[c] / ||v[:, c]||          dv = (g / n) * (dw - v * dot / n^2),  dg = dot / n,  dot[c] = sum_r dw * v
+// Two launches each way, fixed summation order (bit-reproducible): row-chunk partial sums per column, then every block of the apply
+// pass adds the partials of its columns in chunk order and scales its rows.  Replaces ten ATen reduce / elementwise kernels per
+// update (0.46 ms in profiles/r02_kernel_stats.txt).
+// ---------------------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int WN_ROWS = 256;  // rows per partial chunk
+
+template <typename T, bool DOT>
+__global__ __launch_bounds__(256) void wn_partial_kernel(const T* v, const T* dw, float* part, int64_t R, int C) {
+  // thread -> (row lane, 8-column group); C % 8 == 0, C <= 256
+  const int gpr = C / 8, rl = threadIdx.x / gpr, cg = threadIdx.x % gpr, rpp = 256 / gpr;
+  __shared__ float red[256 * 8];
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int64_t r0 = (int64_t)blockIdx.x * WN_ROWS;
+  if (rl < rpp)
+    for (int64_t r = r0 + rl; r < r0 + WN_ROWS && r < R; r += rpp) {
+      float a[8], b[8];
+      load8(v + r * C + cg * 8, a);
+      if (DOT) load8(dw + r * C + cg * 8, b);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += DOT ? a[e] * b[e] : a[e] * a[e];
+    }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = acc[e];
+  __syncthreads();
+  if ((int)threadIdx.x < C) {  // column c: add the row lanes in order
+    const int c = threadIdx.x, g8 = c / 8, e = c % 8;
+    float s = 0.0f;
+    for (int l = 0; l < rpp; ++l) s += red[(l * gpr + g8) * 8 + e];
+    part[(int64_t)blockIdx.x * C + c] = s;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void wn_apply_fwd_kernel(const T* v, const T* g, T* w, float* norm, const float* part, int nchunks, int64_t R, int C) {
+  __shared__ float scale[256];
+  if ((int)threadIdx.x < C) {
+    float s = 0.0f;
+    for (int k = 0; k < nchunks; ++k) s += part[(int64_t)k * C + threadIdx.x];
+    const float n = sqrtf(s);
+    if (blockIdx.x == 0) norm[threadIdx.x] = n;
+    scale[threadIdx.x] = DT<T>::ld(g + threadIdx.x) / n;
+  }
+  __syncthreads();
+  const int gpr = C / 8;
+  const int64_t total = R * gpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(i % gpr);
+    float a[8];
+    load8(v + i * 8, a);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] *= scale[cg * 8 + e];
+    store8(w + i * 8, a);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void wn_apply_bwd_kernel(const T* v, const T* g, const T* dw, const float* norm, T* dv, T* dg, const float* part,
+                                                           int nchunks, int64_t R, int C) {
+  __shared__ float sc[256], co[256];
+  if ((int)threadIdx.x < C) {
+    float dot = 0.0f;
+    for (int k = 0; k < nchunks; ++k) dot += part[(int64_t)k * C + threadIdx.x];
+    const float n = norm[threadIdx.x], gg = DT<T>::ld(g + threadIdx.x);
+    sc[threadIdx.x] = gg / n;
+    co[threadIdx.x] = dot / (n * n);
+    if (blockIdx.x == 0) DT<T>::st(dg + threadIdx.x, dot / n);
+  }
+  __syncthreads();
+  const int gpr = C / 8;
+  const int64_t total = R * gpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(i % gpr);
+    float a[8], b[8];
+    load8(v + i * 8, a);
+    load8(dw + i * 8, b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = sc[cg * 8 + e] * (b[e] - a[e] * co[cg * 8 + e]);
+    store8(dv + i * 8, a);
+  }
+}
+}  // namespace
+
+extern "C" int64_t cst_weight_norm_workspace(int64_t R, int64_t C) { return cst_ceil_div(R, WN_ROWS) * C * (int64_t)sizeof(float); }
+
+extern "C" int cst_weight_norm_fwd(const void* v, const void* g, void* w, float* norm, void* workspace, int64_t R, int64_t C, int dtype,
+                                   cst_stream stream) {
+  CST_REQUIRE(v && g && w && norm && workspace && R > 0, "cst_weight_norm_fwd: null tensor");
+  CST_REQUIRE(C % 8 == 0 && C >= 8 && C <= 256 && 256 % (C / 8) == 0, "cst_weight_norm_fwd: C = %lld (need a multiple of 8 up to 256 whose eighth divides 256)", (long long)C);
+  hipStream_t s = (hipStream_t)stream;
+  CstProfScope prof(CST_K_ELEMENTWISE, s, 0.0, (double)R * C * cst_dtype_size(dtype) * 3);
+  const int nch = (int)cst_ceil_div(R, WN_ROWS);
+  const int blocks = (int)(cst_ceil_div(R * (C / 8), 256) < 1024 ? cst_ceil_div(R * (C / 8), 256) : 1024);
+  if (dtype == CST_BF16) {
+    hipLaunchKernelGGL((wn_partial_kernel<bf16_t, false>), dim3(nch), dim3(256), 0, s, (const bf16_t*)v, (const bf16_t*)nullptr, (float*)workspace, R, (int)C);
+    hipLaunchKernelGGL(wn_apply_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)v, (const bf16_t*)g, (bf16_t*)w, norm, (const float*)workspace, nch, R, (int)C);
+  } else {
+    hipLaunchKernelGGL((wn_partial_kernel<float, false>), dim3(nch), dim3(256), 0, s, (const float*)v, (const float*)nullptr, (float*)workspace, R, (int)C);
+    hipLaunchKernelGGL(wn_apply_fwd_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)v, (const float*)g, (float*)w, norm, (const float*)workspace, nch, R, (int)C);
+  }
+  return cst_check_launch("cst_weight_norm_fwd");
+}
+
+extern "C" int cst_weight_norm_bwd(const void* v, const void* g, const void* dw, const float* norm, void* dv, void* dg, void* workspace, int64_t R,
+                                   int64_t C, int dtype, cst_stream stream) {
+  CST_REQUIRE(v && g && dw && norm && dv && dg && workspace && R > 0, "cst_weight_norm_bwd: null tensor");
+  CST_REQUIRE(C % 8 == 0 && C >= 8 && C <= 256 && 256 % (C / 8) == 0, "cst_weight_norm_bwd: C = %lld", (long long)C);
+  hipStream_t s = (hipStream_t)stream;
+  CstProfScope prof(CST_K_ELEMENTWISE, s, 0.0, (double)R * C * cst_dtype_size(dtype) * 5);
+  const int nch = (int)cst_ceil_div(R, WN_ROWS);
+  const int blocks = (int)(cst_ceil_div(R * (C / 8), 256) < 1024 ? cst_ceil_div(R * (C / 8), 256) : 1024);
+  if (dtype == CST_BF16) {
+    hipLaunchKernelGGL((wn_partial_kernel<bf16_t, true>), dim3(nch), dim3(256), 0, s, (const bf16_t*)v, (const bf16_t*)dw, (float*)workspace, R, (int)C);
+    hipLaunchKernelGGL(wn_apply_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)v, (const bf16_t*)g, (const bf16_t*)dw, norm, (bf16_t*)dv, (bf16_t*)dg,
+                       (const float*)workspace, nch, R, (int)C);
+  } else {
+    hipLaunchKernelGGL((wn_partial_kernel<float, true>), dim3(nch), dim3(256), 0, s, (const float*)v, (const float*)dw, (float*)workspace, R, (int)C);
+    hipLaunchKernelGGL(wn_apply_bwd_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)v, (const float*)g, (const float*)dw, norm, (float*)dv, (float*)dg,
+                       (const float*)workspace, nch, R, (int)C);
+  }
+  return cst_check_launch("cst_weight_norm_bwd");
+}

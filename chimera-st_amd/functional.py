@@ -771,6 +771,28 @@ class _PosConvFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _WeightNormFn(torch.autograd.Function):
+    """nn.utils.weight_norm(conv, dim=2) (wav2vec2.py:773-779): w = v * g / ||v||, norms over all dims but the last."""
+
+    @staticmethod
+    def forward(ctx, v, g):
+        vc, gc = v.contiguous(), g.reshape(-1).contiguous()
+        w, norm = K.weight_norm_fwd(vc, gc)
+        ctx.save_for_backward(vc, gc, norm)
+        ctx.gshape = g.shape
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        vc, gc, norm = ctx.saved_tensors
+        dv, dg = K.weight_norm_bwd(vc, gc, dw.contiguous(), norm)
+        return dv, dg.view(ctx.gshape)
+
+
+def weight_norm_last_dim(v, g):
+    return _WeightNormFn.apply(v, g)
+
+
 def pos_conv_gelu_residual(x, weight, bias, groups):
     return _PosConvFn.apply(x, weight, bias, groups)
 

@@ -536,3 +536,27 @@ def adam_step(master, m, v, grad, param, lr, beta1, beta2, eps, wd, step, grad_s
     L.check(L.load().cst_adam_step(L.ptr(master), L.ptr(m), L.ptr(v), L.ptr(grad), L.ptr(param), master.numel(), lr, beta1, beta2,
                                    eps, wd, step, L.ptr(grad_scale), L.dtype_code(grad.dtype), L.dtype_code(param.dtype),
                                    L.stream_ptr()), "cst_adam_step")
+
+
+def weight_norm_fwd(v, g):
+    """v [..., C] contiguous, g [C] -> (w = v * g / ||v||_{all but last dim}, norm fp32 [C])."""
+    C = v.shape[-1]
+    R = v.numel() // C
+    lib = L.load()
+    w = torch.empty_like(v)
+    norm = torch.empty(C, dtype=torch.float32, device=v.device)
+    ws = torch.empty(int(lib.cst_weight_norm_workspace(R, C)) // 4, dtype=torch.float32, device=v.device)
+    L.check(lib.cst_weight_norm_fwd(v.data_ptr(), g.data_ptr(), w.data_ptr(), norm.data_ptr(), ws.data_ptr(), R, C, L.dtype_code(v.dtype),
+                                    L.stream_ptr()), "cst_weight_norm_fwd")
+    return w, norm
+
+
+def weight_norm_bwd(v, g, dw, norm):
+    C = v.shape[-1]
+    R = v.numel() // C
+    lib = L.load()
+    dv, dg = torch.empty_like(v), torch.empty_like(g)
+    ws = torch.empty(int(lib.cst_weight_norm_workspace(R, C)) // 4, dtype=torch.float32, device=v.device)
+    L.check(lib.cst_weight_norm_bwd(v.data_ptr(), g.data_ptr(), dw.data_ptr(), norm.data_ptr(), dv.data_ptr(), dg.data_ptr(), ws.data_ptr(), R, C,
+                                    L.dtype_code(v.dtype), L.stream_ptr()), "cst_weight_norm_bwd")
+    return dv, dg

@@ -164,6 +164,8 @@ class TransformerEncoder(nn.Module):
     def pos_conv_weight(self):
         pc = getattr(self.pos_conv, "0")
         v = pc.weight_v
+        if v.is_cuda and v.shape[-1] % 8 == 0 and v.shape[-1] <= 256 and 256 % (v.shape[-1] // 8) == 0:
+            return CF.weight_norm_last_dim(v, pc.weight_g)  # cst_weight_norm_fwd/bwd
         norm = v.float().pow(2).sum(dim=(0, 1), keepdim=True).sqrt()
         return (v.float() * (pc.weight_g.float() / norm)).to(v.dtype)
 

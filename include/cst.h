@@ -302,6 +302,14 @@ int cst_colsum_typed_live(const void* x, int64_t ldx, void* out, void* workspace
  * act'(z[b,l,c]) (GELU of the previous conv layer).  dcol [B, Lout, k*C]; dx/z [B, Lin, C]. */
 int cst_col2im1d(const void* dcol, const void* z, void* dx, int64_t B, int64_t Lin, int64_t Lout,
                  int64_t C, int k, int stride, int pad, int dact, int dtype, cst_stream stream);
+/* Weight normalisation along the LAST dimension — nn.utils.weight_norm(conv, dim=2) of the wav2vec2 positional convolution
+ * (models/wav2vec/wav2vec2.py:773-779): v, w, dw, dv [R, C] contiguous (R = C_out * C_in / groups, C = kernel width), g, dg [C],
+ * norm fp32 [C] (saved by the forward call).  w = v * g / ||v[:, c]||;  dv = (g/n) (dw - v dot / n^2), dg = dot / n, dot = sum_r dw v.
+ * Fixed summation order.  C % 8 == 0, C <= 256, (C / 8) divides 256.  workspace: cst_weight_norm_workspace(R, C) bytes. */
+int64_t cst_weight_norm_workspace(int64_t R, int64_t C);
+int cst_weight_norm_fwd(const void* v, const void* g, void* w, float* norm, void* workspace, int64_t R, int64_t C, int dtype, cst_stream stream);
+int cst_weight_norm_bwd(const void* v, const void* g, const void* dw, const float* norm, void* dv, void* dg, void* workspace, int64_t R,
+                        int64_t C, int dtype, cst_stream stream);
 /* y[r,:] = mask[r] ? 0 : x[r,:]   (x[padding_mask] = 0, wav2vec2.py:820-821) */
 int cst_mask_rows(const void* x, const uint8_t* mask, void* y, int64_t rows, int64_t cols, int dtype, cst_stream stream);
 

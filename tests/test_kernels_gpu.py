@@ -1008,3 +1008,28 @@ def test_gemm_reserved_cus_is_a_pure_speed_switch(K):
         assert lib.cst_gemm_reserve_cus(-1) == n and prev in (0, 64)
     lib.cst_gemm_reserve_cus(0)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("shape", [(768, 48, 128), (64, 16, 16), (33, 7, 8)])
+def test_weight_norm_last_dim(K, dt, shape):
+    """cst_weight_norm_fwd/bwd against nn.utils.weight_norm(conv, dim=2) semantics (wav2vec2.py:773-779): w = v g / ||v||, one norm per
+    kernel tap; forward and both gradients, and the same bits on a second call (fixed summation order)."""
+    k, L = K
+    from importlib import import_module
+    CF = import_module("chimera-st_amd.functional")
+    v = rnd(*shape, dt=dt, seed=1).requires_grad_(True)
+    g = (1.0 + 0.1 * rnd(1, 1, shape[-1], dt=torch.float32, seed=2)).to(dt).requires_grad_(True)
+    dw = rnd(*shape, dt=dt, seed=3)
+    w = CF.weight_norm_last_dim(v, g)
+    w.backward(dw)
+    vr, gr = v.detach().float().requires_grad_(True), g.detach().float().requires_grad_(True)
+    wr = vr * (gr / vr.pow(2).sum(dim=(0, 1), keepdim=True).sqrt())
+    wr.backward(dw.float())
+    check(w, wr, dt, "weight_norm fwd")
+    check(v.grad, vr.grad, dt, "weight_norm dv", scale=float(vr.grad.abs().max()))
+    check(g.grad, gr.grad, dt, "weight_norm dg", scale=float(gr.grad.abs().max()))
+    v2, g2 = v.detach().clone().requires_grad_(True), g.detach().clone().requires_grad_(True)
+    w2 = CF.weight_norm_last_dim(v2, g2)
+    w2.backward(dw)
+    assert torch.equal(w, w2) and torch.equal(v.grad, v2.grad) and torch.equal(g.grad, g2.grad)
