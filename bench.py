@@ -110,7 +110,7 @@ def dominant_gemm_launch(args, device):
     out = {"kernel": "gemm8p_kernel<k-major, k-major>", "shape": [M, F, D], "epilogue": "bias+gelu+aux_out", "avg_launch_ms": ms,
            "achieved": flops / ms / 1e9, "unit": "TFLOP/s", "frac": flops / ms / 1e9 / PEAK["bf16"],
            "algorithmic_bytes": 2.0 * (M * D + F * D + 2 * M * F), "traffic": None}
-    pmc = next((f for f in (os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", n) for n in ("r02_pmc_gemm.json", "r01_pmc_gemm.json"))
+    pmc = next((f for f in (os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", n) for n in ("r03_pmc_gemm.json", "r02_pmc_gemm.json", "r01_pmc_gemm.json"))
                 if os.path.exists(f)), None)
     if pmc is not None:
         rec = json.load(open(pmc))
