@@ -608,3 +608,47 @@ extern "C" int cst_weight_norm_bwd(const void* v, const void* g, const void* dw,
   }
   return cst_check_launch("cst_weight_norm_bwd");
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// dst[c, r] = src[r, c]: a [R, C] matrix transposed through a 64 x 64 LDS tile (16-byte global accesses both ways).  Used for the
+// weight operand of the Linear dX GEMMs: with W^T [K_in, N_out] the GEMM dY W reads BOTH operands k-major (ds_read_b128 fragments),
+// as the forward GEMM does; with W [N_out, K_in] its B operand goes through transpose reads, which measured 15-20 % slower on the
+// 31 760-row shapes (tools/gemm_shapes_in_step.py).  R % 8 == 0, C % 8 == 0.
+// ---------------------------------------------------------------------------------------------------------------------------------
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void transpose2d_kernel(const T* src, T* dst, int64_t R, int64_t C) {
+  constexpr int V = DT<T>::VEC, TS = 64, LDT = TS + V;   // padded rows: column reads walk different banks
+  __shared__ __attribute__((aligned(16))) T tile[TS * LDT];
+  const int64_t r0 = (int64_t)blockIdx.y * TS, c0 = (int64_t)blockIdx.x * TS;
+  constexpr int VPR = TS / V;
+  for (int v = threadIdx.x; v < TS * VPR; v += 256) {
+    const int r = v / VPR, cv = (v % VPR) * V;
+    u32x4 x = {0, 0, 0, 0};
+    if (r0 + r < R && c0 + cv < C) x = *reinterpret_cast<const u32x4*>(src + (r0 + r) * C + c0 + cv);
+    *reinterpret_cast<u32x4*>(tile + r * LDT + cv) = x;
+  }
+  __syncthreads();
+  for (int v = threadIdx.x; v < TS * VPR; v += 256) {
+    const int c = v / VPR, rv = (v % VPR) * V;   // output row c (a source column), V consecutive source rows
+    if (c0 + c < C && r0 + rv < R) {
+      T out[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) out[e] = tile[(rv + e) * LDT + c];
+      *reinterpret_cast<u32x4*>(dst + (c0 + c) * R + r0 + rv) = *reinterpret_cast<const u32x4*>(out);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int cst_transpose2d(const void* src, void* dst, int64_t R, int64_t C, int dtype, cst_stream stream) {
+  CST_REQUIRE(src && dst && R > 0 && C > 0, "cst_transpose2d: null tensor");
+  const int v = dtype == CST_BF16 ? 8 : 4;
+  CST_REQUIRE(R % v == 0 && C % v == 0, "cst_transpose2d: R and C must be multiples of %d", v);
+  hipStream_t s = (hipStream_t)stream;
+  CstProfScope prof(CST_K_ELEMENTWISE, s, 0.0, 2.0 * (double)R * C * cst_dtype_size(dtype));
+  dim3 grid((unsigned)cst_ceil_div(C, 64), (unsigned)cst_ceil_div(R, 64));
+  if (dtype == CST_BF16) hipLaunchKernelGGL(transpose2d_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, R, C);
+  else hipLaunchKernelGGL(transpose2d_kernel<float>, grid, dim3(256), 0, s, (const float*)src, (float*)dst, R, C);
+  return cst_check_launch("cst_transpose2d");
+}

@@ -560,3 +560,11 @@ def weight_norm_bwd(v, g, dw, norm):
     L.check(lib.cst_weight_norm_bwd(v.data_ptr(), g.data_ptr(), dw.data_ptr(), norm.data_ptr(), dv.data_ptr(), dg.data_ptr(), ws.data_ptr(), R, C,
                                     L.dtype_code(v.dtype), L.stream_ptr()), "cst_weight_norm_bwd")
     return dv, dg
+
+
+def transpose2d(x):
+    """[R, C] contiguous -> [C, R] contiguous (cst_transpose2d)."""
+    R, C = x.shape
+    out = torch.empty(C, R, dtype=x.dtype, device=x.device)
+    L.check(L.load().cst_transpose2d(x.data_ptr(), out.data_ptr(), R, C, L.dtype_code(x.dtype), L.stream_ptr()), "cst_transpose2d")
+    return out

@@ -102,6 +102,7 @@ SYMBOLS = [
     ("cst_gemm", c_int, [ctypes.POINTER(GemmDesc), c_p]),
     ("cst_prof_dump", c_i64, [c_int, ctypes.c_char_p, c_i64]),
     ("cst_gemm_reserve_cus", c_int, [c_int]),
+    ("cst_transpose2d", c_int, [c_p, c_p, c_i64, c_i64, c_int, c_p]),
     ("cst_weight_norm_workspace", c_i64, [c_i64, c_i64]),
     ("cst_weight_norm_fwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_int, c_p]),
     ("cst_weight_norm_bwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_int, c_p]),

@@ -310,6 +310,9 @@ int64_t cst_weight_norm_workspace(int64_t R, int64_t C);
 int cst_weight_norm_fwd(const void* v, const void* g, void* w, float* norm, void* workspace, int64_t R, int64_t C, int dtype, cst_stream stream);
 int cst_weight_norm_bwd(const void* v, const void* g, const void* dw, const float* norm, void* dv, void* dg, void* workspace, int64_t R,
                         int64_t C, int dtype, cst_stream stream);
+/* dst [C, R] = src [R, C] transposed (contiguous both; R, C multiples of the 16-byte vector).  The Linear dX GEMMs take the weight this
+ * way (dY W with W^T k-major: both operands read as the forward GEMM reads them). */
+int cst_transpose2d(const void* src, void* dst, int64_t R, int64_t C, int dtype, cst_stream stream);
 /* y[r,:] = mask[r] ? 0 : x[r,:]   (x[padding_mask] = 0, wav2vec2.py:820-821) */
 int cst_mask_rows(const void* x, const uint8_t* mask, void* y, int64_t rows, int64_t cols, int dtype, cst_stream stream);
 
