@@ -14,6 +14,7 @@
 // Backward needs ONE pass over dy: per (b,c) it accumulates s1 = sum dz, s2 = sum dz*uhat and
 // r[j] = sum_t dz x[s t + j]; dW/dgamma/dbeta then follow in closed form from (s1, s2, r, m, G).
 #include "cst_common.h"
+#include "gemm_common.h"  // GEMM_MAX_BM: the tile height the layer-1 conv GEMM reads layer-0 frames in
 
 namespace {
 
@@ -549,8 +550,9 @@ __global__ void conv_row_limits_kernel(const int32_t* nz_last, ConvSpec8 sp, int
       if (i >= 1 && r < sp.s[i]) {
         const int d = nz[i - 1] - r;
         v = d > 0 ? (d + sp.s[i] - 1) / sp.s[i] : 0;
-      } else if (i == 0 && r == 0 && L >= 2) {  // rows of layer 0 under layer 1's live 256-row tiles
-        const int64_t need = (int64_t)((nz[1] + 255) / 256) * 256 * sp.s[1] + sp.k[1];
+      } else if (i == 0 && r == 0 && L >= 2) {  // rows of layer 0 under layer 1's live GEMM tiles (tiles start at multiples of BM per batch)
+        constexpr int BM = cstg::GEMM_MAX_BM;
+        const int64_t need = (int64_t)((nz[1] + BM - 1) / BM) * BM * sp.s[1] + sp.k[1];
         v = need < sp.len[0] ? (int)need : sp.len[0];
       } else if (i == 0 && r == 0) {
         v = sp.len[0];

@@ -27,6 +27,7 @@ template <int BM_, int BN_, int WM_, int WN_, int KV_ = 8>
 struct Cfg {
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NT = 64 * WM_ * WN_, TM = BM_ / WM_ / 32, TN = BN_ / WN_ / 32;
   static constexpr int KV = KV_;  // 16-byte vectors per k-major tile row: BK = KV * VEC (64 or 32 bf16)
+  static_assert(BM_ <= GEMM_MAX_BM && GEMM_MAX_BM % BM_ == 0, "conv0.hip (cst_conv_row_limits) sizes live frames from GEMM_MAX_BM");
 };
 using CfgSmall = Cfg<128, 128, 2, 2>;   // 4 waves, 2 blocks/CU: small / skinny problems, grouped conv
 // 16 waves (wave tile 64 x 64), 1 block/CU, 4 waves/SIMD: half the L2->LDS bytes per FLOP of CfgSmall.  Measured

@@ -46,6 +46,7 @@ using namespace cstg;
 using T = bf16_t;
 
 constexpr int BM = 256, BN = 256, BK = 64, NTHREADS = 512;
+static_assert(BM <= cstg::GEMM_MAX_BM && cstg::GEMM_MAX_BM % BM == 0, "conv0.hip (cst_conv_row_limits) sizes live frames from GEMM_MAX_BM");
 constexpr int QB = 17408;           // one half-tile image (k-major images use the first 16 KiB)
 constexpr int GSTRIDE = 1088;       // byte distance of the DMA groups of an mn-major image (64 B pad)
 constexpr int KSTRIDE = 1024;       // k-major images are dense

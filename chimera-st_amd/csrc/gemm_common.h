@@ -4,6 +4,11 @@
 
 namespace cstg {
 
+// The tallest output tile any GEMM kernel of this library uses, and the granularity tiles start at inside one batch of a batched
+// launch.  conv0.hip sizes the frames it writes for the layer-1 conv GEMM from this (cst_conv_row_limits): every row a live tile of
+// that GEMM reads must have been written.  Each kernel static_asserts its BM against it.
+constexpr int GEMM_MAX_BM = 256;
+
 struct GemmParams {
   int64_t M, N, K;
   const void* A; int64_t lda, a_seg, a_seg_stride;

@@ -24,6 +24,7 @@ import torch
 
 from . import kernels as K
 from . import lib as L
+from .optim import PARAM_EPOCH
 
 
 class BeamDecodeEngine:
@@ -61,10 +62,16 @@ class BeamDecodeEngine:
         except AttributeError:
             return False
 
+    def invalidate(self):
+        """Drop the packed / folded weight copies and the captured graphs (call after changing decoder weights by any other route)."""
+        self._packed = None
+        self._state.clear()
+
     def _pack(self, dtype, device):
         """Per-layer packed [3C, C] self-attention projection (weights are constants in eval mode)."""
         # weights may have been updated since the last call (training between validations): re-pack and drop the graphs
-        key = (dtype, device, tuple((p.data_ptr(), p._version) for p in self.dec.parameters()))
+        # (autograd versions catch load_state_dict / copy_; optim.PARAM_EPOCH catches the fused optimizer's raw-pointer updates)
+        key = (dtype, device, PARAM_EPOCH[0], tuple((p.data_ptr(), p._version) for p in self.dec.parameters()))
         if self._packed is not None and self._packed[0] == key:
             return self._packed[1]
         self._state.clear()

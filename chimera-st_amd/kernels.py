@@ -203,23 +203,29 @@ def attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, layout_q="bt", layout_k
     return d
 
 
-_KPM_BITS = []  # [(uint8 mask (kept alive), version, int64 words)]: one padding mask serves every layer of a pass
+_KPM_BITS = []  # [(data_ptr, shape, version, uint8 mask (kept alive), int64 words)]: one padding mask serves every layer of a pass
+_BIT_WEIGHTS = {}  # device -> int64 [64]: 1 << k (built on the device: a host list would be a pageable copy, i.e. a stream sync)
 
 
 def kpm_bits(kpm):
     """uint8 [B, Tk] key padding mask -> int64 [B, ceil(Tk/64)]: bit k of word j = key 64 j + k is masked (bits of keys >= Tk set).
-    cst_attn_desc.kpm_bits: the DMA-staged attention kernels read one mask word per key tile from scalar registers."""
-    for src, ver, bits in _KPM_BITS:
-        if src is kpm and ver == kpm._version:
+    cst_attn_desc.kpm_bits: the DMA-staged attention kernels read one mask word per key tile from scalar registers.
+    Nothing here touches the host: the backward pass asks again with the tensor autograd saved (another Python object over the same
+    storage), so the cache goes by storage address + shape + version."""
+    key = (kpm.data_ptr(), tuple(kpm.shape), kpm._version)
+    for ptr, shape, ver, _, bits in _KPM_BITS:
+        if (ptr, shape, ver) == key:
             return bits
     B, Tk = kpm.shape
     nw = (Tk + 63) // 64
     m = kpm != 0
     if nw * 64 != Tk:
         m = torch.cat([m, torch.ones(B, nw * 64 - Tk, dtype=torch.bool, device=kpm.device)], 1)
-    w = torch.tensor([1 << i if i < 63 else -(1 << 63) for i in range(64)], dtype=torch.int64, device=kpm.device)
+    w = _BIT_WEIGHTS.get(kpm.device)
+    if w is None:
+        w = _BIT_WEIGHTS[kpm.device] = torch.ones(64, dtype=torch.int64, device=kpm.device) << torch.arange(64, dtype=torch.int64, device=kpm.device)
     bits = (m.view(B, nw, 64).to(torch.int64) * w).sum(-1).contiguous()  # distinct powers of two: the wrapping sum is the OR
-    _KPM_BITS.append((kpm, kpm._version, bits))
+    _KPM_BITS.append(key + (kpm, bits))
     if len(_KPM_BITS) > 8:
         _KPM_BITS.pop(0)
     return bits

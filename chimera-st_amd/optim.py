@@ -15,6 +15,10 @@ from . import kernels as K
 
 ALIGN = 8  # elements: keeps every parameter view 16-byte aligned (bf16) for the GEMM loaders
 
+# Bumped by every in-place parameter update that bypasses autograd's version counters (cst_adam_step writes through raw pointers).
+# Anything that caches tensors DERIVED from parameters (decode_engine.BeamDecodeEngine._pack) keys its cache on it.
+PARAM_EPOCH = [0]
+
 
 class FlatParamBuffers:
     """Re-home a model's parameters (and their .grad) as views of two flat tensors."""
@@ -165,6 +169,7 @@ class FusedAdam:
             else:
                 self._scale.fill_(multiply)
         self.num_updates += 1
+        PARAM_EPOCH[0] += 1
         K.adam_step(self.master, self.exp_avg, self.exp_avg_sq, self.buf.flat_grad, self.buf.flat_param, self.lr,
                     self.betas[0], self.betas[1], self.eps, self.weight_decay, self.num_updates, self._scale)
         self.lr = inverse_sqrt_lr(self.num_updates, self.base_lr, self.warmup_updates, self.warmup_init_lr)

@@ -121,9 +121,13 @@ def assert_grads_close_fp32(got, ref, relu_min_abs, tol=1e-3, tie=1e-4, max_tie_
     """Every gradient within tol * max(1, |ref|max) — except the rows of a ReLU fc1 weight / bias whose neuron is a TIE: its
     pre-activation came within `tie` of zero for some token (oracle.RELU_TAPS), where ReLU' is discontinuous and two correct fp32
     evaluations may pick different sides.  Such rows are exempt from the max-abs bound (at most `max_tie_rows` of a tensor's
-    rows, and the tensor must still agree to 1e-2 in relative L2); any other entry beyond the bound fails.
+    rows, and the tensor must still agree to 1e-2 in relative L2); any other entry beyond the bound fails.  The LayerNorm that feeds
+    a block's fc1 receives that neuron's flipped d(pre-activation) through W1^T on the tied token: in a block WITH a tie its two
+    vectors are held to 3 x tol and 1e-2 relative L2 instead (callers that need the strict bound everywhere move the parameters
+    off the kink first, parity_util.detie, and assert that nothing was excused).
     Returns (number of tensors compared, worst error outside ties, number of tie rows excused)."""
     n, worst, excused = 0, ("", 0.0), 0
+    tied_blocks = {t.rsplit(".", 1)[0] for t, v in relu_min_abs.items() if bool((v < tie).any())}
     for name, r in ref.items():
         g = got.get(name)
         if g is None and r is None:
@@ -144,6 +148,12 @@ def assert_grads_close_fp32(got, ref, relu_min_abs, tol=1e-3, tie=1e-4, max_tie_
             excused += int(bad_rows.sum())
             err = err[~bad_rows]
         e = float(err.max()) if err.numel() else 0.0
+        if e > tol and tag.endswith(".final_layer_norm") and tag.rsplit(".", 1)[0] in tied_blocks:
+            rel = float((g - r).norm() / r.norm())
+            assert e <= 3 * tol and rel <= 1e-2, "grad %s (feeds a tied fc1): %.3e, relative L2 %.3e" % (name, e, rel)
+            excused += 1
+            n += 1
+            continue
         worst = max(worst, (name, e), key=lambda t: t[1])
         assert e <= tol, "grad %s: %.3e" % (name, e)
         n += 1

@@ -1033,3 +1033,37 @@ def test_weight_norm_last_dim(K, dt, shape):
     w2 = CF.weight_norm_last_dim(v2, g2)
     w2.backward(dw)
     assert torch.equal(w, w2) and torch.equal(v.grad, v2.grad) and torch.equal(g.grad, g2.grad)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("shape", [(3072, 768), (768, 2304), (64, 64), (72, 136), (8, 264), (336, 8)])
+def test_transpose2d_is_exact(K, dt, shape):
+    """cst_transpose2d (the W^T copy the dX GEMMs read k-major): pure data movement, bit-exact incl. partial 64 x 64 tiles; sides that
+    are no multiple of 8 are refused (functional._want_wt never asks for them)."""
+    k, L = K
+    x = torch.randn(*shape, device="cuda").to(dt)
+    assert torch.equal(k.transpose2d(x), x.t().contiguous())
+    with pytest.raises(RuntimeError, match="multiples of"):
+        k.transpose2d(torch.zeros(65, 128, device="cuda", dtype=dt))
+
+
+def test_dx_through_transposed_weight_equals_m_major_read():
+    """functional._linear_backward reads W^T k-major above CST_WT_MIN_ROWS rows; the GEMM accumulates the same products in the same
+    K order either way, so dX has the same bits as the m-major read it replaces."""
+    import os
+    from importlib import import_module
+    CF = import_module("chimera-st_amd.functional")
+    torch.manual_seed(5)
+    x = torch.randn(4608, 768, device="cuda").bfloat16().requires_grad_(True)
+    w = (torch.randn(1536, 768, device="cuda") / 28).bfloat16().requires_grad_(True)
+    dy = torch.randn(4608, 1536, device="cuda").bfloat16()
+    grads = []
+    for no_wt in ("", "1"):
+        os.environ["CST_NO_WT"] = no_wt
+        try:
+            y = CF.linear(x, w, None)
+            gx, gw = torch.autograd.grad(y, (x, w), dy)
+        finally:
+            os.environ.pop("CST_NO_WT", None)
+        grads.append((gx, gw))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
