@@ -381,9 +381,10 @@ def decode_line(args, device):
             "unit": "utterances/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_s * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "s2t_transformer_l (12 enc + 6 dec, d1024/ffn4096/16h, V=10000), filter-bank input, beam search with "
-                                   "incremental state (device-resident loop, one HIP graph per decode step)", "batch": args.batch, "beam": beam,
+                                   "incremental state (device-resident loop, one HIP graph per decode step and lane; lanes = groups of sentences decoded side by side on their own streams)", "batch": args.batch, "beam": beam,
                        "max_frames": frames, "max_len": max_len, "tokens_per_s": ntok / dt_s, "encoder_ms": enc_s * 1e3,
-                       "ms_per_decode_step": ms_step, "hypothesis_rows_per_step": args.batch * beam},
+                       "ms_per_decode_step": ms_step, "hypothesis_rows_per_step": args.batch * beam,
+                       "lanes": eng.lanes if eng is not None else 0},
             "roofline": {"bound": "hbm", "kernel": "one decode step (%d graph nodes: LayerNorm-folded / skinny GEMMs, cache attention, beam step)" % nodes,
                          "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
                          "algorithmic_bytes": step_bytes, "avg_launch_ms": ms_step,

@@ -743,10 +743,18 @@ int choose_splits(const cst_gemm_desc* d) {
   }
   const int64_t tiles = cst_ceil_div(d->M, 128) * cst_ceil_div(d->N, 128) * nb;
   if (tiles >= 256 || ktiles < 16) return 1;
-  int64_t s = cst_ceil_div(512, tiles);
-  if (s > ktiles / 8) s = ktiles / 8;
-  if (s > 32) s = 32;
-  return s < 1 ? 1 : (int)s;
+  // 128 x 128 tiles, two workgroups fit a CU: a split count is priced as (K share of one workgroup) x (workgroups on the busiest
+  // CU) — one round of <= 256 workgroups at 1/s1, or <= 512 (two per CU, each at half rate) at 2/s2.  The second only when it is
+  // clearly cheaper: it doubles the partial sums the reduce kernel reads.  (Measured, tools/bench_gemm_splitk.py: 1536 x 512 x 7901
+  // s=4 37.8 us against 56.4 us for the former 512-workgroup target (s=11); 512 x 512 x 12000 s=12 26.1 against 33.7 (s=23).)
+  const int64_t cap = ktiles / 8 < 32 ? ktiles / 8 : 32;
+  int64_t s1 = 256 / tiles, s2 = 512 / tiles;
+  if (s1 > cap) s1 = cap;
+  if (s2 > cap) s2 = cap;
+  if (s1 < 1) s1 = 1;
+  if (s2 < 1) s2 = 1;
+  const int64_t s = (2.0 / (double)s2 < 0.9 / (double)s1) ? s2 : s1;
+  return (int)s;
 }
 
 }  // namespace

@@ -29,7 +29,7 @@ from .optim import PARAM_EPOCH
 
 class BeamDecodeEngine:
     def __init__(self, decoder, tgt_dict, beam_size, max_len, min_len=1, normalize_scores=True, len_penalty=1.0,
-                 unk_penalty=0.0, temperature=1.0, use_graph=True, poll=8, cross_kernel="flash"):
+                 unk_penalty=0.0, temperature=1.0, use_graph=True, poll=8, cross_kernel="flash", lanes=None):
         self.dec = decoder
         self.pad, self.unk, self.eos = tgt_dict.pad(), tgt_dict.unk(), tgt_dict.eos()
         self.vocab = len(tgt_dict)
@@ -44,8 +44,15 @@ class BeamDecodeEngine:
         # flash kernel spends on them; kept selectable, covered by the same tests)
         assert cross_kernel in ("flash", "flash_hm", "shared")
         self.cross_kernel = cross_kernel
+        # lanes: the batch may be cut into groups of sentences, each with its own state, step graph and HIP stream, replayed side by
+        # side (sentences never interact in beam search: same hypotheses, tests/test_decode_engine_gpu.py).  Measured on MI355X
+        # (32 x beam 5, s2t_transformer_l): 1 lane 0.877 ms per step, 2 lanes 0.910, 3 lanes 1.60, 4 lanes 1.63 — the step graphs of
+        # different streams do not overlap on this stack (a half-batch step costs 0.455 ms, two of them 0.91), so the default is 1.
+        self.lanes = max(1, int(os.environ.get("CST_DEC_LANES", "1") if lanes is None else lanes))
         self._packed = None
         self._state = {}
+        self._cfg = None
+        self._streams = []
 
     # ------------------------------------------------------------------------------------------------------------
     @staticmethod
@@ -126,12 +133,11 @@ class BeamDecodeEngine:
                 "cst_dec_ln_linear")
 
     # ------------------------------------------------------------------------------------------------------------
-    def _alloc(self, bsz, S, dtype, device, has_mask):
-        key = (bsz, S, dtype, device, has_mask)
+    def _alloc(self, lane, bsz, S, dtype, device, has_mask):
+        key = (lane, bsz, S, dtype, device, has_mask)
         st = self._state.get(key)
         if st is not None:
             return st
-        self._state.clear()  # one resident configuration (caches are the large buffers)
         beam, L1, LT = self.beam, self.max_len + 1, self.max_len + 2
         bbsz, C, nl = bsz * beam, self.dec.embed_dim, len(self.dec.layers)
         F = self.dec.layers[0].fc1.out_features
@@ -270,9 +276,57 @@ class BeamDecodeEngine:
         mask = encoder_out.encoder_padding_mask
         has_mask = mask is not None and mask.dim() == 2
         pk = self._pack(dtype, device)
-        st = self._alloc(bsz, S, dtype, device, has_mask)
+        lanes = min(self.lanes, bsz)
+        bounds = [(bsz * i // lanes, bsz * (i + 1) // lanes) for i in range(lanes)]
+        cfg = (tuple(b1 - b0 for b0, b1 in bounds), S, dtype, device, has_mask)
+        if cfg != self._cfg:
+            self._state.clear()  # one resident configuration (the caches are the large buffers)
+            self._cfg = cfg
+        main = torch.cuda.current_stream()
+        while lanes > 1 and len(self._streams) < lanes:
+            self._streams.append(torch.cuda.Stream(device=device))
         encb = enc.transpose(0, 1)
         encb = encb if encb.is_contiguous() else encb.contiguous()
+        total = self.max_len + 1
+        runs = []
+        for i, (b0, b1) in enumerate(bounds):
+            stream = main if lanes == 1 else self._streams[i]
+            if stream is not main:
+                stream.wait_stream(main)
+            with torch.cuda.stream(stream):
+                st = self._alloc(i, b1 - b0, S, dtype, device, has_mask)
+                done = self._begin(st, pk, encb[b0:b1], mask[b0:b1] if has_mask else None, b1 - b0)
+            runs.append(dict(stream=stream, st=st, bsz=b1 - b0, steps=done, remaining=b1 - b0))
+        while any(r["steps"] < total and r["remaining"] > 0 for r in runs):
+            for r in runs:
+                r["n"] = min(self.poll, total - r["steps"]) if r["remaining"] > 0 else 0
+            for j in range(self.poll):  # the lanes' steps alternate in launch order; each lane's own order is its stream's
+                for r in runs:
+                    if j < r["n"]:
+                        with torch.cuda.stream(r["stream"]):
+                            if self.use_graph:
+                                r["st"]["graph"].replay()
+                            else:
+                                self._step(r["st"], pk, r["bsz"])
+            for r in runs:
+                if r["n"]:
+                    r["steps"] += r["n"]
+                    with torch.cuda.stream(r["stream"]):
+                        r["remaining"] = int(r["st"]["num_remaining"].item())  # the only host sync of the loop (one per lane)
+        assert all(r["remaining"] == 0 for r in runs), "beam search did not terminate within max_len + 1 steps"
+        finalized = []
+        for r in runs:
+            with torch.cuda.stream(r["stream"]):
+                finalized += self._collect(r["st"], r["bsz"], None if r["stream"] is main else main)
+            if r["stream"] is not main:
+                main.wait_stream(r["stream"])
+        return finalized
+
+    def _begin(self, st, pk, encb, mask, bsz):
+        """Queues the per-call work of one lane on the current stream: the static cross-attention K/V of its sentences, the beam
+        state, and — first call of a configuration — the eager step 0 and the capture of the step graph.  Returns the number of
+        decode steps already taken (1 after that eager step, else 0)."""
+        S, Ce = encb.shape[1], encb.shape[2]
         flat = encb.reshape(bsz * S, Ce)
         for li, layer in enumerate(self.dec.layers):  # static cross-attention K/V, once per sentence (not per beam)
             ca = layer.encoder_attn
@@ -284,35 +338,25 @@ class BeamDecodeEngine:
             else:
                 self._linear(flat, ca.k_proj.weight, ca.k_proj.bias, st["kx"][li].view(bsz * S, -1))
                 self._linear(flat, ca.v_proj.weight, ca.v_proj.bias, st["vx"][li].view(bsz * S, -1))
-        if has_mask:
+        if mask is not None:
             st["kpm"].copy_(mask.to(torch.uint8))
-        lib = L.load()
-        L.check(lib.cst_beam_init(ctypes.byref(st["desc"]), L.stream_ptr()), "cst_beam_init")
-
-        steps_done = 0
+        L.check(L.load().cst_beam_init(ctypes.byref(st["desc"]), L.stream_ptr()), "cst_beam_init")
         if self.use_graph and st["graph"] is None:
             self._step(st, pk, bsz)  # eager warm-up step 0 (loads code objects, sizes the GEMM workspace)
-            steps_done = 1
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._step(st, pk, bsz)
             st["graph"] = g
-        total = self.max_len + 1
-        remaining = bsz
-        while steps_done < total and remaining > 0:
-            n = min(self.poll, total - steps_done)
-            for _ in range(n):
-                if self.use_graph:
-                    st["graph"].replay()
-                else:
-                    self._step(st, pk, bsz)
-            steps_done += n
-            remaining = int(st["num_remaining"].item())  # the only host sync of the loop
-        assert remaining == 0, "beam search did not terminate within max_len + 1 steps"
+            return 1
+        return 0
 
+    def _collect(self, st, bsz, consumer=None):
         # hypotheses are views of ONE device-side copy of the result buffers (the engine state is reused by the next call)
         d_tokens, d_pos, d_score = st["fin_tokens"].clone(), st["fin_pos"].clone(), st["fin_score"].clone()
+        if consumer is not None:  # made on a lane's stream, read by the caller on its own
+            for t in (d_tokens, d_pos, d_score):
+                t.record_stream(consumer)
         fin_score, fin_len, nfinal = d_score.cpu(), st["fin_len"].cpu(), st["nfinal"].cpu()
         finalized = []
         for b in range(bsz):

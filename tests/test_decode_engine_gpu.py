@@ -383,3 +383,31 @@ def test_engine_repacks_after_a_fused_optimizer_step():
             assert after_kept[b][r]["tokens"].tolist() == after_fresh[b][r]["tokens"].tolist()
             assert float(after_kept[b][r]["score"]) == float(after_fresh[b][r]["score"])
     del before
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_engine_lanes_give_the_hypotheses_of_the_undivided_batch(monkeypatch, dtype):
+    """The engine cuts the batch into groups of sentences that decode side by side on their own streams (CST_DEC_LANES).  Sentences
+    never interact in beam search and every kernel's per-row arithmetic is independent of the number of rows, so 1, 2 and 3 lanes
+    return the same token ids and bit-identical scores — also on the second call (graph replay on re-initialised state) and
+    when the groups finish at different steps (ragged source lengths)."""
+    model, task = _build_s2t(dtype, d=512, heads=8, layers=2, V=2000, tied=False)
+    SG = import_module("chimera-st_amd.sequence_generator").SequenceGenerator
+    g = torch.Generator().manual_seed(7)
+    B = 7
+    src = torch.randn(B, 150, 80, generator=g).cuda().to(dtype)
+    lens = torch.tensor([150, 150, 131, 90, 77, 41, 30]).cuda()
+    sample = {"net_input": {"src_tokens": src, "src_lengths": lens}}
+    out = {}
+    for lanes in (1, 2, 3):
+        monkeypatch.setenv("CST_DEC_LANES", str(lanes))
+        gen = SG([model], task.target_dictionary, beam_size=4, max_len_a=0, max_len_b=30)
+        for rep in range(2):
+            h = gen.generate([model], sample)
+            assert gen._engine is not None and gen._engine.lanes == lanes and len(gen._engine._state) == lanes
+            out[(lanes, rep)] = [[(x["tokens"].tolist(), float(x["score"]), x["positional_scores"].tolist()) for x in hb] for hb in h]
+    ref = out[(1, 0)]
+    assert len(ref) == B and all(len(hb) == 4 for hb in ref)
+    assert len({tuple(hb[0][0]) for hb in ref}) > 1, "degenerate test: every sentence decodes to the same tokens"
+    for k, v in out.items():
+        assert v == ref, k
