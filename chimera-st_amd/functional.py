@@ -754,14 +754,16 @@ class _PosConvFn(torch.autograd.Function):
         cg = C // groups
         padl = k // 2
         Tp = T + k - 1 + (1 if k % 2 == 0 else 0)  # even k: torch pads k//2 both sides, SamePad drops the last output
-        xg = torch.zeros(B, groups, Tp, cg, dtype=x.dtype, device=x.device)
-        xg[:, :, padl:padl + T] = x.view(B, T, groups, cg).permute(0, 2, 1, 3)
+        # [G, B, Tp, C/G]: group-major OUTSIDE the batch, so that one group's frames of all utterances are one [B * Tp, C/G] matrix
+        # (the weight-gradient GEMM below runs over it with K = every frame of the batch)
+        xg = torch.zeros(groups, B, Tp, cg, dtype=x.dtype, device=x.device)
+        xg[:, :, padl:padl + T] = x.view(B, T, groups, cg).permute(2, 0, 1, 3)
         wg = weight.view(groups, cg, cg, k).permute(0, 1, 3, 2).contiguous()  # [g][co][j][ci]
         y = torch.empty(B, T, C, dtype=x.dtype, device=x.device)
         z = torch.empty_like(y)
         xc = x if x.is_contiguous() else x.contiguous()
         K.gemm(xg, wg, y, T, cg, k * cg, a_kmajor=1, b_kmajor=1, lda=cg, ldb=k * cg, ldc=C, batch0=B, batch1=groups,
-               sa=(groups * Tp * cg, Tp * cg), sb=(0, cg * k * cg), sc=(T * C, cg), bias=bias, sbias=(0, cg), act=L.ACT_GELU,
+               sa=(Tp * cg, B * Tp * cg), sb=(0, cg * k * cg), sc=(T * C, cg), bias=bias, sbias=(0, cg), act=L.ACT_GELU,
                aux_out=z, ld_aux_out=C, resid=xc, ld_resid=C, split_k=1)
         ctx.save_for_backward(xg, weight, z)
         ctx.cfg = (B, T, C, k, groups, cg, padl, Tp)
@@ -774,22 +776,29 @@ class _PosConvFn(torch.autograd.Function):
         dy = dy.contiguous()
         dz = K.act_bwd(dy, z, L.ACT_GELU)
         dx = dw = db = None
+        # dzg[g, b, lp + t] = dz[b, t, group g], zero rows around it, in the frame stride Tp of xg: the operand of BOTH gradient GEMMs
+        lp = k - 1 - padl
+        dzg = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dzg = torch.zeros(groups, B, Tp, cg, dtype=dy.dtype, device=dy.device)
+            dzg[:, :, lp:lp + T] = dz.view(B, T, groups, cg).permute(2, 0, 1, 3)
         if ctx.needs_input_grad[0]:
             # dx[m] = dy[m] + sum_j dz[m + padl - j] w_j  = dy[m] + sum_j' dzp[m + j'] wflip[j'],  dzp[(k-1-padl) + t] = dz[t]
-            lp = k - 1 - padl
-            Tz = T + k - 1
-            dzg = torch.zeros(B, groups, Tz, cg, dtype=dy.dtype, device=dy.device)
-            dzg[:, :, lp:lp + T] = dz.view(B, T, groups, cg).permute(0, 2, 1, 3)
             wflip = weight.view(groups, cg, cg, k).flip(3).permute(0, 2, 3, 1).contiguous()  # [g][ci][j'][co]
             dx = torch.empty(B, T, C, dtype=dy.dtype, device=dy.device)
             K.gemm(dzg, wflip, dx, T, cg, k * cg, a_kmajor=1, b_kmajor=1, lda=cg, ldb=k * cg, ldc=C, batch0=B, batch1=groups,
-                   sa=(groups * Tz * cg, Tz * cg), sb=(0, cg * k * cg), sc=(T * C, cg), resid=dy, ld_resid=C, split_k=1)
+                   sa=(Tp * cg, B * Tp * cg), sb=(0, cg * k * cg), sc=(T * C, cg), resid=dy, ld_resid=C, split_k=1)
         if ctx.needs_input_grad[1]:
-            # dw[g][co][(j,ci)] = sum_t dz[t, g, co] xg[g, t + j, ci]   (B operand: overlapping mn-major rows, ldb = cg)
-            part = torch.empty(B, groups, cg, k * cg, dtype=torch.float32, device=dy.device)
-            K.gemm(dz, xg, part, cg, k * cg, T, a_kmajor=0, b_kmajor=0, lda=C, ldb=cg, ldc=k * cg, batch0=B, batch1=groups,
-                   sa=(T * C, cg), sb=(groups * Tp * cg, Tp * cg), sc=(groups * cg * k * cg, cg * k * cg), split_k=1)
-            dw = part.sum(0).view(groups, cg, k, cg).permute(0, 1, 3, 2).reshape(C, cg, k).to(weight.dtype)
+            # dw[g][co][(j,ci)] = sum_{b,t} dz[b, t, g, co] xg[g, b, t + j, ci]: ONE reduction over the frames of the whole batch per
+            # group.  Row kappa = b Tp + t of A is dzg's row kappa + lp (zero for t >= T: the windows that would run from one
+            # utterance into the next contribute nothing); row kappa of B is the k-frame window of xg starting at frame kappa
+            # (overlapping mn-major rows, ldb = cg).  (Before: one [cg, k cg] product per (utterance, group) — 600 MB of fp32
+            # partial sums written and read back by a sum over the batch.)
+            Kr = B * Tp - (k - 1)
+            dwg = torch.empty(groups, cg, k * cg, dtype=torch.float32, device=dy.device)
+            K.gemm(dzg, xg, dwg, cg, k * cg, Kr, a_kmajor=0, b_kmajor=0, lda=cg, ldb=cg, ldc=k * cg, batch0=1, batch1=groups,
+                   sa=(0, B * Tp * cg), sb=(0, B * Tp * cg), sc=(0, cg * k * cg), a_off=lp * cg, split_k=1)
+            dw = dwg.view(groups, cg, k, cg).permute(0, 1, 3, 2).reshape(C, cg, k).to(weight.dtype)
         if ctx.needs_input_grad[2]:
             db = K.colsum(dz.view(B * T, C), weight.dtype)
         return dx, dw, db, None
