@@ -617,10 +617,8 @@ extern "C" int cst_weight_norm_bwd(const void* v, const void* g, const void* dw,
 // ---------------------------------------------------------------------------------------------------------------------------------
 namespace {
 template <typename T>
-__global__ __launch_bounds__(256) void transpose2d_kernel(const T* src, T* dst, int64_t R, int64_t C) {
+__device__ __forceinline__ void transpose_tile(const T* src, T* dst, int64_t R, int64_t C, int64_t r0, int64_t c0, T* tile) {
   constexpr int V = DT<T>::VEC, TS = 64, LDT = TS + V;   // padded rows: column reads walk different banks
-  __shared__ __attribute__((aligned(16))) T tile[TS * LDT];
-  const int64_t r0 = (int64_t)blockIdx.y * TS, c0 = (int64_t)blockIdx.x * TS;
   constexpr int VPR = TS / V;
   for (int v = threadIdx.x; v < TS * VPR; v += 256) {
     const int r = v / VPR, cv = (v % VPR) * V;
@@ -639,7 +637,38 @@ __global__ __launch_bounds__(256) void transpose2d_kernel(const T* src, T* dst, 
     }
   }
 }
+
+template <typename T>
+__global__ __launch_bounds__(256) void transpose2d_kernel(const T* src, T* dst, int64_t R, int64_t C) {
+  __shared__ __attribute__((aligned(16))) T tile[64 * (64 + DT<T>::VEC)];
+  transpose_tile<T>(src, dst, R, C, (int64_t)blockIdx.y * 64, (int64_t)blockIdx.x * 64, tile);
+}
+
+// every matrix of a table in ONE launch: block -> (matrix, tile) by a binary search over the matrices' first-tile numbers
+template <typename T>
+__global__ __launch_bounds__(256) void transpose2d_multi_kernel(const cst_transpose_item* items, int n) {
+  __shared__ __attribute__((aligned(16))) T tile[64 * (64 + DT<T>::VEC)];
+  const int64_t b = blockIdx.x;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {  // last item whose first tile is <= b (uniform: scalar loads)
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].tile0 <= b) lo = mid; else hi = mid - 1;
+  }
+  const cst_transpose_item it = items[lo];
+  const int64_t t = b - it.tile0, tx = (it.C + 63) / 64;
+  transpose_tile<T>((const T*)it.src, (T*)it.dst, it.R, it.C, (t / tx) * 64, (t % tx) * 64, tile);
+}
 }  // namespace
+
+extern "C" int cst_transpose2d_multi(const cst_transpose_item* items_dev, int n, int64_t total_tiles, int dtype, cst_stream stream) {
+  CST_REQUIRE(items_dev && n > 0 && total_tiles > 0 && total_tiles < (1ll << 31), "cst_transpose2d_multi: bad table");
+  CST_REQUIRE(dtype == CST_F32 || dtype == CST_BF16, "cst_transpose2d_multi: bad dtype");
+  hipStream_t s = (hipStream_t)stream;
+  CstProfScope prof(CST_K_ELEMENTWISE, s, 0.0, 2.0 * (double)total_tiles * 4096 * cst_dtype_size(dtype));
+  if (dtype == CST_BF16) hipLaunchKernelGGL(transpose2d_multi_kernel<bf16_t>, dim3((unsigned)total_tiles), dim3(256), 0, s, items_dev, n);
+  else hipLaunchKernelGGL(transpose2d_multi_kernel<float>, dim3((unsigned)total_tiles), dim3(256), 0, s, items_dev, n);
+  return cst_check_launch("cst_transpose2d_multi");
+}
 
 extern "C" int cst_transpose2d(const void* src, void* dst, int64_t R, int64_t C, int dtype, cst_stream stream) {
   CST_REQUIRE(src && dst && R > 0 && C > 0, "cst_transpose2d: null tensor");

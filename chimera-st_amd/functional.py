@@ -57,6 +57,53 @@ def _want_wt(M, w):
             and w.shape[1] % _vec(w.dtype) == 0 and not _os.environ.get("CST_NO_WT"))
 
 
+class _WeightTransposes:
+    """W^T copies of the Linear weights the dX GEMMs read (see _linear_backward), kept across updates.  A weight changes only in the
+    optimizer step (optim.PARAM_EPOCH counts the fused kernel's raw-pointer updates) or through an in-place torch op (its autograd
+    version): the first request after an optimizer step refreshes EVERY registered copy in one launch (cst_transpose2d_multi —
+    one launch per update instead of one small launch per Linear per backward pass: 0.75 -> 0.15 ms per update on the bench
+    configuration, ~110 launches fewer); a weight changed any other way is re-transposed on its own when it is asked for."""
+
+    MAX_ENTRIES = 1024
+
+    def __init__(self):
+        self.entries = {}   # (data_ptr, shape, dtype) -> [w (kept alive: its address cannot be reused), wt, version, epoch]
+        self.tables = {}    # (device, dtype) -> transpose table over the entries of that kind
+        self.refreshes = 0  # whole-table launches (tests)
+
+    def get(self, w):
+        from .optim import PARAM_EPOCH
+        epoch = PARAM_EPOCH[0]
+        key = (w.data_ptr(), tuple(w.shape), w.dtype)
+        e = self.entries.get(key)
+        if e is None:
+            if len(self.entries) >= self.MAX_ENTRIES:  # models built and dropped again (test suites): start over
+                self.entries.clear()
+                self.tables.clear()
+            e = self.entries[key] = [w.detach(), K.transpose2d(w), w._version, epoch]
+            self.tables.pop((w.device, w.dtype), None)
+            return e[1]
+        if e[2] != w._version:  # written by a torch op since (load_state_dict, manual edits)
+            K.transpose2d(w, e[1])
+            e[2], e[3] = w._version, epoch
+            return e[1]
+        if e[3] != epoch:  # an optimizer step since: refresh every stale copy of this kind at once
+            kind = (w.device, w.dtype)
+            stale = [v for k, v in self.entries.items() if v[0].device == w.device and k[2] == w.dtype and v[3] != epoch]
+            ids = [id(v) for v in stale]
+            t = self.tables.get(kind)
+            if t is None or t[5] != ids:  # (the table is rebuilt only when the set of weights changed: first updates of a run)
+                t = self.tables[kind] = K.transpose_table([(v[0], v[1]) for v in stale]) + (ids,)
+            K.transpose2d_multi(t)
+            self.refreshes += 1
+            for v in stale:
+                v[2], v[3] = v[0]._version, epoch
+        return e[1]
+
+
+WEIGHT_TRANSPOSES = _WeightTransposes()
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, resid, act, drop_p, drop_key):
@@ -124,7 +171,7 @@ def _linear_backward(ctx, dy, dxp):
             # large token counts: dY W with W^T [K_in, N_out] as a k-major B operand — both operands are then read the way the
             # forward GEMM reads them (the transpose reads of an mn-major W measured 15-20 % slower on the 31 760-row shapes); the
             # transposed copy of a <= 5 MB weight costs a few microseconds
-            K.gemm(dz, K.transpose2d(w), dx, M, Kd, Np, a_kmajor=1, b_kmajor=1, lda=Np, ldb=Np, ldc=Kd, split_k=1,
+            K.gemm(dz, WEIGHT_TRANSPOSES.get(w), dx, M, Kd, Np, a_kmajor=1, b_kmajor=1, lda=Np, ldb=Np, ldc=Kd, split_k=1,
                    resid=_flat2d(dxp) if dxp is not None else None, ld_resid=Kd, m_live=live)
         else:
             K.gemm(dz, w, dx, M, Kd, Np, a_kmajor=1, b_kmajor=0, lda=Np, ldb=Kd, ldc=Kd, split_k=1,
@@ -215,7 +262,7 @@ class _FFNFn(torch.autograd.Function):
         dz1 = torch.empty(M, F_, dtype=dy2.dtype, device=dy2.device)
         wt = _want_wt(M, w2) and _want_wt(M, w1)  # dX GEMMs with the weights as k-major B operands (see _linear_backward)
         if wt:
-            K.gemm(dy2, K.transpose2d(w2), dz1, M, F_, dout, a_kmajor=1, b_kmajor=1, lda=dout, ldb=dout, ldc=F_, dact=act, aux_in=z1, ld_aux_in=F_,
+            K.gemm(dy2, WEIGHT_TRANSPOSES.get(w2), dz1, M, F_, dout, a_kmajor=1, b_kmajor=1, lda=dout, ldb=dout, ldc=F_, dact=act, aux_in=z1, ld_aux_in=F_,
                    split_k=1, drop_p=p_act, drop_key=key_act, m_live=live)
         else:
             K.gemm(dy2, w2, dz1, M, F_, dout, a_kmajor=1, b_kmajor=0, lda=dout, ldb=F_, ldc=F_, dact=act, aux_in=z1, ld_aux_in=F_, split_k=1,
@@ -229,7 +276,7 @@ class _FFNFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, d, dtype=x2.dtype, device=x2.device)
             if wt:
-                K.gemm(dz1, K.transpose2d(w1), dx, M, d, F_, a_kmajor=1, b_kmajor=1, lda=F_, ldb=F_, ldc=d, split_k=1,
+                K.gemm(dz1, WEIGHT_TRANSPOSES.get(w1), dx, M, d, F_, a_kmajor=1, b_kmajor=1, lda=F_, ldb=F_, ldc=d, split_k=1,
                        resid=_flat2d(dy) if ctx.res_is_x else None, ld_resid=d, m_live=live)
             else:
                 K.gemm(dz1, w1, dx, M, d, F_, a_kmajor=1, b_kmajor=0, lda=F_, ldb=d, ldc=d, split_k=1,

@@ -568,9 +568,30 @@ def weight_norm_bwd(v, g, dw, norm):
     return dv, dg
 
 
-def transpose2d(x):
+def transpose2d(x, out=None):
     """[R, C] contiguous -> [C, R] contiguous (cst_transpose2d)."""
     R, C = x.shape
-    out = torch.empty(C, R, dtype=x.dtype, device=x.device)
+    if out is None:
+        out = torch.empty(C, R, dtype=x.dtype, device=x.device)
+    assert out.shape == (C, R) and out.is_contiguous() and out.dtype == x.dtype
     L.check(L.load().cst_transpose2d(x.data_ptr(), out.data_ptr(), R, C, L.dtype_code(x.dtype), L.stream_ptr()), "cst_transpose2d")
     return out
+
+
+def transpose_table(pairs):
+    """[(src [R, C], dst [C, R]), ...] of one dtype / device -> (device table, n, total tiles, dtype code) for transpose2d_multi.
+    The table reaches the device through pinned memory (a pageable copy would drain the stream)."""
+    rows, tile0 = [], 0
+    for src, dst in pairs:
+        R, C = src.shape
+        assert src.is_contiguous() and dst.is_contiguous() and dst.shape == (C, R) and dst.dtype == src.dtype
+        rows.append([src.data_ptr(), dst.data_ptr(), R, C, tile0])
+        tile0 += ((R + 63) // 64) * ((C + 63) // 64)
+    host = torch.tensor(rows, dtype=torch.int64).pin_memory()
+    return host.to(pairs[0][0].device, non_blocking=True), len(rows), tile0, L.dtype_code(pairs[0][0].dtype), host
+
+
+def transpose2d_multi(table):
+    """Every matrix of a transpose_table in one launch (cst_transpose2d_multi)."""
+    dev, n, total, dt = table[:4]
+    L.check(L.load().cst_transpose2d_multi(dev.data_ptr(), n, total, dt, L.stream_ptr()), "cst_transpose2d_multi")

@@ -103,6 +103,7 @@ SYMBOLS = [
     ("cst_prof_dump", c_i64, [c_int, ctypes.c_char_p, c_i64]),
     ("cst_gemm_reserve_cus", c_int, [c_int]),
     ("cst_transpose2d", c_int, [c_p, c_p, c_i64, c_i64, c_int, c_p]),
+    ("cst_transpose2d_multi", c_int, [c_p, c_int, c_i64, c_int, c_p]),
     ("cst_weight_norm_workspace", c_i64, [c_i64, c_i64]),
     ("cst_weight_norm_fwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_int, c_p]),
     ("cst_weight_norm_bwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_int, c_p]),

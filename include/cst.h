@@ -313,6 +313,15 @@ int cst_weight_norm_bwd(const void* v, const void* g, const void* dw, const floa
 /* dst [C, R] = src [R, C] transposed (contiguous both; R, C multiples of the 16-byte vector).  The Linear dX GEMMs take the weight this
  * way (dY W with W^T k-major: both operands read as the forward GEMM reads them). */
 int cst_transpose2d(const void* src, void* dst, int64_t R, int64_t C, int dtype, cst_stream stream);
+/* The same for a whole table of matrices in one launch (every Linear weight of a model once per update, after the optimizer step):
+ * items_dev = DEVICE array of n entries ordered by tile0 = the number of 64 x 64 tiles of the entries before it (entry 0: 0);
+ * total_tiles = their sum over the table.  One dtype per call. */
+typedef struct cst_transpose_item {
+  const void* src; void* dst;
+  int64_t R, C;      /* src [R, C] -> dst [C, R] */
+  int64_t tile0;
+} cst_transpose_item;
+int cst_transpose2d_multi(const cst_transpose_item* items_dev, int n, int64_t total_tiles, int dtype, cst_stream stream);
 /* y[r,:] = mask[r] ? 0 : x[r,:]   (x[padding_mask] = 0, wav2vec2.py:820-821) */
 int cst_mask_rows(const void* x, const uint8_t* mask, void* y, int64_t rows, int64_t cols, int dtype, cst_stream stream);
 

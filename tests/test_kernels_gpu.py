@@ -1067,3 +1067,34 @@ def test_dx_through_transposed_weight_equals_m_major_read():
             os.environ.pop("CST_NO_WT", None)
         grads.append((gx, gw))
     assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+
+
+def test_weight_transposes_refresh_in_one_launch_after_an_optimizer_step(K):
+    """functional.WEIGHT_TRANSPOSES: the W^T copies survive across backward passes, every copy is refreshed by ONE multi-matrix launch
+    after a fused optimizer step (raw-pointer update: no autograd version bump), a torch in-place write re-transposes that weight
+    alone, and the copies always equal W^T bit for bit."""
+    from importlib import import_module
+    k, L = K
+    CF = import_module("chimera-st_amd.functional")
+    optim = import_module("chimera-st_amd.optim")
+    cache = CF._WeightTransposes()
+    ws = [torch.randn(r, c, device="cuda").bfloat16() for r, c in ((768, 2304), (3072, 768), (72, 136), (512, 512))]
+    for w in ws:
+        assert torch.equal(cache.get(w), w.t().contiguous())
+    assert cache.refreshes == 0 and len(cache.entries) == 4
+    first = [cache.get(w) for w in ws]
+    assert all(a is cache.get(w) for a, w in zip(first, ws))  # cached: no launch, same tensor
+    # a fused-optimizer-style update: the library writes the storage through raw pointers (no autograd version bump), epoch + 1
+    for w in ws:
+        vers = w._version
+        k.transpose2d(torch.randn(w.shape[1], w.shape[0], device="cuda").to(w.dtype), out=w)
+        assert w._version == vers
+        assert not torch.equal(cache.entries[(w.data_ptr(), tuple(w.shape), w.dtype)][1], w.t().contiguous())  # stale until asked for
+    optim.PARAM_EPOCH[0] += 1
+    got = cache.get(ws[2])
+    assert cache.refreshes == 1
+    for w in ws:
+        assert torch.equal(cache.get(w), w.t().contiguous())
+    assert cache.refreshes == 1 and got is first[2]
+    ws[1].mul_(2.0)  # a torch op: version bump, this weight alone
+    assert torch.equal(cache.get(ws[1]), ws[1].t().contiguous()) and cache.refreshes == 1

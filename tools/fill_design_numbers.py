@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Fills the @@…@@ placeholders of DESIGN.md §8 from the files tools/collect_profiles.sh produced:  python tools/fill_design_numbers.py profiles/r02"""
-import json, re, sys
+"""Fills the @@…@@ placeholders of DESIGN.md §8 from the files tools/collect_profiles.sh produced:  python tools/fill_design_numbers.py profiles/r03
+(the section text is tools/design_section8_<round>.md.in; placeholders a template does not use are skipped)"""
+import json, os, re, sys
 tag = sys.argv[1]  # e.g. gpurun_out/r02_prof/r02
 def J(name):
     for l in open("%s_%s.json" % (tag, name)):
@@ -20,7 +21,7 @@ def row(pattern, sect):
             return l
     return ""
 def mfma(pattern):
-    l = row(pattern, 1); mm = re.search(r"MFMA busy\s+([\d.]+)%", l); return mm.group(1) if mm else "?"
+    l = row(pattern, 1); mm = re.search(r"MFMA busy\s+([\d.]+)%", l); return mm.group(1) if mm else "–"
 def fab(pattern):
     l = row(pattern, 2); mm = re.search(r"fabric\s+([\d.]+) MB/launch.*?(\d+) GB/s", l); return (mm.group(1), mm.group(2)) if mm else ("?", "?")
 mm0 = re.search(r"([\d.]+) +([\d.]+)  _ZN12_GLOBAL__N_120conv0_fwd_reg", stats)
@@ -51,13 +52,26 @@ rep = {
  "@@FABRIC@@": "persistent GEMM (mode 1) %s MB at %s GB/s, dW kernel %s MB at %s GB/s, LayerNorm (768-wide rows) forward %s MB at %s GB/s / backward %s MB at %s GB/s, column sums %s GB/s, dropout %s GB/s, Adam %s MB at %s GB/s, conv0 forward ≈ 2.1 GB written in %s ms ≈ %.1f TB/s (below the listing's cut-off since it stops at the frames that are read) / backward %s MB at %s GB/s (VALU-bound)." % (fab("gemm8p_kernel<true, true, 1>") + fab("CfgILi256ELi256") + fab("ln_fwd_kernelIDF16bLi2") + fab("ln_bwd_kernelIDF16bLi2") + (fab("colsum_kernel")[1], fab("dropout_kernel")[1]) + fab("adam_kernel") + (c0f, 2.1 / float(c0f)) + fab("conv0_bwd_reg")),
  "@@DECODE@@": "s2t_transformer_l (12 + 6 layers), 32 utterances × ≤ 30 s of filter banks, beam 5, 201 steps, bf16: **%.0f utterances/s, %.0f tokens/s, %.3f ms per decode step** (encoder %.1f ms per batch); `roofline` bound = hbm: %.2f GB of algorithmic bytes per step ÷ %.3f ms = %.0f GB/s = %.3f of 8 TB/s (round 1, builder-measured: 0.82 ms on another box; the same-box A/B of this round's LayerNorm folding is in §5.7)." % (dec["value"], dec["config"]["tokens_per_s"], dec["config"]["ms_per_decode_step"], dec["config"]["encoder_ms"], dec["roofline"]["algorithmic_bytes"] / 1e9, dec["roofline"]["avg_launch_ms"], dec["roofline"]["achieved"], dec["roofline"]["frac"]),
 }
-import os
 here = os.path.dirname(os.path.abspath(__file__))
-sec = open(os.path.join(here, "design_section8.md.in")).read()  # DESIGN.md section 8 with @@...@@ placeholders
+rnd = os.path.basename(tag)
+tmpl = os.path.join(here, "design_section8_%s.md.in" % rnd)
+sec = open(tmpl if os.path.exists(tmpl) else os.path.join(here, "design_section8.md.in")).read()  # DESIGN.md section 8 with @@...@@ placeholders
+if rnd != "r02":
+    h2d = s2t["config"].get("h2d", {})
+    rep["@@H2D@@"] = "%.0f utterances/s (`value_with_h2d`)." % h2d["value_with_h2d"] if "value_with_h2d" in h2d else "not measured."
+    rep["@@MFMA@@"] = ("persistent GEMM %s %% (forward: bias / activation epilogues), %s %% (one-operand epilogues: the dX GEMMs, conv stack); 16-wave dW kernel %s %%; "
+                       "attention forward %s %%, dQ %s %%, dK/dV %s %% (dropout 0.1)." % (mfma("gemm8p_kernel<true, true, 1>"), mfma("gemm8p_kernel<true, true, 2>"), mfma("CfgILi256ELi256"),
+                                                                                         mfma("fa_fwd_kernel<true>"), mfma("fa_dq_kernel<true>"), mfma("fa_dkv_kernel<true>")))
+    try:
+        rep["@@VENDOR@@"] = " ".join(l.strip().replace("(A k-major, W [N,K]): ", "").replace("torch.matmul/hipBLASLt", "hipBLASLt") + ";" for l in open("%s_hipblaslt_vs_this_library.txt" % tag) if " x " in l and "ratio" in l)
+    except OSError:
+        rep["@@VENDOR@@"] = "(not collected)"
+    rep["@@DECODE@@"] = rep["@@DECODE@@"].split(" (round 1, builder-measured")[0] + "."
 for k, v in rep.items():
-    assert k in sec, k
-    sec = sec.replace(k, v)
+    if k in sec:
+        sec = sec.replace(k, v)
+assert "@@" not in sec, re.findall(r"@@\w+@@", sec)
 d = open("DESIGN.md").read()
-a, b = d.index("## 8. Measurement (round 2"), d.index("## 9. VERDICT round 1")
+a, b = d.index("## 8. Measurement (round"), d.index("## 9. VERDICT round")
 open("DESIGN.md", "w").write(d[:a] + sec + d[b:])
 print("filled", len(rep))
