@@ -114,7 +114,8 @@ def layernorm_fwd(x, res, gamma, beta, eps, want_sum=False):
     return y, s, mean, rstd
 
 
-_EPOCH = [0]
+_EPOCH = [0x3C6EF372]  # (not 0: the stamp buffers are never initialised, and recycled device memory is full of small integers — a dead
+#                          tile whose stale word equals the epoch would be visited for nothing; harmless, but not what the stamps are for)
 
 
 def next_epoch():

@@ -17,6 +17,7 @@ TDB=$(find $O/trace -name '*.db' | head -1); DDB=$(find $O/dec_trace -name '*.db
 python tools/pmc_gemm_one.py $O/pmc_one_ea $O/pmc_one_hm 47968 3072 768 $BUILD > $O/${TAG}_pmc_gemm.json 2> $O/pmc_gemm_one.err
 python tools/kernel_stats.py $TDB 13 90 > $O/${TAG}_kernel_stats.txt 2>&1
 python tools/kernel_stats.py $DDB 1 30 > $O/${TAG}_decode_kernel_stats.txt 2>&1
+python tools/idle_gaps.py $TDB 3 10 4 40 > $O/${TAG}_idle_gaps.txt 2>&1
 python tools/pmc_step_summary.py --trace-db $TDB $O/pmc_mfma $O/pmc_hbm > $O/${TAG}_pmc_step_summary.txt 2>&1
 python tools/pmc_gemm_class.py $O/pmc_hbm 2 $BUILD > $O/${TAG}_pmc_gemm_class.json 2> $O/pmc_gemm_class.err
 grep -h '^{' $O/trace.log > $O/${TAG}_bench_under_trace.json
@@ -28,4 +29,6 @@ python bench.py --model chimera --no-cpu-baseline --no-extra > $O/${TAG}_bench_c
 python bench.py --dropout 0 --no-cpu-baseline --no-extra > $O/${TAG}_bench_dropout0.json 2> $O/bench_dropout0.err
 python bench.py --mode decode > $O/${TAG}_bench_decode.json 2> $O/bench_decode.err
 python bench.py --lengths max --no-cpu-baseline --no-extra > $O/${TAG}_bench_maxlen.json 2> $O/bench_maxlen.err
+python tools/probes/hipblaslt_names.py 2>/dev/null | grep ratio > $O/${TAG}_hipblaslt_vs_this_library.txt
+python tools/gemm_shapes_in_step.py > $O/${TAG}_gemm_shapes_in_step.txt 2>/dev/null
 ls -la $O; du -sh $O
