@@ -224,10 +224,12 @@ def test_config1_wav_input_one_step_through_the_driver(tmp_path, capsys):
 
 
 # ------------------------------------------------------------------------------------------------------------------------
-def test_config5_s2t_transformer_l_full_depth_beam5():
+@pytest.mark.parametrize("beam", [5, 10])
+def test_config5_s2t_transformer_l_full_depth_beam5(beam):
     """s2t_transformer_l as the reference defines it (12 + 6 layers, d 1024, 16 heads, ffn 4096; s2t_transformer.py:433-478), V = 10 000,
-    fp32, 32 utterances x up to 30 s of filter banks, beam 5: device engine == host mirror loop on EVERY token id of every
-    hypothesis; on a 2-sentence slice both == oracle.beam_search (CPU) on the same parameters."""
+    fp32, 32 utterances x up to 30 s of filter banks, beam 5 (BASELINE configs[4]) and beam 10 (chimera/generate/generate-mustc-final.sh:5-8 `--beam 10`:
+    320 hypothesis rows per step): device engine == host mirror loop on EVERY token id of every hypothesis; at beam 5, on a 2-sentence
+    slice both == oracle.beam_search (CPU) on the same parameters."""
     from oracle import chimera_oracle as O
     model, task, args = _build_stock("s2t_transformer_l", 10000, seed=5, untied=True)
     assert (args.encoder_layers, args.decoder_layers, args.encoder_embed_dim, args.encoder_attention_heads) == (12, 6, 1024, 16)
@@ -244,16 +246,18 @@ def test_config5_s2t_transformer_l_full_depth_beam5():
         src[b, l:] = 0
     sample = {"net_input": {"src_tokens": src.cuda(), "src_lengths": torch.tensor(lens).cuda()}}
     max_len = 24
-    h1 = SG([model], task.target_dictionary, beam_size=5, max_len_a=0, max_len_b=max_len).generate([model], sample)
-    h2 = SG([model], task.target_dictionary, beam_size=5, max_len_a=0, max_len_b=max_len, fused=False).generate([model], sample)
+    h1 = SG([model], task.target_dictionary, beam_size=beam, max_len_a=0, max_len_b=max_len).generate([model], sample)
+    h2 = SG([model], task.target_dictionary, beam_size=beam, max_len_a=0, max_len_b=max_len, fused=False).generate([model], sample)
     seen = set()
     for b in range(B):
-        assert len(h1[b]) == len(h2[b]) == 5
-        for r in range(5):
+        assert len(h1[b]) == len(h2[b]) == beam
+        for r in range(beam):
             assert h1[b][r]["tokens"].tolist() == h2[b][r]["tokens"].tolist(), (b, r)
             assert abs(float(h1[b][r]["score"]) - float(h2[b][r]["score"])) < 1e-3
             seen.update(h1[b][r]["tokens"].tolist())
     assert len(seen) > 12, "degenerate test: the hypotheses repeat a handful of tokens"
+    if beam != 5:
+        return
     # oracle on the last two sentences (the shortest: least CPU time), same parameters
     sl = [B - 2, B - 1]
     p = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}

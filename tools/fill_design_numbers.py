@@ -67,6 +67,7 @@ if rnd != "r02":
     except OSError:
         rep["@@VENDOR@@"] = "(not collected)"
     rep["@@DECODE@@"] = rep["@@DECODE@@"].split(" (round 1, builder-measured")[0] + "."
+    rep["@@FABRIC@@"] = rep["@@FABRIC@@"].replace(", dropout ? GB/s", "")
 for k, v in rep.items():
     if k in sec:
         sec = sec.replace(k, v)
