@@ -743,7 +743,9 @@ class _Conv1dCLFn(torch.autograd.Function):
                     if n == 0 or U <= 0:
                         continue
                     # B_r[ci][q*Cout + co] = W[co][ci][r + s*(n-1-q)]   (window position q <-> dz[u - (n-1) + q])
-                    wr = w3[:, [taps[n - 1 - q] for q in range(n)], :].permute(2, 1, 0).reshape(Cin, n * Cout).contiguous()
+                    # (taps r, r + s, ... in reverse order by a strided slice and a flip: indexing with a Python list would build the
+                    #  index tensor on the host — a pageable copy, i.e. a stream synchronisation in the middle of the backward pass)
+                    wr = w3[:, r::stride, :].flip(1).permute(2, 1, 0).reshape(Cin, n * Cout).contiguous()
                     # rows u with stride * u + r >= nz_in[b] read only dz rows that are exactly zero: their K loop is skipped
                     ml = ctx.nz_in[r] if ctx.nz_in is not None else None
                     K.gemm(dzp, wr, dx_full, U, Cin, n * Cout, a_kmajor=1, b_kmajor=1, lda=Cout, ldb=n * Cout, ldc=stride * Cin,
