@@ -376,7 +376,7 @@ def decode_line(args, device):
     ach = step_bytes / (ms_step * 1e-3) / 1e9
     ntok = sum(len(h[0]["tokens"]) for h in hyps)
     eng = getattr(gen, "_engine", None)
-    nodes = eng.nodes_per_step(dt) if eng is not None else 0
+    nodes = eng.nodes_per_step(dt, args.batch * beam) if eng is not None else 0
     line = {"metric": "decode utterances/sec, s2t_transformer_l beam 5 incremental decode, 1 MI355X", "value": args.batch / dt_s,
             "unit": "utterances/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_s * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",

@@ -103,11 +103,15 @@ class BeamDecodeEngine:
         self._packed = (key, dict(layers=layers, pos=table))
         return self._packed[1]
 
-    def nodes_per_step(self, dtype):
+    def nodes_per_step(self, dtype, rows=None):
         """Kernel launches (graph nodes) of one decode step: embed + per layer (LayerNorm, qkv, self-attention, out, LayerNorm, q,
         cross-attention, out, LayerNorm, fc1, fc2 — the three LayerNorms folded into their projections on the bf16 path) + final
-        LayerNorm + vocabulary projection + the two beam-search kernels."""
+        LayerNorm + vocabulary projection + the two beam-search kernels; + the split-K reduce of fc2 where it is split (bf16, <= 256
+        hypothesis rows, ffn >= 4096)."""
         per_layer = 8 if self._fuse_ln(dtype) else 11
+        F = self.dec.layers[0].fc1.out_features
+        if rows is not None and rows <= 256 and F >= 4096 and dtype == torch.bfloat16 and not os.environ.get("CST_DEC_NO_SPLITK"):
+            per_layer += 1
         return 1 + per_layer * len(self.dec.layers) + (1 if self.dec.layer_norm is not None else 0) + 1 + 2
 
     def _fuse_ln(self, dtype):
@@ -153,7 +157,8 @@ class BeamDecodeEngine:
             mean=z(bbsz, dt=torch.float32), rstd=z(bbsz, dt=torch.float32), lse=z(bsz * 64 * beam, dt=torch.float32),
             kc=[z(bbsz, L1, C) for _ in range(nl)], vc=[z(bbsz, L1, C) for _ in range(nl)],
             kx=[z(bsz, S, C) for _ in range(nl)], vx=[z(bsz, S, C) for _ in range(nl)],
-            proj=z(bsz * S, C), kpm=z(bsz, S, dt=torch.uint8) if has_mask else None, graph=None)
+            proj=z(bsz * S, C), kpm=z(bsz, S, dt=torch.uint8) if has_mask else None, graph=None,
+            gemm_ws=z(8 * bbsz * C * 4 if bbsz <= 256 else 0, dt=torch.uint8))  # split-K partials of the fc2 projection (own buffer: captured)
         d = L.BeamDesc()
         d.dtype = L.dtype_code(dtype)
         d.bsz, d.beam, d.vocab, d.max_len = bsz, beam, self.vocab, self.max_len
@@ -172,7 +177,7 @@ class BeamDecodeEngine:
         return st
 
     # ------------------------------------------------------------------------------------------------------------
-    def _linear(self, x, w, b, out, act=L.ACT_NONE, resid=None):
+    def _linear(self, x, w, b, out, act=L.ACT_NONE, resid=None, ws=None):
         M, Kd = x.shape
         N = w.shape[0]
         if (M <= 1024 and x.dtype == torch.bfloat16 and Kd % 512 == 0 and x.stride(0) % 8 == 0 and w.is_contiguous()
@@ -184,8 +189,12 @@ class BeamDecodeEngine:
                                             0 if resid is None else resid.stride(0), out.stride(0), act, None, 0,
                                             L.dtype_code(x.dtype), L.stream_ptr()), "cst_dec_linear")
             return
+        # fc2 (K = 4096) at <= 256 rows: 48 workgroups would stream 170 KB of weights each through a 48 KB ring — 23.7 us; eight K
+        # slices + the reduce launch: 15.3 us although it is a node more (tools/bench_dec_splitk.py; K = 1024 projections lose with any
+        # split).  bf16 only: the fp32 parity configuration keeps the summation order of the module path it is compared with.
+        split = 8 if (ws is not None and M <= 256 and Kd >= 4096 and x.dtype == torch.bfloat16 and not os.environ.get("CST_DEC_NO_SPLITK")) else 1
         K.gemm(x, w, out, M, N, Kd, a_kmajor=1, b_kmajor=1, lda=Kd, ldb=Kd, ldc=out.stride(0), bias=b, act=act,
-               resid=resid, ld_resid=0 if resid is None else resid.stride(0), split_k=1)
+               resid=resid, ld_resid=0 if resid is None else resid.stride(0), split_k=split, ws=ws if split > 1 else None)
 
     def _cross_fits(self, S, D):
         """True: the encoder K/V of this engine are stored head-major [bsz, H, S, D]."""
@@ -251,7 +260,7 @@ class BeamDecodeEngine:
             else:
                 self._ln(x, layer.final_layer_norm, st["h"], st)
                 self._linear(st["h"], layer.fc1.weight, layer.fc1.bias, st["f"], act=act)
-            self._linear(st["f"], layer.fc2.weight, layer.fc2.bias, x2, resid=x)
+            self._linear(st["f"], layer.fc2.weight, layer.fc2.bias, x2, resid=x, ws=st["gemm_ws"])
             x, x2 = x2, x
         if dec.layer_norm is not None:
             self._ln(x, dec.layer_norm, st["h"], st)

@@ -29,10 +29,12 @@ def _2d(t):
 def gemm(A, B, C, M, N, K, *, a_kmajor, b_kmajor, lda, ldb, ldc, bias=None, bias_mode=L.BIAS_COL, act=L.ACT_NONE,
          aux_out=None, ld_aux_out=0, dact=L.ACT_NONE, aux_in=None, ld_aux_in=0, resid=None, ld_resid=0, alpha=1.0,
          batch0=1, batch1=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), sbias=(0, 0), a_seg=0, a_seg_stride=0, b_seg=0,
-         b_seg_stride=0, split_k=-1, a_off=0, b_off=0, c_off=0, drop_p=0.0, drop_key=0, k_live=None, m_live=None, k_len=None, m_len=None):
+         b_seg_stride=0, split_k=-1, a_off=0, b_off=0, c_off=0, drop_p=0.0, drop_key=0, k_live=None, m_live=None, k_len=None, m_len=None,
+         ws=None):
     """C = epilogue(alpha * Aop @ Bop); see include/cst.h.  Offsets *_off are in elements.  k_live = (stamps, epoch): the 64-wide
     K blocks of A that are not all-zero (LiveTiles.pair()); dead blocks may be skipped; m_live: the same stamps for the rows of A of a
-    row-wise GEMM (dX): output tiles without a live row skip their K loop."""
+    row-wise GEMM (dX): output tiles without a live row skip their K loop.  ws: the caller's own split-K scratch (uint8; launches
+    captured into a graph must not depend on the shared grow-only buffer)."""
     lib = L.load()
     d = L.GemmDesc()
     d.dtype = L.dtype_code(A.dtype)
@@ -94,7 +96,9 @@ def gemm(A, B, C, M, N, K, *, a_kmajor, b_kmajor, lda, ldb, ldc, bias=None, bias
         d.m_len = None
     need = lib.cst_gemm_workspace(ctypes.byref(d))
     if need > 0:
-        ws = workspace(need, A.device)
+        if ws is None:
+            ws = workspace(need, A.device)
+        assert ws.dtype == torch.uint8 and ws.numel() >= need, "split-K scratch too small: %d < %d" % (ws.numel(), need)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     else:
         d.workspace, d.workspace_bytes = None, 0
