@@ -17,6 +17,7 @@
 #include "gemm_common.h"
 #include <vector>
 #include <stdlib.h>
+#include <string>
 #include <type_traits>
 
 namespace {
@@ -926,21 +927,47 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
   // act'(aux_in) epilogues: taken since the operand vectors are requested in one burst ahead of the epilogue passes (gemm8p.hip)
   static const bool dact_8p = getenv("CST_GEMM_8P_NO_DACT") == nullptr;
   static const bool no_skinny = getenv("CST_GEMM_NO_SKINNY") != nullptr;
-  static const int64_t skinny_tiles = getenv("CST_GEMM_SKINNY_TILES") ? atoll(getenv("CST_GEMM_SKINNY_TILES")) : 256;  // measured: 256 -0.3 ms per update, 512 no better than 0
+  // (with the four-stage ring: 256 -0.3 ms per update, 512 no better than 0; with two stages 64 x 64 tiles also win the problems of
+  //  376 / 384 tiles — 12000 x 512 x 512 17.1 -> 15.3 us, 4064 x 1536 x 512 17.4 -> 15.9 — and lose at 512: 4064 x 2048 x 512 19.9 -> 21.8)
+  static const int64_t skinny_tiles = getenv("CST_GEMM_SKINNY_TILES") ? atoll(getenv("CST_GEMM_SKINNY_TILES")) : 400;
+  static const bool skinny_ns4 = getenv("CST_GEMM_SKINNY_NS4") != nullptr;   // A/B switches
+  static const bool no_mid8p = getenv("CST_GEMM_NO_MID8P") != nullptr;
+  // k/k problems of 150-199 tiles of 256 x 256 (7901 x 1536 x 512: 186): the persistent kernel on 3/4 of the CUs still beats 744
+  // workgroups of 128 x 128 (19.5 vs 28.4 us)
+  const bool mid8p = !no_mid8p && ak && bk && !seg && nbatch == 1 && p.splits == 1 && d->M >= 256 && d->N >= 256 &&
+                     cst_ceil_div(d->M, 256) * cst_ceil_div(d->N, 256) >= 150;
   static const bool no_narrow = getenv("CST_GEMM_NO_NARROW") != nullptr;
+  static const bool experiment = getenv("CST_GEMM_EXPERIMENT") != nullptr;
+  const char* force_cfg = experiment ? getenv("CST_GEMM_FORCE_CFG") : nullptr;
+  if (force_cfg && !*force_cfg) force_cfg = nullptr;
   if (!no_narrow && !seg && !large && ak && bk && d->N <= 64 && d->M > 256) {
     rc = d->dtype == CST_BF16 ? launch_glds<bf16_t, true, true, CfgNarrowN, 2>(p, d->M, d->N, nbatch, s)
                               : launch_glds<float, true, true, CfgNarrowN, 2>(p, d->M, d->N, nbatch, s);
   } else if (!no_narrow && !seg && !large && !ak && !bk && d->M <= 64 && d->N > 256) {
     rc = d->dtype == CST_BF16 ? launch<bf16_t, false, false, false, CfgNarrowM>(p, d->M, d->N, nbatch, s)
                               : launch<float, false, false, false, CfgNarrowM>(p, d->M, d->N, nbatch, s);
+  } else if (force_cfg && ak && bk && !seg && nbatch == 1 && p.splits == 1 && d->dtype == CST_BF16) {
+    // tools/bench_gemm_cfg.py: one shape through every k/k configuration (CST_GEMM_EXPERIMENT=1, CST_GEMM_FORCE_CFG read per call)
+    const std::string f(force_cfg);
+    if (f == "skinny4") rc = launch_glds<bf16_t, true, true, CfgSkinny, 4>(p, d->M, d->N, nbatch, s);
+    else if (f == "skinny2") rc = launch_glds<bf16_t, true, true, CfgSkinny, 2>(p, d->M, d->N, nbatch, s);
+    else if (f == "small2") rc = launch_glds<bf16_t, true, true, CfgSmall, 2>(p, d->M, d->N, nbatch, s);
+    else if (f == "small3") rc = launch_glds<bf16_t, true, true, CfgSmall, 3>(p, d->M, d->N, nbatch, s);
+    else if (f == "8p" && cst_gemm8p_supported(p, ak, bk, nbatch)) rc = cst_gemm8p_launch(p, ak, bk, nbatch, s);
+    else { cst_set_error("cst_gemm: unknown CST_GEMM_FORCE_CFG %s", force_cfg); return CST_ERR_BAD_ARG; }
   } else if (!no_skinny && ak && bk && !seg && nbatch == 1 && p.splits == 1 &&
-             (d->M <= 256 || (!large && cst_ceil_div(d->M, 128) * cst_ceil_div(d->N, 128) < skinny_tiles))) {
-    // (mid-size problems too — decoder-sized Linear layers: fewer than one 128 x 128 tile per CU leaves CUs idle; 64 x 64 tiles
-    //  quadruple the workgroups)
-    rc = d->dtype == CST_BF16 ? launch_glds<bf16_t, true, true, CfgSkinny, 4>(p, d->M, d->N, nbatch, s)
-                              : launch_glds<float, true, true, CfgSkinny, 4>(p, d->M, d->N, nbatch, s);
-  } else if (d->dtype == CST_BF16 && !seg && !no_8p && (ak || all_8p || force_8p) && (!d->dact || (dact_8p && !d->resid && !d->aux_out) || all_8p || force_8p) && (large || force_8p) && cst_gemm8p_supported(p, ak, bk, nbatch))
+             (d->M <= 256 || (!large && !mid8p && cst_ceil_div(d->M, 128) * cst_ceil_div(d->N, 128) < skinny_tiles))) {
+    // (mid-size problems too — the Linear layers of the 512-wide encoder / decoder: few 128 x 128 tiles per CU leave CUs idle; 64 x 64
+    //  tiles quadruple the workgroups.)  Ring depth: four stages keep 48 KB per workgroup in flight, which is what a decode-step
+    //  projection (<= 256 rows, a few dozen workgroups, long K) is bound by; with more workgroups than fit two per CU the LDS they
+    //  hold is the limit instead — two stages let five of them share a CU (tools/bench_gemm_cfg.py: 7901 x 512 x 512 14.9 -> 12.1 us,
+    //  7901 x 512 x 2048 33.7 -> 28.7, 12000 x 512 x 512 17.1 -> 15.3; same bits: the K order per output element does not change).
+    const bool two_stage = d->M > 256 && cst_ceil_div(d->M, 64) * cst_ceil_div(d->N, 64) > 512 && !skinny_ns4;
+    if (two_stage) rc = d->dtype == CST_BF16 ? launch_glds<bf16_t, true, true, CfgSkinny, 2>(p, d->M, d->N, nbatch, s)
+                                             : launch_glds<float, true, true, CfgSkinny, 2>(p, d->M, d->N, nbatch, s);
+    else rc = d->dtype == CST_BF16 ? launch_glds<bf16_t, true, true, CfgSkinny, 4>(p, d->M, d->N, nbatch, s)
+                                   : launch_glds<float, true, true, CfgSkinny, 4>(p, d->M, d->N, nbatch, s);
+  } else if (d->dtype == CST_BF16 && !seg && !no_8p && (ak || all_8p || force_8p) && (!d->dact || (dact_8p && !d->resid && !d->aux_out) || all_8p || force_8p) && (large || mid8p || force_8p) && cst_gemm8p_supported(p, ak, bk, nbatch))
     rc = cst_gemm8p_launch(p, ak, bk, nbatch, s);
   else if (d->dtype == CST_BF16) rc = CST_GEMM_DISPATCH(bf16_t);
   else rc = CST_GEMM_DISPATCH(float);
