@@ -124,7 +124,7 @@ class BeamDecodeEngine:
         wf = w.detach().float()
         wg = (wf * ln.weight.detach().float().unsqueeze(0)).to(w.dtype).contiguous()
         sg = wg.float().sum(dim=1).contiguous()
-        sb = (wf @ ln.bias.detach().float()).contiguous()
+        sb = (wf * ln.bias.detach().float().unsqueeze(0)).sum(dim=1).contiguous()  # (a row-wise sum, not `wf @ beta`: no vendor BLAS in the package)
         if b is not None:
             sb = (sb + b.detach().float()).contiguous()
         return wg, sg, sb, float(ln.eps)
