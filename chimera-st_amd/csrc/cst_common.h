@@ -132,22 +132,6 @@ __device__ __forceinline__ uint32_t cst_drop_bits32(uint32_t key, uint32_t key2,
   return x ^ (x >> 13);
 }
 __device__ __forceinline__ uint32_t cst_drop_key2(uint32_t key) { return key * 0x2C1B3C6DU + 0x297A2D39U; }
-// Attention-probability dropout: the same word-per-element-pair scheme with a mixer built from 24-bit multiply-adds only.
-// v_mul_lo_u32 is a quarter-rate instruction on gfx950 (16 issue cycles per wave against 4 for a plain VALU op); the two 32-bit
-// multiplies of cst_drop_bits32 were 32 of the 56 cycles a mask word cost, in kernels that are VALU-bound (rocprofv3:
-// SQ_ACTIVE_INST_VALU 92 % of SIMD time in attn_fwd_kernel with dropout).  v_mad_u32_u24 runs at the full rate:
-//   x = pair ^ key;  t = lo24(x) * 0x9E3779 + lo24(x >> 8) * 0x7FEB35;  t ^= t >> 15;  w = lo24(t) * 0x85EBCB + key2;  w ^= w >> 13
-// (9 full-rate operations, 36 cycles).  Both 24-bit windows of x enter the first step, so index bits 24-31 are mixed as well;
-// measured on 4 M consecutive pairs: keep rate 0.8999 at p = 0.1, |correlation| < 1e-3 between the halves of a word, between
-// neighbouring words and between rows, chi-square of every output byte within 255 +- 45.  Numpy twin: rng.keep_mask_attn_numpy.
-__device__ __forceinline__ uint32_t cst_drop_bits24(uint32_t key, uint32_t key2, uint32_t pair) {
-  const uint32_t x = pair ^ key;
-  uint32_t t = __umul24(x, 0x9E3779U);
-  t = __umul24(x >> 8, 0x7FEB35U) + t;
-  t ^= t >> 15;
-  uint32_t w = __umul24(t, 0x85EBCBU) + key2;
-  return w ^ (w >> 13);
-}
 // Attention-probability dropout: the mask is generated ON THE MATRIX CORES.  Hashing a mask word per score pair cost more VALU issue
 // than a 32 x 64 score tile's 16 MFMAs (270 of 390 VALU instructions per tile in round 2; a separable hash of round 3 still 4
 // operations per score, 9 in the dK/dV kernel where a lane owns a key), in kernels whose matrix pipe idles two thirds of the time.
