@@ -736,9 +736,11 @@ int choose_splits(const cst_gemm_desc* d) {
     const int64_t tl = cst_ceil_div(d->M, 256) * cst_ceil_div(d->N, 256) * nb;
     if (tl >= 200) return 1;
     // one workgroup per CU: the largest split count that still fits ONE round of 256 workgroups (288 would run as a full
-    // round plus a 12 %-occupied second one)
+    // round plus a 12 %-occupied second one) — and leaves every workgroup at least 16 K tiles: below that the 256 x 256 tile's
+    // prologue and its 256 KB of partial sums per workgroup outweigh it (512 x 2048 x 7901: 15 slices of 8 K tiles 45.6 us,
+    // 128 x 128 tiles in 4 slices 39.2)
     int64_t s = 256 / tl;
-    if (s > ktiles / 8) s = ktiles / 8;
+    if (s > ktiles / 16) s = ktiles / 16;
     if (s > 32) s = 32;
     if (s >= 1 && tl * s >= 200) return (int)s;
   }
@@ -946,6 +948,18 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
   } else if (!no_narrow && !seg && !large && !ak && !bk && d->M <= 64 && d->N > 256) {
     rc = d->dtype == CST_BF16 ? launch<bf16_t, false, false, false, CfgNarrowM>(p, d->M, d->N, nbatch, s)
                               : launch<float, false, false, false, CfgNarrowM>(p, d->M, d->N, nbatch, s);
+  } else if (force_cfg && !ak && !bk && !seg && nbatch == 1 && d->dtype == CST_BF16) {
+    // (dW layouts: both operands mn-major; the split count comes from the caller's split_k.  tools/bench_gemm_cfg_dw.py — its
+    //  back-to-back launches keep the operands in L2 / Infinity Cache: 64 x 64 tiles with a quarter of the K slices won there
+    //  (512 x 512 x 4064: 19.9 -> 16.2 us) and LOST inside the update, where the operands come from HBM and the longer K loop per
+    //  workgroup is exposed (22.4 -> 24.6 us; x 7901: 24.8 -> 35.2): not adopted.)
+    const std::string f(force_cfg);
+    if (f == "small") rc = launch<bf16_t, false, false, false, CfgSmall>(p, d->M, d->N, nbatch, s);
+    else if (f == "narrowm") rc = launch<bf16_t, false, false, false, CfgNarrowM>(p, d->M, d->N, nbatch, s);
+    else if (f == "narrown") rc = launch<bf16_t, false, false, false, CfgNarrowN>(p, d->M, d->N, nbatch, s);
+    else if (f == "skinny") rc = launch<bf16_t, false, false, false, CfgSkinny>(p, d->M, d->N, nbatch, s);
+    else if (f == "large") rc = launch<bf16_t, false, false, false, CfgLarge>(p, d->M, d->N, nbatch, s);
+    else { cst_set_error("cst_gemm: unknown CST_GEMM_FORCE_CFG %s", force_cfg); return CST_ERR_BAD_ARG; }
   } else if (force_cfg && ak && bk && !seg && nbatch == 1 && p.splits == 1 && d->dtype == CST_BF16) {
     // tools/bench_gemm_cfg.py: one shape through every k/k configuration (CST_GEMM_EXPERIMENT=1, CST_GEMM_FORCE_CFG read per call)
     const std::string f(force_cfg);
