@@ -929,9 +929,9 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
   // act'(aux_in) epilogues: taken since the operand vectors are requested in one burst ahead of the epilogue passes (gemm8p.hip)
   static const bool dact_8p = getenv("CST_GEMM_8P_NO_DACT") == nullptr;
   static const bool no_skinny = getenv("CST_GEMM_NO_SKINNY") != nullptr;
-  // (with the four-stage ring: 256 -0.3 ms per update, 512 no better than 0; with two stages 64 x 64 tiles also win the problems of
-  //  376 / 384 tiles — 12000 x 512 x 512 17.1 -> 15.3 us, 4064 x 1536 x 512 17.4 -> 15.9 — and lose at 512: 4064 x 2048 x 512 19.9 -> 21.8)
-  static const int64_t skinny_tiles = getenv("CST_GEMM_SKINNY_TILES") ? atoll(getenv("CST_GEMM_SKINNY_TILES")) : 400;
+  // (256: -0.3 ms per update, 512 no better than 0.  400 looked better in back-to-back launches with the two-stage ring (4064 x 1536 x 512
+  //  17.4 -> 15.9 us) and was worse inside the update, where the operands are not L2-warm: 21.5 -> 24.4 us.)
+  static const int64_t skinny_tiles = getenv("CST_GEMM_SKINNY_TILES") ? atoll(getenv("CST_GEMM_SKINNY_TILES")) : 256;
   static const bool skinny_ns4 = getenv("CST_GEMM_SKINNY_NS4") != nullptr;   // A/B switches
   static const bool no_mid8p = getenv("CST_GEMM_NO_MID8P") != nullptr;
   // k/k problems of 150-199 tiles of 256 x 256 (7901 x 1536 x 512: 186): the persistent kernel on 3/4 of the CUs still beats 744
