@@ -83,6 +83,11 @@ class BucketedGradAllReduce:
         # CUs the persistent GEMMs leave to the all-reduce kernels while buckets are in flight (first-8-GPU-run knob; 0 = off):
         # --ddp-reserve-cus / CST_DDP_RESERVE_CUS.  Bucket size: --bucket-cap-mb / CST_BUCKET_CAP_MB.
         self.reserve_cus = int(os.environ.get("CST_DDP_RESERVE_CUS", "0"))
+        # CST_DDP_COLLECTIVE = allreduce (default) | rs_ag: the gradient exchange of a bucket as reduce-scatter + all-gather
+        self.collective = os.environ.get("CST_DDP_COLLECTIVE", "allreduce")
+        if self.collective not in ("allreduce", "rs_ag"):
+            raise ValueError("CST_DDP_COLLECTIVE must be allreduce or rs_ag, not %r" % self.collective)
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self._reserved = False
         self.last_early, self.last_missing = 0, []
         self.late_params = []
@@ -107,6 +112,8 @@ class BucketedGradAllReduce:
                     self._ready[b] = True  # launched from the next gradient hook (never during forward)
 
     def reset(self):
+        if getattr(self, "_reserved", False):  # a backward pass that raised before finish(): the reservation is process-global
+            self._set_reserved(False)
         self._pending = [len(b["members"]) for b in self.buckets]
         self._ready = [False] * len(self.buckets)
         self._next = 0
@@ -152,33 +159,54 @@ class BucketedGradAllReduce:
         g.div_(self.world)
         if self.reserve_cus > 0 and not self._reserved:  # from the first bucket in flight until finish()
             self._set_reserved(True)
-        self._works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        n = g.numel()
+        if self.collective == "rs_ag" and n % self.world == 0 and n > 0:
+            # reduce-scatter + all-gather of the bucket, in place (rank r owns shard r between the two): the same sums as the
+            # all-reduce in two collectives RCCL can route over all seven xGMI links at once; the first 8-GPU session A/Bs it
+            # (tools/ddp_overlap_trace.py).  Both are queued on the communicator's stream in this order, so only the second is awaited.
+            shard = g[self.rank * (n // self.world):(self.rank + 1) * (n // self.world)]
+            rs = dist.reduce_scatter_tensor(shard, g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            if dist.get_backend(self.pg) != "nccl":  # gloo (CPU tests) runs asynchronous collectives on a thread pool: no stream order
+                rs.wait()
+            self._works.append(dist.all_gather_into_tensor(g, shard, group=self.pg, async_op=True))
+        else:
+            self._works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def _set_reserved(self, on):
-        try:
-            from . import lib as L
-            L.load().cst_gemm_reserve_cus(self.reserve_cus if on else 0)
-            self._reserved = on
-        except Exception:  # CPU-only hosts (the gloo tests): there is no persistent GEMM to shrink
+        if not torch.cuda.is_available():  # CPU-only hosts (the gloo tests): there is no persistent GEMM to shrink
             self._reserved = False
+            return
+        from . import lib as L
+        L.load().cst_gemm_reserve_cus(self.reserve_cus if on else 0)  # a GPU host: a missing symbol or a bad value must be heard
+        self._reserved = on
 
     def _launch_ready(self):
         while self._next < len(self.buckets) and self._ready[self._next]:
             self._launch(self._next)
             self._next += 1
 
-    def late_reduce(self, indices):
-        """All-reduce the gradients of `indices` (parameters whose bucket left without them) on their own.  EVERY rank calls this
-        with the SAME list: the trainer agrees on it through the statistics all-reduce (a rank that lost its forward pass to an
-        out-of-memory error has no late parameters of its own, and an update that is going to be dropped skips the call).  Only
-        the late parameter's slice is touched, so the members of its bucket that were already averaged are not divided again."""
+    def late_reduce(self, late_by_rank):
+        """Second, rank-agreed reduction of the parameters whose bucket left without the gradient of SOME rank.  late_by_rank[r] =
+        the set of parameter indices that were late on rank r (every rank holds the same table: the trainer all-gathers the 0/1
+        masks; a rank that lost its forward pass to an out-of-memory error has an empty set, and an update that is going to be
+        dropped skips the call).  For a parameter in the union, a rank where it was late holds its own raw gradient (the bucket
+        carried zeros for it) and contributes gradient / world; the ranks where it was on time all hold the same partial mean
+        S = sum over the on-time ranks / world: the lowest of them contributes S, the others zeros.  The sum is the mean over all
+        ranks, exactly.  Only the late parameter's slice is touched, so the other members of its bucket are not divided again."""
+        rank = dist.get_rank(self.pg)
+        union = sorted(set().union(*late_by_rank))
         works = []
-        for idx in indices:
-            if self.gather is not None:
-                self.gather([idx])
+        for idx in union:
             p = self.params[idx]
             g = self.flat_grad[self._offsets[idx]:self._offsets[idx] + p.numel()]
-            g.div_(self.world)
+            if idx in late_by_rank[rank]:
+                if self.gather is not None:
+                    self.gather([idx])
+                g.div_(self.world)
+            else:
+                on_time = [r for r in range(self.world) if idx not in late_by_rank[r]]
+                if rank != on_time[0]:
+                    g.zero_()
             works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         for w in works:
             w.wait()

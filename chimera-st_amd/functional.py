@@ -3,6 +3,7 @@ path is nn.Module.forward / autograd.Function calling ATen; here they call libcs
 
 Every function requires CUDA(HIP) tensors; there is no CPU path."""
 import os as _os
+import weakref as _weakref
 
 import torch
 
@@ -58,47 +59,96 @@ def _want_wt(M, w):
             and w.shape[1] % _vec(w.dtype) == 0 and not _os.environ.get("CST_NO_WT"))
 
 
+def _wversion(w):
+    """Autograd version of a weight operand; the stacked q | k | v view (stacked_rows) shares only q's counter, so it carries its
+    three parameters and reports the sum of theirs."""
+    parts = getattr(w, "_cst_parts", None)
+    return w._version if parts is None else sum(p._version for p in parts)
+
+
 class _WeightTransposes:
     """W^T copies of the Linear weights the dX GEMMs read (see _linear_backward), kept across updates.  A weight changes only in the
-    optimizer step (optim.PARAM_EPOCH counts the fused kernel's raw-pointer updates) or through an in-place torch op (its autograd
-    version): the first request after an optimizer step refreshes EVERY registered copy in one launch (cst_transpose2d_multi —
-    one launch per update instead of one small launch per Linear per backward pass: 0.75 -> 0.15 ms per update on the bench
-    configuration, ~110 launches fewer); a weight changed any other way is re-transposed on its own when it is asked for."""
+    optimizer step (optim.PARAM_EPOCH counts every raw-pointer write of the flat parameter buffer) or through an in-place torch op
+    (its autograd version): the first request after an optimizer step refreshes EVERY registered copy in one launch
+    (cst_transpose2d_multi — one launch per update instead of one small launch per Linear per backward pass: 0.75 -> 0.15 ms per
+    update on the bench configuration, ~110 launches fewer); a weight changed any other way is re-transposed on its own when it is
+    asked for.
 
-    MAX_ENTRIES = 1024
+    Only weights that outlive an update are cached: views of a flat parameter buffer registered by optim.FlatParamBuffers (the
+    entries go when the buffers object is collected) and free-standing nn.Parameters (held weakly).  Anything else — the torch.cat
+    fallback of stacked_rows, a zero-padded odd-width weight — is transposed into a fresh tensor and forgotten."""
 
     def __init__(self):
-        self.entries = {}   # (data_ptr, shape, dtype) -> [w (kept alive: its address cannot be reused), wt, version, epoch]
-        self.tables = {}    # (device, dtype) -> transpose table over the entries of that kind
-        self.refreshes = 0  # whole-table launches (tests)
+        self.entries = {}     # (data_ptr, shape, dtype) -> [src: detached w | weakref to a Parameter, wt, version, epoch, storage ptr]
+        self.tables = {}      # (device, dtype) -> transpose table over the entries of that kind
+        self.refreshes = 0    # whole-table launches (tests)
+        self.persistent = {}  # storage data_ptr of a registered flat parameter buffer -> weakref to its owner
+
+    def register_storage(self, owner, flat):
+        sp = flat.untyped_storage().data_ptr()
+        self.persistent[sp] = _weakref.ref(owner)
+        _weakref.finalize(owner, self._drop_storage, sp)
+
+    def _drop_storage(self, sp):
+        self.persistent.pop(sp, None)
+        for k in [k for k, e in self.entries.items() if e[4] == sp]:
+            del self.entries[k]
+        self.tables.clear()
+
+    def invalidate(self):
+        """Forget every copy (between models of one process: bench.py's extra legs, test suites)."""
+        self.entries.clear()
+        self.tables.clear()
+
+    @staticmethod
+    def _src(e):
+        return e[0]() if isinstance(e[0], _weakref.ref) else e[0]
 
     def get(self, w):
         from .optim import PARAM_EPOCH
         epoch = PARAM_EPOCH[0]
         key = (w.data_ptr(), tuple(w.shape), w.dtype)
         e = self.entries.get(key)
+        if e is not None and self._src(e) is None:  # a dead Parameter whose address was handed out again
+            del self.entries[key]
+            self.tables.pop((w.device, w.dtype), None)
+            e = None
         if e is None:
-            if len(self.entries) >= self.MAX_ENTRIES:  # models built and dropped again (test suites): start over
-                self.entries.clear()
-                self.tables.clear()
-            e = self.entries[key] = [w.detach(), K.transpose2d(w), w._version, epoch]
+            sp = w.untyped_storage().data_ptr()
+            owner = self.persistent.get(sp)
+            if owner is not None and owner() is not None:
+                src = w.detach()
+                parts = getattr(w, "_cst_parts", None)
+                if parts is not None:
+                    src._cst_parts = parts
+            elif isinstance(w, torch.nn.Parameter):
+                src, sp = _weakref.ref(w), None
+            else:
+                return K.transpose2d(w)  # a temporary: not cached
+            e = self.entries[key] = [src, K.transpose2d(w), _wversion(w), epoch, sp]
             self.tables.pop((w.device, w.dtype), None)
             return e[1]
-        if e[2] != w._version:  # written by a torch op since (load_state_dict, manual edits)
+        if e[2] != _wversion(w):  # written by a torch op since (load_state_dict, manual edits)
             K.transpose2d(w, e[1])
-            e[2], e[3] = w._version, epoch
+            e[2], e[3] = _wversion(w), epoch
             return e[1]
         if e[3] != epoch:  # an optimizer step since: refresh every stale copy of this kind at once
             kind = (w.device, w.dtype)
-            stale = [v for k, v in self.entries.items() if v[0].device == w.device and k[2] == w.dtype and v[3] != epoch]
+            stale = []
+            for k, v in list(self.entries.items()):
+                t = self._src(v)
+                if t is None:
+                    del self.entries[k]
+                elif t.device == w.device and k[2] == w.dtype and v[3] != epoch:
+                    stale.append(v)
             ids = [id(v) for v in stale]
             t = self.tables.get(kind)
             if t is None or t[5] != ids:  # (the table is rebuilt only when the set of weights changed: first updates of a run)
-                t = self.tables[kind] = K.transpose_table([(v[0], v[1]) for v in stale]) + (ids,)
+                t = self.tables[kind] = K.transpose_table([(self._src(v), v[1]) for v in stale]) + (ids,)
             K.transpose2d_multi(t)
             self.refreshes += 1
             for v in stale:
-                v[2], v[3] = v[0]._version, epoch
+                v[2], v[3] = _wversion(self._src(v)), epoch
         return e[1]
 
 
@@ -535,7 +585,9 @@ def stacked_rows(a, b, c):
             and a.data_ptr() + n == b.data_ptr() and b.data_ptr() + n == c.data_ptr()
             and a.untyped_storage().data_ptr() == c.untyped_storage().data_ptr()):
         K.STATS["qkv_view"] = K.STATS.get("qkv_view", 0) + 1
-        return _StackedRowsFn.apply(a, b, c)
+        out = _StackedRowsFn.apply(a, b, c)
+        out._cst_parts = (a.detach(), b.detach(), c.detach())  # version counters of all three (WEIGHT_TRANSPOSES, _wversion)
+        return out
     return torch.cat((a, b, c), 0)
 
 

@@ -15,8 +15,9 @@ from . import kernels as K
 
 ALIGN = 8  # elements: keeps every parameter view 16-byte aligned (bf16) for the GEMM loaders
 
-# Bumped by every in-place parameter update that bypasses autograd's version counters (cst_adam_step writes through raw pointers).
-# Anything that caches tensors DERIVED from parameters (decode_engine.BeamDecodeEngine._pack) keys its cache on it.
+# Bumped by every write of the flat parameter buffer that the parameters' own autograd version counters do not see: cst_adam_step
+# (raw pointers) and copies into `flat_param` itself (each parameter was re-homed with `p.data = view` and counts on its own).
+# Anything that caches tensors DERIVED from parameters (decode_engine.BeamDecodeEngine._pack, functional.WEIGHT_TRANSPOSES) keys on it.
 PARAM_EPOCH = [0]
 
 
@@ -60,6 +61,9 @@ class FlatParamBuffers:
             p.data = self.flat_param[o:o + n].view(p.shape)
             self.grad_views.append(self.flat_grad[o:o + n].view(p.shape))
             p.grad = None
+        if self.flat_param.is_cuda:
+            from .functional import WEIGHT_TRANSPOSES
+            WEIGHT_TRANSPOSES.register_storage(self, self.flat_param)  # views of this buffer may be cached as W^T copies
 
     def zero_grad(self):
         """Gradients are left to autograd as free-standing tensors (p.grad = None lets AccumulateGrad STEAL the tensor our
@@ -222,3 +226,4 @@ class FusedAdam:
         self.master.copy_(sd["master"]); self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.num_updates, self.lr = sd["num_updates"], sd["lr"]
         self.buf.flat_param.copy_(self.master)
+        PARAM_EPOCH[0] += 1  # the parameters changed under their views

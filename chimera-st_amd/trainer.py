@@ -146,13 +146,15 @@ class Trainer:
         self.last_late_count = int(vals[len(keys) + 1])  # diagnostics: late gradients seen by all ranks in this update
         if vals[len(keys) + 1] != 0:
             # some rank saw a gradient arrive after its bucket had been reduced (a parameter reported unused that took part after
-            # all).  Rare; every rank takes this branch together: agree on the parameter set (element-wise MAX of a 0/1 mask),
-            # reduce those parameters again and exchange the norms of the corrected gradients.
+            # all).  Rare; every rank takes this branch together: all-gather the 0/1 masks (WHO was late matters: a rank where the
+            # gradient was on time already holds a partial mean, see late_reduce), reduce those parameters again and exchange the
+            # norms of the corrected gradients.
             mask = torch.zeros(len(self.buffers.params), dtype=torch.int32, device=self.device)
             if late:
                 mask[torch.tensor(late, device=self.device)] = 1
-            dist.all_reduce(mask, op=dist.ReduceOp.MAX)
-            self.model.reducer.late_reduce([i for i, m in enumerate(mask.tolist()) if m])
+            masks = [torch.zeros_like(mask) for _ in range(self.world)]
+            dist.all_gather(masks, mask)
+            self.model.reducer.late_reduce([{i for i, m in enumerate(mk.tolist()) if m} for mk in masks])
             slots = norm_slots()
             dist.all_reduce(slots)
             sumsq = slots.tolist()

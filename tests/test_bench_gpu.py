@@ -38,10 +38,12 @@ def test_bench_line_contract():
     assert r["unit"] in ("TFLOP/s", "GB/s") and r["launches"] > 0 and r["avg_launch_ms"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == "utterances/s" and c["sample"]
-    assert c["reference_equivalent"]["value"] > c["value"] and c["reference_equivalent"]["source"].startswith("profiles/")
+    assert c["reference_equivalent"]["value"] > c["value"] and "profiles/" in c["reference_equivalent"]["source"] and c["reference_equivalent"]["approximate"] is True
     assert d["config"]["h2d"]["included_in_value"] is False and d["config"]["h2d"]["value_with_h2d"] > 0
     # the default 1-GPU run also carries BASELINE configs 4 (Chimera) and 5 (beam-search decode) measured on the same box
     x = d["extra"]
+    # ... and the all-max-length variant of the headline workload (the configuration BASELINE.md section 3 prices)
+    assert x["maxlen"]["value"] > 0 and x["maxlen"]["steps"] == 4 and 0 < x["maxlen"]["mfu"] < 1 and x["maxlen"]["per_class_ms"]["gemm"] > 0
     assert x["chimera"]["value"] > 0 and x["chimera"]["unit"] == "utterances/s" and x["chimera"]["roofline"]["frac"] > 0
     assert x["decode"]["value"] > 0 and x["decode"]["ms_per_decode_step"] > 0 and x["decode"]["roofline"]["bound"] == "hbm"
 

@@ -1078,10 +1078,13 @@ def test_weight_transposes_refresh_in_one_launch_after_an_optimizer_step(K):
     CF = import_module("chimera-st_amd.functional")
     optim = import_module("chimera-st_amd.optim")
     cache = CF._WeightTransposes()
-    ws = [torch.randn(r, c, device="cuda").bfloat16() for r, c in ((768, 2304), (3072, 768), (72, 136), (512, 512))]
+    ws = [torch.nn.Parameter(torch.randn(r, c, device="cuda").bfloat16(), requires_grad=False)
+          for r, c in ((768, 2304), (3072, 768), (72, 136), (512, 512))]
     for w in ws:
         assert torch.equal(cache.get(w), w.t().contiguous())
     assert cache.refreshes == 0 and len(cache.entries) == 4
+    tmp = torch.randn(256, 512, device="cuda").bfloat16()  # a temporary (torch.cat fallback, padded weight): transposed, never cached
+    assert torch.equal(cache.get(tmp), tmp.t().contiguous()) and len(cache.entries) == 4
     first = [cache.get(w) for w in ws]
     assert all(a is cache.get(w) for a, w in zip(first, ws))  # cached: no launch, same tensor
     # a fused-optimizer-style update: the library writes the storage through raw pointers (no autograd version bump), epoch + 1
@@ -1098,3 +1101,48 @@ def test_weight_transposes_refresh_in_one_launch_after_an_optimizer_step(K):
     assert cache.refreshes == 1 and got is first[2]
     ws[1].mul_(2.0)  # a torch op: version bump, this weight alone
     assert torch.equal(cache.get(ws[1]), ws[1].t().contiguous()) and cache.refreshes == 1
+    # a dead Parameter does not pin its copy: the entry goes with the next whole-table refresh
+    key3 = (ws[3].data_ptr(), tuple(ws[3].shape), ws[3].dtype)
+    del first, got, w
+    ws.pop()
+    optim.PARAM_EPOCH[0] += 1
+    cache.get(ws[0])
+    assert key3 not in cache.entries and len(cache.entries) == 3
+
+
+def test_weight_transposes_follow_the_flat_buffer_and_the_stacked_view(K):
+    """Views of a FlatParamBuffers storage are cached while the buffers live; the stacked q | k | v view notices an in-place edit of k
+    or v alone (it shares only q's version counter); a restore through FusedAdam.load_state_dict (a copy into the flat buffer: no
+    per-parameter version bump) refreshes the copies; dropping the buffers drops the entries."""
+    import gc
+    from importlib import import_module
+    CF = import_module("chimera-st_amd.functional")
+    optim = import_module("chimera-st_amd.optim")
+
+    class Attn(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.self_attention = True
+            self.k_proj, self.v_proj, self.q_proj = (torch.nn.Linear(64, 64) for _ in range(3))
+
+    net = Attn().cuda().bfloat16()
+    buf = optim.FlatParamBuffers(net.parameters(), adjacent=optim.qkv_groups(net))
+    cache = CF.WEIGHT_TRANSPOSES
+    cache.invalidate()
+    cat = lambda: torch.cat((net.q_proj.weight, net.k_proj.weight, net.v_proj.weight), 0).detach()
+    w = CF.stacked_rows(net.q_proj.weight, net.k_proj.weight, net.v_proj.weight)
+    assert w.data_ptr() == net.q_proj.weight.data_ptr()
+    assert torch.equal(cache.get(w), cat().t().contiguous()) and len(cache.entries) == 1
+    with torch.no_grad():
+        net.v_proj.weight.mul_(3.0)  # v alone: q's version counter does not move
+    w = CF.stacked_rows(net.q_proj.weight, net.k_proj.weight, net.v_proj.weight)
+    assert torch.equal(cache.get(w), cat().t().contiguous())
+    opt = optim.FusedAdam(None, buffers=buf)
+    sd = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in opt.state_dict().items()}
+    sd["master"].mul_(0.5)
+    opt.load_state_dict(sd)
+    w = CF.stacked_rows(net.q_proj.weight, net.k_proj.weight, net.v_proj.weight)
+    assert torch.equal(cache.get(w), cat().t().contiguous())
+    del w, opt, buf, net
+    gc.collect()
+    assert len(cache.entries) == 0
