@@ -198,6 +198,8 @@ def attn_desc(q, k, v, o, lse, H, D, kpm, causal, scale, layout_q="bt", layout_k
         d.kpm_bits = None
     d.bwd_ws = None
     d.causal, d.scale = int(causal), scale
+    if q.dtype == torch.bfloat16 and D == 64 and not causal and not os.environ.get("CST_ATTN_GENERIC"):
+        STATS["attn_fast"] = STATS.get("attn_fast", 0) + 1  # (mirrors attn_fast_ok of csrc/attention.hip: the DMA-staged kernels)
     d.drop_p, d.drop_key = float(drop_p), int(drop_key) & 0xFFFFFFFF
     if kv_len is not None:
         assert (kpm is not None or seq is not None) and kv_len.dtype == torch.int32 and kv_len.numel() == B and kv_len.is_contiguous()
