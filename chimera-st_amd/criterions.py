@@ -9,6 +9,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import functional as CF
+from .distributed import notify_unused_parameters
 from .registry import register_criterion
 
 
@@ -54,6 +55,17 @@ class LabelSmoothedCrossEntropyCriterion(FairseqCriterion):
 
     def forward(self, model, sample, reduce=True):
         """:56-86.  Note Q6: net_input carries the collater's `mask`; the models here swallow it."""
+        src = sample["net_input"].get("src_tokens")
+        if torch.is_tensor(src) and not src.dtype.is_floating_point and model.training and torch.is_grad_enabled():
+            # a text-only update (the MT pre-training recipe, chimera/scripts/train-en2any-MT.sh:38-60, runs this criterion over
+            # token ids on the Chimera arch): the audio front end takes no part, its ~96 M parameters never fire a gradient hook and
+            # are all-reduced as zeros (legacy_distributed_data_parallel.py:155-156).  Reported here — where it is known that NO
+            # pass of this micro-batch is an audio pass — their buckets leave during backward instead of at finish().
+            enc = getattr(model, "encoder", None)
+            unused = [p for name in ("wav2vec_model", "subsample") if getattr(enc, name, None) is not None
+                      for p in getattr(enc, name).parameters()]
+            if unused:
+                notify_unused_parameters(unused)
         net_output = model(**sample["net_input"])
         loss, nll_loss = self.compute_loss(model, net_output, sample, reduce=reduce)
         sample_size = sample["target"].size(0) if self.sentence_avg else sample["ntokens"]

@@ -479,6 +479,20 @@ def triplet_criterion(p: P, sample: dict, cfg, eps=0.1, loss_ratio=(1.0, 1.0, 1.
     return out
 
 
+def lsce_criterion_chimera(p: P, sample: dict, cfg, eps=0.1):
+    """label_smoothed_cross_entropy on the Chimera model (criterions/label_smoothed_cross_entropy.py:56-108 over
+    S2TTransformerInterlinguaModelW2V2.forward): the MT pre-training update of chimera/scripts/train-en2any-MT.sh:38-60
+    (`--task translation --arch s2t_transformer_w2v2_interlingua_base`) when net_input.src_tokens are token ids — the encoder takes
+    its text branch (w2v2_transformer_interlingua.py:212-217, 233-236) and wav2vec2 / the subsampler receive no gradient — and the
+    plain ST update when they are samples.  The key padding mask is derived from src_lengths as a suffix mask whatever side the
+    collater padded on (:232): with the translation task's default --left-pad-source True the reference masks the LAST
+    src_len_max - len tokens of a short sentence and attends its leading pad embeddings (zeros + positions)."""
+    ni = sample["net_input"]
+    logits, mem, inter = chimera_forward_with_internal(p, ni["src_tokens"], ni["src_lengths"], ni["prev_output_tokens"], cfg)
+    loss, nll = label_smoothed_nll_loss(logits, sample["target"], eps)
+    return dict(loss=loss, nll_loss=nll, logits=logits, memory=mem, sample_size=sample["ntokens"])
+
+
 def s2t_w2v2_forward(p: P, wav, src_lengths, prev_output_tokens, cfg):
     """S2TTransformerModelW2V2.forward (models/chimera/w2v2_transformer.py:222-236)."""
     enc, enc_pm, inter = s2t_w2v2_encoder(p, wav, src_lengths, cfg)
