@@ -45,7 +45,10 @@ using CfgNarrowN = Cfg<128, 64, 2, 2>;
 using CfgNarrowM = Cfg<64, 128, 2, 2>;
 using CfgLarge = Cfg<256, 256, 4, 4>;   // 8 waves (wave tile 128 x 64), 1 block/CU: half the L2->LDS bytes per FLOP
 
-template <typename T, bool A_KMAJOR, bool B_KMAJOR, bool SEG, typename C>
+// CS: the column sums of A as a by-product (cst_gemm_desc.colsum); its own instantiation — eight more live VGPRs do not fit the
+// 16-wave configuration (128 VGPRs: 213 spills inside the K loop), so only the 4-wave configurations are built with it and the
+// launcher runs the two-launch column sum for the others.
+template <typename T, bool A_KMAJOR, bool B_KMAJOR, bool SEG, typename C, bool CS = false>
 __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmParams p) {
   constexpr int BM = C::BM, BN = C::BN, NTHREADS = C::NT, TM = C::TM, TN = C::TN;
   constexpr int VEC = DT<T>::VEC;
@@ -206,12 +209,32 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmParams p) {
     if (kt < kfull) load_tile(std::false_type{});
     else load_tile(std::true_type{});
   };
+  // column sums of A (cst_gemm_desc.colsum: the bias gradient next to dW = dY^T X): the workgroups of output-tile column 0 add up
+  // the A vectors they stage anyway.  Thread t always stages the same VEC columns (NTHREADS % MVA == 0), so VEC running sums per
+  // thread cover its k rows of every K tile; the threads sharing a column group are added through LDS after the K loop.
+  static_assert(!CS || (!A_KMAJOR && NTHREADS % MVA == 0), "a thread must stage the same columns of an mn-major A in every vector");
+  const bool do_cs = CS && tn == 0;
+  float cs[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) cs[e] = 0.0f;
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < NVA; ++i) {
       const int v = tid + NTHREADS * i;
       T* da = smem + buf * STAGE + (A_KMAJOR ? (v / KV) * LDK + (v % KV) * VEC : (v / MVA) * LDMA + (v % MVA) * VEC);
       *reinterpret_cast<u32x4*>(da) = ra[i];
+      if (CS && do_cs) {
+        if (sizeof(T) == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            cs[2 * e] += __uint_as_float(ra[i][e] << 16);
+            cs[2 * e + 1] += __uint_as_float(ra[i][e] & 0xffff0000u);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) cs[e] += __uint_as_float(ra[i][e]);
+        }
+      }
     }
 #pragma unroll
     for (int i = 0; i < NVB; ++i) {
@@ -323,6 +346,19 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmParams p) {
     if (more) store_tile(cur ^ 1);
     __syncthreads();
     cur ^= 1;
+  }
+
+  if (CS && do_cs) {  // (block-uniform) column sums: threads with equal tid % MVA hold partial sums of the same VEC columns
+    float* red = reinterpret_cast<float*>(smem_raw);  // [NTHREADS / MVA][BM]: the operand stages are free (barrier at the loop's end)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) red[(tid / MVA) * BM + (tid % MVA) * VEC + e] = cs[e];
+    __syncthreads();
+    if (tid < BM && m0 + tid < p.M) {
+      float tot = 0.0f;
+      for (int r = 0; r < NTHREADS / MVA; ++r) tot += red[r * BM + tid];  // fixed order
+      if (p.splits > 1) p.colsum_ws[((int64_t)bidx * p.splits + split) * p.M + m0 + tid] = tot;
+      else DT<T>::st((T*)p.colsum + bidx * p.M + m0 + tid, tot);
+    }
   }
 
   // ---- epilogue: accumulators -> LDS (fp32, 64 rows x (BN+4) per pass) -> row-contiguous 8-column vectors -> 16-byte
@@ -633,6 +669,13 @@ __global__ void splitk_reduce_kernel(GemmParams p) {
   const int64_t cofs = b0 * p.sc0 + b1 * p.sc1;
   const int64_t bofs = b0 * p.sbias0 + b1 * p.sbias1;
   const float* ws = p.ws + bidx * p.splits * total;
+  if (p.colsum) {  // the slices' column sums of A (cst_gemm_desc.colsum), added in split order
+    for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < p.M; m += (int64_t)gridDim.x * blockDim.x) {
+      float v = 0.0f;
+      for (int s = 0; s < p.splits; ++s) v += p.colsum_ws[(bidx * p.splits + s) * p.M + m];
+      DT<T>::st((T*)p.colsum + bidx * p.M + m, v);
+    }
+  }
   if (p.vec_epi && (p.N % 8) == 0) {
     // 8 consecutive columns per thread: 16-byte loads, four splits' loads in flight, ONE row/column division per 8 elements, the vector
     // epilogue.  The slabs are added in split order, as in the scalar loop below (same bits).
@@ -690,6 +733,18 @@ int launch(GemmParams p, int64_t M, int64_t N, int64_t nbatch, hipStream_t s) {
   static const bool no_split_order = getenv("CST_GEMM_NO_SPLIT_ORDER") != nullptr;
   p.split_order = (p.splits > 1 && nbatch == 1 && !no_split_order) ? 1 : 0;
   dim3 grid(p.tiles_m * p.tiles_n, 1, (unsigned)(nbatch * p.splits));
+  if constexpr (!AK && !BK_ && !SEG && C::NT <= 256) {
+    if (p.colsum) {
+      static bool attr_cs = false;
+      if (!attr_cs) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, AK, BK_, SEG, C, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        attr_cs = true;
+      }
+      hipLaunchKernelGGL((gemm_kernel<T, AK, BK_, SEG, C, true>), grid, dim3(C::NT), lds, s, p);
+      return cst_check_launch("cst_gemm");
+    }
+  }
+  if (p.colsum) { cst_set_error("cst_gemm: internal: column sums requested from a configuration that does not build them"); return CST_ERR_UNSUPPORTED; }
   hipLaunchKernelGGL((gemm_kernel<T, AK, BK_, SEG, C>), grid, dim3(C::NT), lds, s, p);
   return cst_check_launch("cst_gemm");
 }
@@ -762,10 +817,25 @@ int choose_splits(const cst_gemm_desc* d) {
 
 }  // namespace
 
+// cst_gemm_desc.colsum is a by-product of the 4-wave register-staged configurations (both operands mn-major: the dW layout); every
+// other launch gets it from the two-launch column sum over A, run by cst_gemm itself behind the GEMM (unbatched problems only).
+static bool colsum_fused(const cst_gemm_desc* d, int splits) {
+  return d->colsum && !d->a_kmajor && !d->b_kmajor && !d->a_seg && !d->b_seg && !use_large(d, splits);
+}
+
+extern "C" int64_t cst_colsum_workspace(int64_t rows, int64_t cols);
+extern "C" int cst_colsum_typed(const void* x, int64_t ldx, void* out, void* workspace, int64_t rows, int64_t cols, int dtype, int out_dtype, cst_stream stream);
+extern "C" int cst_colsum_typed_live(const void* x, int64_t ldx, void* out, void* workspace, int64_t rows, int64_t cols, int dtype, int out_dtype,
+                                     const uint32_t* row_live, uint32_t epoch, cst_stream stream);
+
+extern "C" int cst_gemm_colsum_is_fused(const cst_gemm_desc* d) { return d && colsum_fused(d, choose_splits(d)) ? 1 : 0; }
+
 extern "C" int64_t cst_gemm_workspace(const cst_gemm_desc* d) {
   const int s = choose_splits(d);
-  if (s <= 1) return 0;
-  return (int64_t)s * d->M * d->N * d->batch0 * d->batch1 * (int64_t)sizeof(float);
+  const int64_t nb = d->batch0 * d->batch1;
+  int64_t bytes = s > 1 ? (int64_t)s * d->M * d->N * nb * (int64_t)sizeof(float) : 0;
+  if (d->colsum) bytes += colsum_fused(d, s) ? (s > 1 ? (int64_t)s * d->M * nb * (int64_t)sizeof(float) : 0) : cst_colsum_workspace(d->K, d->M);
+  return bytes;
 }
 
 static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0) {
@@ -837,19 +907,29 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
   }
   p.splits = choose_splits(d);
   p.ws = nullptr;
+  CST_REQUIRE(!d->colsum || (!d->a_kmajor && !d->a_seg), "cst_gemm: colsum needs an mn-major, unsegmented A");
+  const bool cs_fused = colsum_fused(d, p.splits);
+  CST_REQUIRE(!d->colsum || cs_fused || (d->batch0 * d->batch1 == 1 && d->M % 8 == 0 && d->lda % 8 == 0),
+              "cst_gemm: colsum of this configuration runs as a separate column sum: unbatched, M and lda multiples of 8");
+  p.colsum = cs_fused ? d->colsum : nullptr;
+  p.colsum_ws = nullptr;
 #ifdef CST_TRACE
   if (p.splits == 1 && d->workspace) p.ws = (float*)d->workspace;  // cycle-stamp buffer of tools/gemm8p_trace.py
 #endif
   const int64_t nbatch = d->batch0 * d->batch1;
   CST_REQUIRE(cst_ceil_div(d->M, 128) * cst_ceil_div(d->N, 128) < (1ll << 31) && nbatch * p.splits < 65536, "cst_gemm: grid too large");
   if (p.splits > 1) {
-    const int64_t need = (int64_t)p.splits * d->M * d->N * nbatch * (int64_t)sizeof(float);
+    const int64_t need = cst_gemm_workspace(d);
     if (!d->workspace || d->workspace_bytes < need) {
       cst_set_error("cst_gemm: split_k=%d needs %lld workspace bytes, got %lld", p.splits, (long long)need,
                     (long long)d->workspace_bytes);
       return CST_ERR_WORKSPACE;
     }
     p.ws = (float*)d->workspace;
+    p.colsum_ws = p.ws + (int64_t)p.splits * d->M * d->N * nbatch;
+  } else if (d->colsum && !cs_fused && (!d->workspace || d->workspace_bytes < cst_gemm_workspace(d))) {
+    cst_set_error("cst_gemm: colsum needs %lld workspace bytes, got %lld", (long long)cst_gemm_workspace(d), (long long)d->workspace_bytes);
+    return CST_ERR_WORKSPACE;
   }
   hipStream_t s = (hipStream_t)stream;
   // Work that is skipped is never credited: with live-tile stamps only the live K blocks count.  The stamps live on the device,
@@ -916,7 +996,7 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
   // measured on MI355X (tools/bench_kernels.py): the DMA path wins when both operands are k-major (716 vs 661 TF/s, fc1
   // forward); with an mn-major operand the register-staged path + padded LDS rows is faster (690 vs 649, 562 vs 486).
   static const bool glds_all = getenv("CST_GEMM_GLDS_ALL") != nullptr;
-  const bool no_glds = getenv_no_glds() || (!(ak && bk) && !glds_all);
+  const bool no_glds = getenv_no_glds() || (!(ak && bk) && !glds_all) || d->colsum != nullptr;  // (column sums live in gemm_kernel)
 #define CST_GEMM_DISPATCH(T)                                                                         \
   (seg ? CST_GEMM_LAYOUT(T, true, CfgSmall)                                                           \
        : (no_glds ? (large ? CST_GEMM_LAYOUT(T, false, CfgLarge) : CST_GEMM_LAYOUT(T, false, CfgSmall)) \
@@ -981,7 +1061,7 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
                                              : launch_glds<float, true, true, CfgSkinny, 2>(p, d->M, d->N, nbatch, s);
     else rc = d->dtype == CST_BF16 ? launch_glds<bf16_t, true, true, CfgSkinny, 4>(p, d->M, d->N, nbatch, s)
                                    : launch_glds<float, true, true, CfgSkinny, 4>(p, d->M, d->N, nbatch, s);
-  } else if (d->dtype == CST_BF16 && !seg && !no_8p && (ak || all_8p || force_8p) && (!d->dact || (dact_8p && !d->resid && !d->aux_out) || all_8p || force_8p) && (large || mid8p || force_8p) && cst_gemm8p_supported(p, ak, bk, nbatch))
+  } else if (d->dtype == CST_BF16 && !seg && !no_8p && !d->colsum && (ak || all_8p || force_8p) && (!d->dact || (dact_8p && !d->resid && !d->aux_out) || all_8p || force_8p) && (large || mid8p || force_8p) && cst_gemm8p_supported(p, ak, bk, nbatch))
     rc = cst_gemm8p_launch(p, ak, bk, nbatch, s);
   else if (d->dtype == CST_BF16) rc = CST_GEMM_DISPATCH(bf16_t);
   else rc = CST_GEMM_DISPATCH(float);
@@ -1001,6 +1081,13 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
     if (d->dtype == CST_BF16) hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(splitk_reduce_kernel<float>, grid, dim3(256), 0, s, p);
     rc = cst_check_launch("cst_gemm split-k reduce");
+  }
+  if (rc == CST_OK && d->colsum && !cs_fused) {
+    // the 16-wave / DMA configurations do not build the by-product: two-launch column sum over A [K rows, M columns], its row-chunk
+    // partials behind the split-K slabs of the caller's workspace; the live K stamps are the same 64-row blocks
+    void* cws = (char*)d->workspace + (p.splits > 1 ? (int64_t)p.splits * d->M * d->N * (int64_t)sizeof(float) : 0);
+    rc = p.k_live ? cst_colsum_typed_live(d->A, d->lda, d->colsum, cws, d->K, d->M, d->dtype, d->dtype, p.k_live, p.k_epoch, stream)
+                  : cst_colsum_typed(d->A, d->lda, d->colsum, cws, d->K, d->M, d->dtype, d->dtype, stream);
   }
   return rc;
 }

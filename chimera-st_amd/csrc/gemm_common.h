@@ -42,6 +42,8 @@ struct GemmParams {
   const int32_t* k_len;  // gemm_kernel, per batch0: K rows >= k_len[b0] of A are zero
   const int32_t* m_len;  // per batch0: output tiles with m0 >= m_len[b0] skip their K loop (rows of A all zero, values of C unused)
   const uint32_t* k_live; uint32_t k_epoch;  // gemm_kernel: K blocks of 64 whose stamp != k_epoch are all-zero in A and skipped
+  void* colsum;      // gemm_kernel, mn-major A: [batch][M] column sums of A over k (storage dtype), written by the n-tile-0 workgroups
+  float* colsum_ws;  // splits > 1: fp32 partials [batch][split][M] behind the slabs; added by the reduce kernel in split order
 };
 
 __device__ __forceinline__ int64_t segaddr(int64_t c, int64_t seg, int64_t seg_stride) {

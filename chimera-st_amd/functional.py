@@ -155,6 +155,14 @@ class _WeightTransposes:
 WEIGHT_TRANSPOSES = _WeightTransposes()
 
 
+def _grad_out(w):
+    """The flat-gradient-buffer slot of weight `w` as the output tensor of its weight-gradient GEMM (optim.grad_slot), or None."""
+    if _os.environ.get("CST_NO_GRAD_SLOT"):
+        return None
+    from .optim import grad_slot
+    return grad_slot(w)
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, resid, act, drop_p, drop_key):
@@ -208,9 +216,12 @@ def _linear_backward(ctx, dy, dxp):
         dyp[:, :N] = dy2
         dy2 = dyp
     db_fused = None
+    want_db = ctx.has_bias and ctx.needs_input_grad[2]
+    # the bias gradient rides in the weight-gradient GEMM when that GEMM's kernel builds it for free (cst_gemm_desc.colsum)
+    db_in_dw = want_db and ctx.needs_input_grad[1] and Np % 8 == 0 and not _os.environ.get("CST_NO_GEMM_COLSUM") and K.dw_colsum_is_fused(Np, Kd, M, w.dtype)
     if ctx.drop[0] > 0.0:  # gradient of the dropped branch: the same mask, regenerated
         dyc = dy2 if dy2.is_contiguous() else dy2.contiguous()
-        if ctx.act == L.ACT_NONE and ctx.has_bias and ctx.needs_input_grad[2] and Np == N and N % 8 == 0 and not _os.environ.get("CST_NO_DROP_COLSUM"):
+        if not db_in_dw and ctx.act == L.ACT_NONE and want_db and Np == N and N % 8 == 0 and not _os.environ.get("CST_NO_DROP_COLSUM"):
             dy2, db_fused = K.dropout_colsum(dyc, ctx.drop[0], ctx.drop[1], w.dtype, live)  # mask + bias gradient in one pass
         else:
             dy2 = K.dropout(dyc, *ctx.drop)
@@ -231,10 +242,16 @@ def _linear_backward(ctx, dy, dxp):
         if live is not None and dxp is None:
             dx = _with_tiles(dx, live)  # a zero row of dz is a zero row of dz W
     if ctx.needs_input_grad[1]:
-        dw = torch.empty(Np, Kd, dtype=w.dtype, device=w.device)
-        K.gemm(dz, x2, dw, Np, Kd, M, a_kmajor=0, b_kmajor=0, lda=Np, ldb=Kd, ldc=Kd, split_k=-1, k_live=live)
+        dw = _grad_out(w) if Np == N else None
+        if dw is None:
+            dw = torch.empty(Np, Kd, dtype=w.dtype, device=w.device)
+        if db_in_dw:
+            db = torch.empty(Np, dtype=w.dtype, device=w.device)
+        K.gemm(dz, x2, dw, Np, Kd, M, a_kmajor=0, b_kmajor=0, lda=Np, ldb=Kd, ldc=Kd, split_k=-1, k_live=live, colsum=db)
         dw = dw[:N]
-    if ctx.has_bias and ctx.needs_input_grad[2]:
+        if db is not None:
+            db = db[:N]
+    if want_db and db is None:
         db = db_fused if db_fused is not None else K.colsum(dz, w.dtype, live)[:N]
     if ctx.has_resid and ctx.needs_input_grad[3]:
         dres = dy
@@ -304,9 +321,12 @@ class _FFNFn(torch.autograd.Function):
         live = _tiles_of(dy, M)  # zero rows of dy are zero rows of dy2 (mask) and of dz1 (row-wise GEMM, act', mask)
         p_act, key_act, p_out, key_out = ctx.drop
         db2_fused = None
+        gcs = not _os.environ.get("CST_NO_GEMM_COLSUM")
+        db2_in_dw = gcs and has_b2 and ctx.needs_input_grad[4] and ctx.needs_input_grad[3] and dout % 8 == 0 and K.dw_colsum_is_fused(dout, F_, M, w2.dtype)
+        db1_in_dw = gcs and has_b1 and ctx.needs_input_grad[2] and ctx.needs_input_grad[1] and F_ % 8 == 0 and K.dw_colsum_is_fused(F_, d, M, w1.dtype)
         if p_out > 0.0:  # d(fc2 output) = dy * mask_out
             dyc = dy2 if dy2.is_contiguous() else dy2.contiguous()
-            if has_b2 and ctx.needs_input_grad[4] and dout % 8 == 0 and not _os.environ.get("CST_NO_DROP_COLSUM"):
+            if not db2_in_dw and has_b2 and ctx.needs_input_grad[4] and dout % 8 == 0 and not _os.environ.get("CST_NO_DROP_COLSUM"):
                 dy2, db2_fused = K.dropout_colsum(dyc, p_out, key_out, w2.dtype, live)  # mask + fc2 bias gradient in one pass
             else:
                 dy2 = K.dropout(dyc, p_out, key_out)
@@ -320,9 +340,13 @@ class _FFNFn(torch.autograd.Function):
                    drop_p=p_act, drop_key=key_act, m_live=live)
         dx = dw1 = db1 = dw2 = db2 = None
         if ctx.needs_input_grad[3]:
-            dw2 = torch.empty(dout, F_, dtype=w2.dtype, device=w2.device)
-            K.gemm(dy2, h, dw2, dout, F_, M, a_kmajor=0, b_kmajor=0, lda=dout, ldb=F_, ldc=F_, split_k=-1, k_live=live)
-        if has_b2 and ctx.needs_input_grad[4]:
+            dw2 = _grad_out(w2)
+            if dw2 is None:
+                dw2 = torch.empty(dout, F_, dtype=w2.dtype, device=w2.device)
+            if db2_in_dw:
+                db2 = torch.empty(dout, dtype=w2.dtype, device=w2.device)
+            K.gemm(dy2, h, dw2, dout, F_, M, a_kmajor=0, b_kmajor=0, lda=dout, ldb=F_, ldc=F_, split_k=-1, k_live=live, colsum=db2)
+        if has_b2 and ctx.needs_input_grad[4] and db2 is None:
             db2 = db2_fused if db2_fused is not None else K.colsum(dy2, w2.dtype, live)
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, d, dtype=x2.dtype, device=x2.device)
@@ -334,9 +358,13 @@ class _FFNFn(torch.autograd.Function):
                        resid=_flat2d(dy) if ctx.res_is_x else None, ld_resid=d, m_live=live)
             dx = dx.view(xshape)
         if ctx.needs_input_grad[1]:
-            dw1 = torch.empty(F_, d, dtype=w1.dtype, device=w1.device)
-            K.gemm(dz1, x2, dw1, F_, d, M, a_kmajor=0, b_kmajor=0, lda=F_, ldb=d, ldc=d, split_k=-1, k_live=live)
-        if has_b1 and ctx.needs_input_grad[2]:
+            dw1 = _grad_out(w1)
+            if dw1 is None:
+                dw1 = torch.empty(F_, d, dtype=w1.dtype, device=w1.device)
+            if db1_in_dw:
+                db1 = torch.empty(F_, dtype=w1.dtype, device=w1.device)
+            K.gemm(dz1, x2, dw1, F_, d, M, a_kmajor=0, b_kmajor=0, lda=F_, ldb=d, ldc=d, split_k=-1, k_live=live, colsum=db1)
+        if has_b1 and ctx.needs_input_grad[2] and db1 is None:
             db1 = K.colsum(dz1, w1.dtype, live)
         dres = dy if has_res and ctx.needs_input_grad[5] and not (ctx.res_is_x and ctx.needs_input_grad[0]) else None
         return dx, dw1, db1, dw2, db2, dres, None, None, None, None, None
@@ -587,6 +615,7 @@ def stacked_rows(a, b, c):
         K.STATS["qkv_view"] = K.STATS.get("qkv_view", 0) + 1
         out = _StackedRowsFn.apply(a, b, c)
         out._cst_parts = (a.detach(), b.detach(), c.detach())  # version counters of all three (WEIGHT_TRANSPOSES, _wversion)
+        out._cst_parts_params = (a, b, c)                      # ... and the parameters themselves (optim.grad_slot)
         return out
     return torch.cat((a, b, c), 0)
 
@@ -898,10 +927,16 @@ class _PosConvFn(torch.autograd.Function):
             # partial sums written and read back by a sum over the batch.)
             Kr = B * Tp - (k - 1)
             dwg = torch.empty(groups, cg, k * cg, dtype=torch.float32, device=dy.device)
+            if ctx.needs_input_grad[2] and not _os.environ.get("CST_NO_GEMM_COLSUM"):
+                # the bias gradient = column sums of this GEMM's A operand (every dz row is inside its K range, the rest are zeros):
+                # [groups][cg] = channel order (cst_gemm_desc.colsum)
+                db = torch.empty(C, dtype=dy.dtype, device=dy.device)
             K.gemm(dzg, xg, dwg, cg, k * cg, Kr, a_kmajor=0, b_kmajor=0, lda=cg, ldb=cg, ldc=k * cg, batch0=1, batch1=groups,
-                   sa=(0, B * Tp * cg), sb=(0, B * Tp * cg), sc=(0, cg * k * cg), a_off=lp * cg, split_k=1)
+                   sa=(0, B * Tp * cg), sb=(0, B * Tp * cg), sc=(0, cg * k * cg), a_off=lp * cg, split_k=1, colsum=db)
             dw = dwg.view(groups, cg, k, cg).permute(0, 1, 3, 2).reshape(C, cg, k).to(weight.dtype)
-        if ctx.needs_input_grad[2]:
+            if db is not None:
+                db = db.to(weight.dtype)
+        if ctx.needs_input_grad[2] and db is None:
             db = K.colsum(dz.view(B * T, C), weight.dtype)
         return dx, dw, db, None
 

@@ -1,6 +1,7 @@
 """Raw (non-autograd) wrappers: torch tensors in, C-ABI calls out.  Torch only supplies device
 memory and the current HIP stream here; every arithmetic op is a kernel of libcst_hip.so."""
 import ctypes
+import os
 
 import torch
 
@@ -30,8 +31,9 @@ def gemm(A, B, C, M, N, K, *, a_kmajor, b_kmajor, lda, ldb, ldc, bias=None, bias
          aux_out=None, ld_aux_out=0, dact=L.ACT_NONE, aux_in=None, ld_aux_in=0, resid=None, ld_resid=0, alpha=1.0,
          batch0=1, batch1=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), sbias=(0, 0), a_seg=0, a_seg_stride=0, b_seg=0,
          b_seg_stride=0, split_k=-1, a_off=0, b_off=0, c_off=0, drop_p=0.0, drop_key=0, k_live=None, m_live=None, k_len=None, m_len=None,
-         ws=None):
-    """C = epilogue(alpha * Aop @ Bop); see include/cst.h.  Offsets *_off are in elements.  k_live = (stamps, epoch): the 64-wide
+         ws=None, colsum=None):
+    """C = epilogue(alpha * Aop @ Bop); see include/cst.h.  colsum (mn-major A): [batch, M] tensor of A's dtype that receives the
+    column sums of A over k — the bias gradient next to a weight-gradient GEMM (cst_gemm_desc.colsum).  Offsets *_off are in elements.  k_live = (stamps, epoch): the 64-wide
     K blocks of A that are not all-zero (LiveTiles.pair()); dead blocks may be skipped; m_live: the same stamps for the rows of A of a
     row-wise GEMM (dX): output tiles without a live row skip their K loop.  ws: the caller's own split-K scratch (uint8; launches
     captured into a graph must not depend on the shared grow-only buffer)."""
@@ -94,6 +96,11 @@ def gemm(A, B, C, M, N, K, *, a_kmajor, b_kmajor, lda, ldb, ldc, bias=None, bias
         STATS["gemm_m_len"] = STATS.get("gemm_m_len", 0) + 1
     else:
         d.m_len = None
+    if colsum is not None:
+        assert not a_kmajor and colsum.dtype == A.dtype and colsum.is_contiguous() and colsum.numel() == M * batch0 * batch1
+        d.colsum = colsum.data_ptr()
+    else:
+        d.colsum = None
     need = lib.cst_gemm_workspace(ctypes.byref(d))
     if need > 0:
         if ws is None:
@@ -104,6 +111,28 @@ def gemm(A, B, C, M, N, K, *, a_kmajor, b_kmajor, lda, ldb, ldc, bias=None, bias
         d.workspace, d.workspace_bytes = None, 0
     L.check(lib.cst_gemm(ctypes.byref(d), L.stream_ptr()), "cst_gemm")
     return C
+
+
+_DW_FUSED = {}
+
+
+def dw_colsum_is_fused(n_out, k_in, tokens, dtype):
+    """Whether the weight-gradient GEMM dW[n_out, k_in] = dY^T X over `tokens` rows yields the bias gradient as a by-product of its
+    own kernel (cst_gemm_colsum_is_fused) — the 4-wave configurations do, the 16-wave one runs a separate column sum."""
+    key = (n_out, k_in, tokens, dtype)
+    r = _DW_FUSED.get(key)
+    if r is None:
+        d = L.GemmDesc()
+        d.dtype = d.c_dtype = L.dtype_code(dtype)
+        d.a_kmajor = d.b_kmajor = 0
+        d.M, d.N, d.K = n_out, k_in, tokens
+        d.batch0 = d.batch1 = 1
+        d.split_k = -1
+        d.colsum = 1  # (any non-NULL value: the query reads no memory)
+        r = _DW_FUSED[key] = bool(L.load().cst_gemm_colsum_is_fused(ctypes.byref(d)))
+        if len(_DW_FUSED) > 4096:
+            _DW_FUSED.clear()
+    return r
 
 
 def layernorm_fwd(x, res, gamma, beta, eps, want_sum=False):

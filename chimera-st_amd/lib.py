@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcst_hip.so")
-ABI_VERSION = 4  # include/cst.h: CST_ABI_VERSION
+ABI_VERSION = 5  # include/cst.h: CST_ABI_VERSION
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
@@ -43,6 +43,7 @@ class GemmDesc(ctypes.Structure):
         ("m_live", c_p), ("m_epoch", ctypes.c_uint32),
         ("k_len", c_p),
         ("m_len", c_p),
+        ("colsum", c_p),
     ]
 
 
@@ -99,6 +100,7 @@ SYMBOLS = [
     ("cst_layernorm_bwd", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_int, c_int, c_p]),
     ("cst_layernorm_bwd_tiles", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_int, c_int, c_p, ctypes.c_uint32, c_p]),
     ("cst_gemm_workspace", c_i64, [ctypes.POINTER(GemmDesc)]),
+    ("cst_gemm_colsum_is_fused", c_int, [ctypes.POINTER(GemmDesc)]),
     ("cst_gemm", c_int, [ctypes.POINTER(GemmDesc), c_p]),
     ("cst_prof_dump", c_i64, [c_int, ctypes.c_char_p, c_i64]),
     ("cst_gemm_reserve_cus", c_int, [c_int]),

@@ -8,6 +8,7 @@ optim/fp16_optimizer.py:16-300) -> multiply_grads -> utils.clip_grad_norm_ (util
     master, and writes the model-dtype parameter.  The combined scale is a DEVICE scalar: no host sync in the step.
 Flags mirror fairseq: --adam-betas --adam-eps --weight-decay --lr --clip-norm --warmup-updates --warmup-init-lr."""
 import math
+import weakref
 
 import torch
 
@@ -55,12 +56,16 @@ class FlatParamBuffers:
         self.flat_param = torch.zeros(total, dtype=self.dtype, device=self.device)
         self.flat_grad = torch.zeros(total, dtype=self.dtype, device=self.device)
         self.grad_views = []
+        self.epoch = 1  # bumped by zero_grad: a gradient slot is handed out at most once per epoch (grad_slot)
         for p, o in zip(self.params, self.offsets):
             n = p.numel()
             self.flat_param[o:o + n].copy_(p.data.reshape(-1))
             p.data = self.flat_param[o:o + n].view(p.shape)
             self.grad_views.append(self.flat_grad[o:o + n].view(p.shape))
             p.grad = None
+            # functional._linear_backward writes a weight gradient straight into its slot of the flat buffer (grad_slot below)
+            p._cst_grad_slot = (weakref.ref(self), len(self.grad_views) - 1)
+            p._cst_grad_claim = 0
         if self.flat_param.is_cuda:
             from .functional import WEIGHT_TRANSPOSES
             WEIGHT_TRANSPOSES.register_storage(self, self.flat_param)  # views of this buffer may be cached as W^T copies
@@ -70,6 +75,7 @@ class FlatParamBuffers:
         backward kernels wrote, instead of launching one `grad += new` kernel per parameter); they are gathered into the flat
         buffer bucket-by-bucket (gather_grads) right before they are all-reduced / consumed by the fused optimizer."""
         self.flat_grad.zero_()
+        self.epoch += 1
         for p in self.params:
             p.grad = None
 
@@ -88,6 +94,40 @@ class FlatParamBuffers:
             for i in idxs:
                 if self.params[i].grad is not None:
                     self.params[i].grad = self.grad_views[i]
+
+
+def grad_slot(w):
+    """Where a backward kernel may write the gradient of weight `w` directly: its view of the flat gradient buffer — instead of a
+    fresh tensor that gather_grads copies there later (339 MB per update on the bench model) — or None.  Handed out at most once
+    per zero_grad epoch and only while w.grad is None: a second use of a shared weight in the same backward pass, or a later
+    micro-batch of an accumulated update, gets None and takes the ordinary route (autograd then ADDS into the slot; writing there
+    again would overwrite what it already holds).  `w` is a Parameter re-homed by FlatParamBuffers, or the stacked q | k | v view of
+    three adjacent ones (functional.stacked_rows: their slots are adjacent too)."""
+    parts = getattr(w, "_cst_parts_params", None)
+    ps = parts if parts is not None else (w,)
+    slots = []
+    for p in ps:
+        s = getattr(p, "_cst_grad_slot", None)
+        buf = s[0]() if s is not None else None
+        if buf is None or p.grad is not None or p._cst_grad_claim == buf.epoch or not p.requires_grad:
+            return None
+        slots.append((buf, s[1], p))
+    buf = slots[0][0]
+    if any(b is not buf for b, _, _ in slots):
+        return None
+    views = [buf.grad_views[i] for _, i, _ in slots]
+    if len(views) == 1:
+        out = views[0].detach()  # a fresh alias: AccumulateGrad only adopts a gradient tensor nobody else holds
+    else:
+        n = views[0].numel() * views[0].element_size()
+        if not all(v.shape == views[0].shape and views[k].data_ptr() + n == v.data_ptr() for k, v in enumerate(views[1:])):
+            return None
+        out = torch.as_strided(views[0], (len(views) * views[0].shape[0],) + tuple(views[0].shape[1:]), views[0].stride(), views[0].storage_offset())
+    if tuple(out.shape) != tuple(w.shape):
+        return None
+    for _, _, p in slots:
+        p._cst_grad_claim = buf.epoch
+    return out
 
 
 def qkv_groups(model):

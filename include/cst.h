@@ -29,9 +29,9 @@ extern "C" {
 #endif
 
 /* Bumps on any change of a signature or a descriptor layout (3: cst_gemm_desc.m_len, cst_attn_desc.seq_offsets, workspaces of the
- * fixed-order reductions; 4: cst_attn_desc.kpm_bits / bwd_ws, the separable attention-dropout mask).  cst_version() returns the
- * value the library was built with; chimera-st_amd/lib.py refuses a mismatch. */
-#define CST_ABI_VERSION 4
+ * fixed-order reductions; 4: cst_attn_desc.kpm_bits / bwd_ws, the separable attention-dropout mask; 5: cst_gemm_desc.colsum).
+ * cst_version() returns the value the library was built with; chimera-st_amd/lib.py refuses a mismatch. */
+#define CST_ABI_VERSION 5
 
 typedef enum { CST_F32 = 0, CST_BF16 = 1 } cst_dtype;
 
@@ -154,9 +154,20 @@ typedef struct {
                                         reference zeroes them behind the CNN, wav2vec2.py:820-821, and their gradient is exactly zero).
                                         Output tiles that lie entirely behind m_len[b0] skip their K loop and run the epilogue on
                                         zero accumulators (C = epilogue(0): 0 for the bias-free GELU / GELU' epilogues of that stack). */
+  void* colsum;                      /* optional (ABI 5), mn-major A only: colsum[batch][m] = sum_k A[k][m] in `dtype`, a by-product of staging
+                                        A (the tiles of output column 0 add up the A vectors they load anyway; with split-K the slices'
+                                        partial sums ride behind the slabs in the workspace and the reduce kernel adds them in split
+                                        order).  With A = dY of a Linear this is the bias gradient (torch's `grad_output.sum(0)` behind
+                                        F.linear, modules/multihead_attention.py / transformer_layer.py call sites): the weight-gradient
+                                        GEMM dW = dY^T X reads every dY element exactly once per output tile column, so no separate
+                                        column-sum pass over dY is needed.  Fixed summation order (bit-reproducible). */
 } cst_gemm_desc;
 
 int64_t cst_gemm_workspace(const cst_gemm_desc* d);
+/* 1 if cst_gemm would produce d->colsum (non-NULL) as a by-product of this launch's own kernel, 0 if it would run the separate
+ * two-launch column sum behind it (the 16-wave / DMA configurations): a caller that can get the sums cheaper elsewhere — e.g. from
+ * the dropout pass that has to read dY anyway, cst_dropout_colsum — asks first. */
+int cst_gemm_colsum_is_fused(const cst_gemm_desc* d);
 /* Persistent GEMM launches use (CUs - n) workgroups from now on (n < 0: query only); returns the previous value.  The data-parallel
  * reducer sets it while bucket all-reduces are in flight under the backward pass, so that the RCCL kernels on the side stream find free
  * CUs instead of waiting for a launch boundary (legacy_distributed_data_parallel.py has no overlap to protect).  Initial value:

@@ -1237,3 +1237,44 @@ def test_attention_dma_staged_kernels_at_the_bench_sequence_length(K, packed):
         check(pdqkv[0, sl, :C], qr.grad[b, :n], dt, "packed dq[%d]" % b)
         check(pdqkv[0, sl, C:2 * C], kr.grad[b, :n], dt, "packed dk[%d]" % b)
         check(pdqkv[0, sl, 2 * C:], vr.grad[b, :n], dt, "packed dv[%d]" % b)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("n_out,k_in,tokens", [(512, 512, 4064), (1536, 512, 7901), (512, 2048, 7901), (768, 3072, 31760), (72, 136, 300)])
+def test_gemm_colsum_is_the_bias_gradient_next_to_dw(K, dt, n_out, k_in, tokens):
+    """cst_gemm_desc.colsum on the weight-gradient layout (both operands mn-major): dW = dY^T X and db = column sums of dY from ONE
+    call — a by-product of the 4-wave kernels (with and without split-K, with live-tile stamps), the separate two-launch column sum
+    behind the 16-wave kernel — against fp32 torch; bit-reproducible; dW has the bits of the launch without the by-product."""
+    k, L = K
+    if dt == torch.float32 and tokens > 20000:
+        pytest.skip("bf16-only shape")
+    dy = rnd(tokens, n_out, dt=dt, seed=61)
+    dy[tokens // 2: tokens // 2 + 700] = 0  # dead rows (padded frames)
+    x = rnd(tokens, k_in, dt=dt, seed=62)
+    fused = k.dw_colsum_is_fused(n_out, k_in, tokens, dt)
+    if dt == torch.bfloat16:  # (the 16-wave configuration takes the wav2vec2-sized products only; fp32 splits K differently)
+        assert fused == (n_out < 256 or k_in < 256 or tokens < 20000)
+    outs = []
+    for rep in range(2):
+        dw, db = torch.empty(n_out, k_in, dtype=dt, device="cuda"), torch.empty(n_out, dtype=dt, device="cuda")
+        k.gemm(dy, x, dw, n_out, k_in, tokens, a_kmajor=0, b_kmajor=0, lda=n_out, ldb=k_in, ldc=k_in, split_k=-1, colsum=db)
+        outs.append((dw, db))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    dw0 = torch.empty(n_out, k_in, dtype=dt, device="cuda")
+    k.gemm(dy, x, dw0, n_out, k_in, tokens, a_kmajor=0, b_kmajor=0, lda=n_out, ldb=k_in, ldc=k_in, split_k=-1)
+    assert torch.equal(dw0, outs[0][0])
+    ref = dy.float().sum(0)
+    check(outs[0][1], ref, dt, "db", scale=float(ref.abs().max()))
+    check(outs[0][0], dy.float().t() @ x.float(), dt, "dW")
+    if tokens % 64 == 0 or True:
+        # live-tile stamps (the dead rows' 64-row blocks skipped): same sums
+        rows64 = (tokens + 63) // 64
+        live_rows = (dy.float().abs().sum(1) > 0)
+        pad = rows64 * 64 - tokens
+        lr = torch.cat([live_rows, torch.zeros(pad, dtype=torch.bool, device="cuda")]).view(rows64, 64).any(1)
+        epoch = 0x1234567
+        stamps = torch.where(lr, torch.full((rows64,), epoch, dtype=torch.int32, device="cuda"), torch.zeros(rows64, dtype=torch.int32, device="cuda"))
+        dw2, db2 = torch.empty(n_out, k_in, dtype=dt, device="cuda"), torch.empty(n_out, dtype=dt, device="cuda")
+        k.gemm(dy, x, dw2, n_out, k_in, tokens, a_kmajor=0, b_kmajor=0, lda=n_out, ldb=k_in, ldc=k_in, split_k=-1, k_live=(stamps, epoch), colsum=db2)
+        check(db2, ref, dt, "db with stamps", scale=float(ref.abs().max()))
+        check(dw2, dy.float().t() @ x.float(), dt, "dW with stamps")

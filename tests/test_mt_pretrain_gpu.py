@@ -78,6 +78,7 @@ def test_text_only_update_matches_the_oracle(left_pad):
     loss, sample_size, log = crit(model, to_cuda(sample))
     loss.backward()
     p = golden_params(g, requires_grad=True)
+    p["decoder.output_projection.weight"] = p["decoder.embed_tokens.weight"]  # tied (one Parameter in named_parameters(), Q5)
     ref = O.lsce_criterion_chimera(p, sample, golden_cfg(g))
     ref["loss"].backward()
     assert sample_size == sample["ntokens"]
