@@ -34,6 +34,8 @@ class FairseqCriterion(nn.Module):
 
 @register_criterion("label_smoothed_cross_entropy")
 class LabelSmoothedCrossEntropyCriterion(FairseqCriterion):
+    single_pass = True  # one forward pass per sample: every parameter receives one gradient per backward pass (trainer.py)
+
     def __init__(self, task, sentence_avg, label_smoothing, ignore_prefix_size=0, report_accuracy=False):
         super().__init__(task)
         self.sentence_avg = sentence_avg
@@ -92,6 +94,8 @@ class LabelSmoothedCrossEntropyCriterion(FairseqCriterion):
 
 @register_criterion("triplet_st_mt_contrastive")
 class TripletSTMTContrastiveCriterion(LabelSmoothedCrossEntropyCriterion):
+    single_pass = False  # an audio pass and a text pass per sample: the shared layers receive two gradients per backward pass
+
     def __init__(self, task, sentence_avg, label_smoothing, loss_ratio, contrastive_temp=0.1, ignore_prefix_size=0,
                  report_accuracy=False, contrastive_increase_until=None, kd_ratio=None):
         super().__init__(task, sentence_avg, label_smoothing, ignore_prefix_size, report_accuracy)

@@ -670,6 +670,89 @@ extern "C" int cst_transpose2d_multi(const cst_transpose_item* items_dev, int n,
   return cst_check_launch("cst_transpose2d_multi");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// cst_reduce_multi — the second stage of MANY fixed-order reductions in one launch.  The backward pass of one update ends ~140
+// two-stage reductions (split-K slabs of the small layers' weight gradients, bias-gradient slices riding with them, the
+// LayerNorm dgamma / dbeta row-block partials) with a tiny launch each; their results are only read when the gradients are
+// gathered, so the first stages leave their partials in place and ONE launch finishes them all (functional / kernels.py: deferred
+// reductions, flushed before anything reads a gradient).
+// Item: dst[i] = sum_{p < P} src[p * stride + i], i < L (L % 8 == 0), fp32 partials, dst in fp32 or bf16.  A block of 256 threads
+// owns 256 consecutive elements: 32 lanes x 8 elements, P dealt to 8 slices (slice s adds p = s, s + 8, ... in order, the slices
+// are added 0..7 through LDS): a fixed order whatever else shares the launch.
+// ---------------------------------------------------------------------------------------------------------------------------------
+namespace {
+struct ReduceTable { cst_reduce_item it[CST_REDUCE_MAX_ITEMS]; int n; };
+
+__global__ __launch_bounds__(256) void reduce_multi_kernel(ReduceTable t) {
+  __shared__ float part[8][32][9];
+  const int b = blockIdx.x;
+  int lo = 0, hi = t.n - 1;
+  while (lo < hi) {  // last item whose first block is <= b (uniform)
+    const int mid = (lo + hi + 1) >> 1;
+    if (t.it[mid].block0 <= b) lo = mid; else hi = mid - 1;
+  }
+  const cst_reduce_item& it = t.it[lo];
+  const int lane = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int64_t i0 = ((int64_t)(b - it.block0) * 32 + lane) * 8;
+  float a[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  if (i0 < it.L) {
+    const float* src = it.src + i0;
+    int p = sl;
+    for (; p + 24 < it.P; p += 32) {  // four partials of this slice in flight
+      f32x4 v[4][2];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v[u][0] = *reinterpret_cast<const f32x4*>(src + (int64_t)(p + 8 * u) * it.stride);
+        v[u][1] = *reinterpret_cast<const f32x4*>(src + (int64_t)(p + 8 * u) * it.stride + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] += v[u][0][e]; a[4 + e] += v[u][1][e]; }
+    }
+    for (; p < it.P; p += 8) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + (int64_t)p * it.stride), v1 = *reinterpret_cast<const f32x4*>(src + (int64_t)p * it.stride + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a[e] += v0[e]; a[4 + e] += v1[e]; }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) part[sl][lane][e] = a[e];
+  __syncthreads();
+  if (sl == 0 && i0 < it.L) {
+#pragma unroll
+    for (int s = 1; s < 8; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += part[s][lane][e];
+    if (it.dst_dtype == CST_BF16) store8((bf16_t*)it.dst + i0, a);
+    else store8((float*)it.dst + i0, a);
+  }
+}
+}  // namespace
+
+extern "C" int cst_reduce_multi(const cst_reduce_item* items, int n, cst_stream stream) {
+  CST_REQUIRE(items && n > 0 && n <= CST_REDUCE_MAX_ITEMS, "cst_reduce_multi: 1..%d items per call", CST_REDUCE_MAX_ITEMS);
+  ReduceTable t;
+  int64_t blocks = 0;
+  double bytes = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const cst_reduce_item& it = items[i];
+    CST_REQUIRE(it.src && it.dst && it.L > 0 && it.L % 8 == 0 && it.P > 0 && it.stride % 4 == 0 && ((uintptr_t)it.src % 16) == 0 && ((uintptr_t)it.dst % 16) == 0,
+                "cst_reduce_multi: item %d: L, stride, alignment", i);
+    CST_REQUIRE(it.dst_dtype == CST_F32 || it.dst_dtype == CST_BF16, "cst_reduce_multi: item %d: bad dst_dtype", i);
+    t.it[i] = it;
+    t.it[i].block0 = (int32_t)blocks;
+    blocks += cst_ceil_div(it.L, 256);
+    bytes += (double)it.L * ((double)it.P * 4.0 + cst_dtype_size(it.dst_dtype));
+  }
+  CST_REQUIRE(blocks < (1ll << 31), "cst_reduce_multi: too many blocks");
+  t.n = n;
+  hipStream_t s = (hipStream_t)stream;
+  CstProfScope prof(CST_K_ELEMENTWISE, s, 0.0, bytes);
+  hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, s, t);
+  return cst_check_launch("cst_reduce_multi");
+}
+
 extern "C" int cst_transpose2d(const void* src, void* dst, int64_t R, int64_t C, int dtype, cst_stream stream) {
   CST_REQUIRE(src && dst && R > 0 && C > 0, "cst_transpose2d: null tensor");
   const int v = dtype == CST_BF16 ? 8 : 4;

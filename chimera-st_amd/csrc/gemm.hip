@@ -828,6 +828,8 @@ extern "C" int cst_colsum_typed(const void* x, int64_t ldx, void* out, void* wor
 extern "C" int cst_colsum_typed_live(const void* x, int64_t ldx, void* out, void* workspace, int64_t rows, int64_t cols, int dtype, int out_dtype,
                                      const uint32_t* row_live, uint32_t epoch, cst_stream stream);
 
+extern "C" int cst_gemm_splits(const cst_gemm_desc* d) { return d ? choose_splits(d) : 0; }
+
 extern "C" int cst_gemm_colsum_is_fused(const cst_gemm_desc* d) { return d && colsum_fused(d, choose_splits(d)) ? 1 : 0; }
 
 extern "C" int64_t cst_gemm_workspace(const cst_gemm_desc* d) {
@@ -1073,6 +1075,13 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
              bk ? 'k' : 'm', p.splits, d->bias ? " bias" : "", d->act ? " act" : "", d->aux_out ? " aux_out" : "", d->dact ? " dact" : "",
              d->resid ? " resid" : "", d->drop_p > 0 ? " drop" : "", (d->k_live || d->m_live || d->k_len || d->m_len) ? " live" : "");
   if (rc != CST_OK) return rc;
+  if (p.splits > 1 && d->defer_reduce) {
+    // the slabs stay in the caller's workspace for cst_reduce_multi: only epilogues that are a plain conversion can be finished there
+    CST_REQUIRE(nbatch == 1 && d->alpha == 1.0f && !d->bias && !d->act && !d->dact && !d->aux_out && !d->resid && d->drop_p == 0.0f && d->ldc == d->N &&
+                    d->N % 8 == 0 && (!d->colsum || cs_fused),
+                "cst_gemm: defer_reduce needs a plain epilogue, a dense C and an unbatched problem");
+    return rc;
+  }
   if (p.splits > 1) {
     const int64_t total = d->M * d->N;
     const int64_t work = (p.vec_epi && d->N % 8 == 0) ? total / 8 : total;  // items the reduce kernel's threads walk

@@ -262,7 +262,7 @@ extern "C" int64_t cst_layernorm_bwd_workspace(int64_t rows, int64_t cols) {
 static int layernorm_bwd_impl(const void* dy, const void* sx, const void* gamma, const float* mean, const float* rstd,
                               const void* dres, void* dx, void* dgamma, void* dbeta, void* workspace, int64_t rows,
                               int64_t cols, int dtype, int grad_dtype, uint32_t* tile_live, uint32_t epoch, cst_stream stream) {
-  CST_REQUIRE(dy && sx && gamma && mean && rstd && dx && dgamma && dbeta && workspace, "cst_layernorm_bwd: null tensor");
+  CST_REQUIRE(dy && sx && gamma && mean && rstd && dx && workspace && ((dgamma != nullptr) == (dbeta != nullptr)), "cst_layernorm_bwd: null tensor");
   CST_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 8 * 64 * LN_MAXV, "cst_layernorm_bwd: cols=%lld must be a multiple of 8 and <= %d", (long long)cols, 8 * 64 * LN_MAXV);
   hipStream_t s = (hipStream_t)stream;
   const double bytes = (double)rows * cols * cst_dtype_size(dtype) * (3.0 + (dres ? 1.0 : 0.0));
@@ -278,6 +278,7 @@ static int layernorm_bwd_impl(const void* dy, const void* sx, const void* gamma,
   int rc = cst_check_launch("cst_layernorm_bwd");
   if (rc != CST_OK) return rc;
   CST_REQUIRE(grad_dtype == CST_F32 || grad_dtype == dtype, "cst_layernorm_bwd: grad_dtype must be f32 or dtype");
+  if (!dgamma) return rc;  // deferred: the row-block partials [blocks][2][cols] stay in `workspace` for cst_reduce_multi (include/cst.h)
   if (grad_dtype == CST_BF16)
     hipLaunchKernelGGL(ln_bwd_reduce_kernel<bf16_t>, dim3((unsigned)cst_ceil_div(cols, 16)), dim3(1024), 0, s, (const float*)workspace, (bf16_t*)dgamma, (bf16_t*)dbeta, nb, (int)cols);
   else

@@ -153,6 +153,9 @@ class BucketedGradAllReduce:
 
     def _launch(self, b):
         bk = self.buckets[b]
+        if self.flat_grad.is_cuda:  # gradients whose last reduction stage was deferred (kernels.DEFER) are finished before they travel
+            from . import kernels as K
+            K.DEFER.flush()
         if self.gather is not None:
             self.gather(bk["members"])
         g = self.flat_grad[bk["lo"]:bk["hi"]]

@@ -155,6 +155,21 @@ class _WeightTransposes:
 WEIGHT_TRANSPOSES = _WeightTransposes()
 
 
+def _may_defer(*params):
+    """May the second stage of a reduction that produces the gradients of `params` wait for the deferred-reduction flush
+    (kernels.DEFER)?  Only while the mode is on, none of them is shared between modules (trainer.py marks those: a second gradient
+    would be added to the first at once) and none is being accumulated into (a later micro-batch of an update)."""
+    if not K.DEFER.on:
+        return False
+    for w in params:
+        if w is None:
+            continue
+        for p in (getattr(w, "_cst_parts_params", None) or (w,)):
+            if not isinstance(p, torch.nn.Parameter) or p.grad is not None or getattr(p, "_cst_shared", False):
+                return False
+    return True
+
+
 def _grad_out(w):
     """The flat-gradient-buffer slot of weight `w` as the output tensor of its weight-gradient GEMM (optim.grad_slot), or None."""
     if _os.environ.get("CST_NO_GRAD_SLOT"):
@@ -247,7 +262,8 @@ def _linear_backward(ctx, dy, dxp):
             dw = torch.empty(Np, Kd, dtype=w.dtype, device=w.device)
         if db_in_dw:
             db = torch.empty(Np, dtype=w.dtype, device=w.device)
-        K.gemm(dz, x2, dw, Np, Kd, M, a_kmajor=0, b_kmajor=0, lda=Np, ldb=Kd, ldc=Kd, split_k=-1, k_live=live, colsum=db)
+        K.gemm(dz, x2, dw, Np, Kd, M, a_kmajor=0, b_kmajor=0, lda=Np, ldb=Kd, ldc=Kd, split_k=-1, k_live=live, colsum=db,
+               defer=Np == N and _may_defer(w))
         dw = dw[:N]
         if db is not None:
             db = db[:N]
@@ -345,7 +361,8 @@ class _FFNFn(torch.autograd.Function):
                 dw2 = torch.empty(dout, F_, dtype=w2.dtype, device=w2.device)
             if db2_in_dw:
                 db2 = torch.empty(dout, dtype=w2.dtype, device=w2.device)
-            K.gemm(dy2, h, dw2, dout, F_, M, a_kmajor=0, b_kmajor=0, lda=dout, ldb=F_, ldc=F_, split_k=-1, k_live=live, colsum=db2)
+            K.gemm(dy2, h, dw2, dout, F_, M, a_kmajor=0, b_kmajor=0, lda=dout, ldb=F_, ldc=F_, split_k=-1, k_live=live, colsum=db2,
+                   defer=_may_defer(w2))
         if has_b2 and ctx.needs_input_grad[4] and db2 is None:
             db2 = db2_fused if db2_fused is not None else K.colsum(dy2, w2.dtype, live)
         if ctx.needs_input_grad[0]:
@@ -363,7 +380,8 @@ class _FFNFn(torch.autograd.Function):
                 dw1 = torch.empty(F_, d, dtype=w1.dtype, device=w1.device)
             if db1_in_dw:
                 db1 = torch.empty(F_, dtype=w1.dtype, device=w1.device)
-            K.gemm(dz1, x2, dw1, F_, d, M, a_kmajor=0, b_kmajor=0, lda=F_, ldb=d, ldc=d, split_k=-1, k_live=live, colsum=db1)
+            K.gemm(dz1, x2, dw1, F_, d, M, a_kmajor=0, b_kmajor=0, lda=F_, ldb=d, ldc=d, split_k=-1, k_live=live, colsum=db1,
+                   defer=_may_defer(w1))
         if has_b1 and ctx.needs_input_grad[2] and db1 is None:
             db1 = K.colsum(dz1, w1.dtype, live)
         dres = dy if has_res and ctx.needs_input_grad[5] and not (ctx.res_is_x and ctx.needs_input_grad[0]) else None
@@ -401,7 +419,7 @@ class _LayerNormFn(torch.autograd.Function):
             return ds, (ds if ctx.has_res else None), None, None, None
         dy2 = _flat2d(dy)
         dres = _flat2d(ds) if ds is not None else None
-        dx, dg, db, tiles = K.layernorm_bwd(dy2, src, gamma, mean, rstd, dres, grad_dtype=gamma.dtype, want_tiles=True)
+        dx, dg, db, tiles = K.layernorm_bwd(dy2, src, gamma, mean, rstd, dres, grad_dtype=gamma.dtype, want_tiles=True, defer=_may_defer(gamma))
         dx = _with_tiles(dx.view(ctx.shape), tiles)
         return dx, (dx if ctx.has_res else None), dg, db, None
 
@@ -435,7 +453,7 @@ class _LayerNormPassFn(torch.autograd.Function):
         dres = _flat2d(dxp) if dxp is not None else None
         if dy is None:
             return (dxp, None, None, None)
-        dx, dg, db = K.layernorm_bwd(_flat2d(dy), x2, gamma, mean, rstd, dres, grad_dtype=gamma.dtype)
+        dx, dg, db = K.layernorm_bwd(_flat2d(dy), x2, gamma, mean, rstd, dres, grad_dtype=gamma.dtype, defer=_may_defer(gamma))
         return dx.view(ctx.shape), dg, db, None
 
 
@@ -848,9 +866,12 @@ class _Conv1dCLFn(torch.autograd.Function):
             wgs = B * ((Cout + 255) // 256) * ((k * Cin + 255) // 256)
             rem = wgs % 256
             sk = 2 if (wgs >= 256 and 0 < rem < 192 and Lout >= 2048) else 1
+            # the sum over the utterances (and over the K slices) is ONE fixed-order pass of cst_reduce_multi over the fp32 partials,
+            # written in the parameter dtype (before: split-K reduce launch + torch sum over the batch + dtype conversion)
+            dw = torch.empty(Cout, k * Cin, dtype=w_cl.dtype, device=dy.device)
             K.gemm(dz_rows, xp, part, Cout, k * Cin, Lout, a_kmajor=0, b_kmajor=0, lda=Cout, ldb=stride * Cin, ldc=k * Cin, batch0=B,
-                   sa=(dz_bs, 0), sb=(xp.stride(0), 0), sc=(Cout * k * Cin, 0), a_off=dz_off, split_k=sk, k_len=ctx.nz_out)
-            dw = part.sum(0).to(w_cl.dtype)
+                   sa=(dz_bs, 0), sb=(xp.stride(0), 0), sc=(Cout * k * Cin, 0), a_off=dz_off, split_k=sk, k_len=ctx.nz_out, reduce_to=dw)
+            # (not deferred: autograd re-lays this gradient out — permute / reshape back to [Cout, Cin, k] — as soon as it is returned)
         if has_bias and ctx.needs_input_grad[2]:
             db = K.colsum(dz_rows.reshape(B * Lout, Cout) if dzp is None else dzp[:, 1:1 + Lout].reshape(B * Lout, Cout), w_cl.dtype)
         return dx, dw, db, None, None, None, None, None, None, None, None

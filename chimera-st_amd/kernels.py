@@ -21,6 +21,70 @@ def workspace(nbytes: int, device) -> torch.Tensor:
     return t
 
 
+class _Deferred:
+    """Second stages of fixed-order reductions (split-K slabs of the small weight-gradient GEMMs, bias-gradient slices, LayerNorm
+    dgamma / dbeta partials) that are finished together by ONE cst_reduce_multi launch instead of a launch each.  The results
+    are gradients of parameters: nothing reads them before the update gathers them, PROVIDED no second gradient of the same
+    parameter arrives in the same backward pass (autograd would add the two at once) — so the mode is switched on only by a trainer
+    whose criterion runs one pass over a model that uses each parameter once (trainer.py), parameters shared between modules are
+    excluded at the call sites, and a gradient that is being accumulated into (p.grad is not None) takes the immediate route.
+    CST_DEFER_POISON=1 (the test suite sets it) fills every deferred destination with NaN until the flush writes it: a read that
+    comes too early cannot go unnoticed."""
+
+    MAX_BYTES = 16 << 20  # slabs above this stay with their own reduce launch (they would have to be re-read cold from HBM)
+
+    def __init__(self):
+        self.on, self.items, self.keep, self.flushes = 0, [], [], 0
+
+    def push(self, src_ptr, dst, stride, Lr, P, keep):
+        if os.environ.get("CST_DEFER_POISON"):
+            dst.fill_(float("nan"))
+        self.items.append((src_ptr, dst.data_ptr(), stride, Lr, P, L.dtype_code(dst.dtype)))
+        # (an ALIAS of dst keeps its storage alive: holding dst itself would raise its reference count, and AccumulateGrad only adopts
+        #  a gradient tensor nobody else holds — otherwise it clones it on the spot, i.e. reads it before the flush has written it)
+        self.keep.append((keep, dst.detach()))
+        if len(self.items) >= 64:
+            self.flush()
+
+    def flush(self):
+        if self.items:
+            reduce_multi(self.items)
+            self.flushes += 1
+            self.items, self.keep = [], []
+
+
+DEFER = _Deferred()
+
+
+def reduce_multi(items):
+    """items: [(src_ptr, dst_ptr, stride, L, P, dst_dtype_code)] -> dst[i] = sum_p src[p * stride + i]: ONE launch (include/cst.h)."""
+    lib = L.load()
+    for at in range(0, len(items), 64):
+        chunk = items[at:at + 64]
+        arr = (L.ReduceItem * len(chunk))()
+        for a, (src, dst, stride, Lr, P, dt) in zip(arr, chunk):
+            a.src, a.dst, a.stride, a.L, a.P, a.dst_dtype = src, dst, stride, Lr, P, dt
+        L.check(lib.cst_reduce_multi(arr, len(chunk), L.stream_ptr()), "cst_reduce_multi")
+
+
+class deferred_reductions:
+    """with deferred_reductions(enabled): loss.backward()  — the flush runs on exit (and before any bucket all-reduce: distributed.py)."""
+
+    def __init__(self, enabled=True):
+        self.enabled = bool(enabled) and not os.environ.get("CST_NO_DEFER")
+
+    def __enter__(self):
+        DEFER.on += 1 if self.enabled else 0
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            DEFER.on -= 1
+            if DEFER.on == 0:
+                DEFER.flush()
+        return False
+
+
 def _2d(t):
     assert t.dim() == 2 and t.stride(1) == 1, "expected a row-major 2-D tensor, got %s / %s" % (tuple(t.shape), t.stride())
     return t
@@ -31,9 +95,13 @@ def gemm(A, B, C, M, N, K, *, a_kmajor, b_kmajor, lda, ldb, ldc, bias=None, bias
          aux_out=None, ld_aux_out=0, dact=L.ACT_NONE, aux_in=None, ld_aux_in=0, resid=None, ld_resid=0, alpha=1.0,
          batch0=1, batch1=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), sbias=(0, 0), a_seg=0, a_seg_stride=0, b_seg=0,
          b_seg_stride=0, split_k=-1, a_off=0, b_off=0, c_off=0, drop_p=0.0, drop_key=0, k_live=None, m_live=None, k_len=None, m_len=None,
-         ws=None, colsum=None):
+         ws=None, colsum=None, defer=False, reduce_to=None):
     """C = epilogue(alpha * Aop @ Bop); see include/cst.h.  colsum (mn-major A): [batch, M] tensor of A's dtype that receives the
-    column sums of A over k — the bias gradient next to a weight-gradient GEMM (cst_gemm_desc.colsum).  Offsets *_off are in elements.  k_live = (stamps, epoch): the 64-wide
+    column sums of A over k — the bias gradient next to a weight-gradient GEMM (cst_gemm_desc.colsum).
+    defer: the caller allows the split-K reduce of this launch (C and colsum are parameter gradients nobody reads yet) to be left to
+    the deferred-reduction flush (DEFER); ignored when the mode is off, the launch does not split, or the slabs are large.
+    reduce_to (batched launches into an fp32 C [batch, M, N] with sc = (M * N, 0)): the sum over the batch — and over the K slices
+    — goes to `reduce_to` [M, N] through cst_reduce_multi instead of a torch sum over C (which is then never written when K is split).  Offsets *_off are in elements.  k_live = (stamps, epoch): the 64-wide
     K blocks of A that are not all-zero (LiveTiles.pair()); dead blocks may be skipped; m_live: the same stamps for the rows of A of a
     row-wise GEMM (dX): output tiles without a live row skip their K loop.  ws: the caller's own split-K scratch (uint8; launches
     captured into a graph must not depend on the shared grow-only buffer)."""
@@ -101,7 +169,18 @@ def gemm(A, B, C, M, N, K, *, a_kmajor, b_kmajor, lda, ldb, ldc, bias=None, bias
         d.colsum = colsum.data_ptr()
     else:
         d.colsum = None
+    d.defer_reduce = 0
+    splits = 1
     need = lib.cst_gemm_workspace(ctypes.byref(d))
+    nb = batch0 * batch1
+    deferred = False
+    if need > 0 and (reduce_to is not None or (defer and DEFER.on and nb == 1 and need <= DEFER.MAX_BYTES and ldc == N and N % 8 == 0)):
+        splits = lib.cst_gemm_splits(ctypes.byref(d))
+        if splits > 1:
+            assert ws is None and bias is None and act == L.ACT_NONE and dact == L.ACT_NONE and resid is None and aux_out is None and alpha == 1.0
+            ws = torch.empty(need, dtype=torch.uint8, device=A.device)  # private: it must outlive this call (slabs read by the flush)
+            d.defer_reduce = 1
+            deferred = True
     if need > 0:
         if ws is None:
             ws = workspace(need, A.device)
@@ -110,6 +189,17 @@ def gemm(A, B, C, M, N, K, *, a_kmajor, b_kmajor, lda, ldb, ldc, bias=None, bias
     else:
         d.workspace, d.workspace_bytes = None, 0
     L.check(lib.cst_gemm(ctypes.byref(d), L.stream_ptr()), "cst_gemm")
+    if reduce_to is not None:
+        assert C.dtype == torch.float32 and sc == (M * N, 0) and ldc == N and reduce_to.numel() == M * N and reduce_to.is_contiguous() and colsum is None
+        item = ((ws.data_ptr(), reduce_to, M * N, M * N, nb * splits, ws) if deferred else (C.data_ptr(), reduce_to, M * N, M * N, nb, C))
+        if defer and DEFER.on:
+            DEFER.push(*item)
+        else:
+            reduce_multi([(item[0], item[1].data_ptr(), item[2], item[3], item[4], L.dtype_code(reduce_to.dtype))])
+    elif deferred:
+        DEFER.push(ws.data_ptr(), C, M * N, M * N, splits, ws)
+        if colsum is not None:
+            DEFER.push(ws.data_ptr() + 4 * splits * M * N, colsum, M, M, splits, ws)
     return C
 
 
@@ -157,26 +247,36 @@ def next_epoch():
     return _EPOCH[0]
 
 
-def layernorm_bwd(dy, s, gamma, mean, rstd, dres=None, grad_dtype=torch.float32, want_tiles=False):
+def layernorm_bwd(dy, s, gamma, mean, rstd, dres=None, grad_dtype=torch.float32, want_tiles=False, defer=False):
     """dgamma / dbeta come back in `grad_dtype` (fp32, or the parameter dtype: accumulated in fp32, rounded once).
-    want_tiles: also returns (stamps int32 [ceil(rows/64)], epoch) marking the 64-row tiles of dx that are not exactly zero."""
+    want_tiles: also returns (stamps int32 [ceil(rows/64)], epoch) marking the 64-row tiles of dx that are not exactly zero.
+    defer: the caller allows the second stage (row-block partials -> dgamma / dbeta) to be left to the deferred-reduction flush."""
     dy, s = _2d(dy), _2d(s)
     rows, cols = s.shape
     lib = L.load()
     dx = torch.empty_like(s)
     dg = torch.empty(cols, dtype=grad_dtype, device=s.device)
     db = torch.empty(cols, dtype=grad_dtype, device=s.device)
-    ws = workspace(lib.cst_layernorm_bwd_workspace(rows, cols), s.device)
+    wbytes = lib.cst_layernorm_bwd_workspace(rows, cols)
+    defer = bool(defer) and DEFER.on > 0
+    ws = torch.empty(wbytes, dtype=torch.uint8, device=s.device) if defer else workspace(wbytes, s.device)
+    pg, pb = (None, None) if defer else (L.ptr(dg), L.ptr(db))
+    out = (dx, dg, db)
     if want_tiles:
         stamps, epoch = torch.empty((rows + 63) // 64, dtype=torch.int32, device=s.device), next_epoch()
-        L.check(lib.cst_layernorm_bwd_tiles(L.ptr(dy), L.ptr(s), L.ptr(gamma), L.ptr(mean), L.ptr(rstd), L.ptr(dres), L.ptr(dx), L.ptr(dg),
-                                            L.ptr(db), L.ptr(ws), rows, cols, L.dtype_code(s.dtype), L.dtype_code(grad_dtype),
+        L.check(lib.cst_layernorm_bwd_tiles(L.ptr(dy), L.ptr(s), L.ptr(gamma), L.ptr(mean), L.ptr(rstd), L.ptr(dres), L.ptr(dx), pg,
+                                            pb, L.ptr(ws), rows, cols, L.dtype_code(s.dtype), L.dtype_code(grad_dtype),
                                             L.ptr(stamps), epoch, L.stream_ptr()), "cst_layernorm_bwd_tiles")
-        return dx, dg, db, (stamps, epoch)
-    L.check(lib.cst_layernorm_bwd(L.ptr(dy), L.ptr(s), L.ptr(gamma), L.ptr(mean), L.ptr(rstd), L.ptr(dres), L.ptr(dx), L.ptr(dg),
-                                  L.ptr(db), L.ptr(ws), rows, cols, L.dtype_code(s.dtype), L.dtype_code(grad_dtype), L.stream_ptr()),
-            "cst_layernorm_bwd")
-    return dx, dg, db
+        out = (dx, dg, db, (stamps, epoch))
+    else:
+        L.check(lib.cst_layernorm_bwd(L.ptr(dy), L.ptr(s), L.ptr(gamma), L.ptr(mean), L.ptr(rstd), L.ptr(dres), L.ptr(dx), pg,
+                                      pb, L.ptr(ws), rows, cols, L.dtype_code(s.dtype), L.dtype_code(grad_dtype), L.stream_ptr()),
+                "cst_layernorm_bwd")
+    if defer:  # partials: fp32 [blocks][2][cols]
+        blocks = wbytes // (8 * cols)
+        DEFER.push(ws.data_ptr(), dg, 2 * cols, cols, blocks, ws)
+        DEFER.push(ws.data_ptr() + 4 * cols, db, 2 * cols, cols, blocks, ws)
+    return out
 
 
 def _bhtd_strides(t, layout):

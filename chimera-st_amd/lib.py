@@ -44,7 +44,13 @@ class GemmDesc(ctypes.Structure):
         ("k_len", c_p),
         ("m_len", c_p),
         ("colsum", c_p),
+        ("defer_reduce", c_int),
     ]
+
+
+class ReduceItem(ctypes.Structure):
+    _fields_ = [("src", c_p), ("dst", c_p), ("stride", c_i64), ("L", c_i64), ("P", ctypes.c_int32), ("dst_dtype", ctypes.c_int32),
+                ("block0", ctypes.c_int32), ("pad_", ctypes.c_int32)]
 
 
 class AttnDesc(ctypes.Structure):
@@ -101,6 +107,8 @@ SYMBOLS = [
     ("cst_layernorm_bwd_tiles", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_int, c_int, c_p, ctypes.c_uint32, c_p]),
     ("cst_gemm_workspace", c_i64, [ctypes.POINTER(GemmDesc)]),
     ("cst_gemm_colsum_is_fused", c_int, [ctypes.POINTER(GemmDesc)]),
+    ("cst_gemm_splits", c_int, [ctypes.POINTER(GemmDesc)]),
+    ("cst_reduce_multi", c_int, [ctypes.POINTER(ReduceItem), c_int, c_p]),
     ("cst_gemm", c_int, [ctypes.POINTER(GemmDesc), c_p]),
     ("cst_prof_dump", c_i64, [c_int, ctypes.c_char_p, c_i64]),
     ("cst_gemm_reserve_cus", c_int, [c_int]),

@@ -179,7 +179,10 @@ class FusedAdam:
         self.buf.zero_grad()
 
     def backward(self, loss):
-        loss.backward()
+        # second stages of the small fixed-order reductions of this backward pass in one launch (kernels.DEFER): only when the
+        # trainer established that every parameter receives ONE gradient per backward pass (Trainer.__init__)
+        with K.deferred_reductions(getattr(self, "defer_reductions", False)):
+            loss.backward()
 
     def get_lr(self):
         return self.lr

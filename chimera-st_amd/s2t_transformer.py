@@ -202,6 +202,7 @@ def reorder_encoder_out(encoder_out: EncoderOut, new_order):
 class S2TTransformerModel(FairseqEncoderDecoderModel):
     """s2t_transformer.py:80-266 — filter-bank input variant (fbank [B,T,80] -> Conv1dSubsampler -> Transformer).
     Accepts and ignores the collater's `mask` kwarg (the reference raises TypeError there)."""
+    single_use_parameters = True  # one forward pass uses every parameter once (trainer.py: deferred reductions); tied tables are detected by name
 
     @staticmethod
     def add_args(parser):

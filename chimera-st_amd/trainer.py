@@ -34,6 +34,16 @@ class Trainer:
         self.ddp = self.world > 1 or (dist.is_initialized() and os.environ.get("CST_DDP_FORCE") == "1")
         self.model = DistributedFairseqModel(args, model, self.buffers) if self.ddp else model
         self._model = model
+        # Deferred reductions (kernels.DEFER): allowed when every parameter receives exactly one gradient per backward pass — the
+        # criterion runs ONE pass over the model (label_smoothed_cross_entropy; the triplet criterion runs two) and the model
+        # declares that a pass uses each parameter once.  Parameters reachable under two names (tied embeddings) are marked and
+        # excluded at the call sites: their two gradients are added by autograd as soon as the second one exists.
+        seen = {}
+        for _, p in model.named_parameters(remove_duplicate=False):
+            seen[id(p)] = seen.get(id(p), 0) + 1
+        for p in model.parameters():
+            p._cst_shared = seen.get(id(p), 1) > 1
+        self.optimizer.defer_reductions = bool(getattr(self.criterion, "single_pass", False) and getattr(model, "single_use_parameters", False))
         self.num_updates = 0
         self.dtype = dtype
         self._dummy_batch = None

@@ -36,6 +36,8 @@ def load_w2v_checkpoint(path):
 
 @register_model("s2t_transformer_w2v2")
 class S2TTransformerModelW2V2(FairseqEncoderDecoderModel):
+    single_use_parameters = True  # one forward pass uses every parameter once (trainer.py: deferred reductions); tied tables are detected by name
+
     @staticmethod
     def add_args(parser):
         """w2v2_transformer.py:53-172."""

@@ -76,7 +76,9 @@ int cst_layernorm_fwd(const void* x, const void* res, const void* gamma, const v
                       int64_t rows, int64_t cols, float eps, int dtype, cst_stream stream);
 /* dx = LN backward w.r.t. s (s = x + res is what `s` points to); dgamma/dbeta fp32 [cols]
  * (overwritten) in `grad_dtype` (CST_F32 or `dtype`: accumulated in fp32, rounded once).  dres (optional extra upstream gradient on s, e.g. the residual branch) is
- * added into dx when non-NULL.  workspace: cst_layernorm_bwd_workspace() bytes. */
+ * added into dx when non-NULL.  workspace: cst_layernorm_bwd_workspace() bytes.  dgamma = dbeta = NULL (ABI 5): the second stage is
+ * left to cst_reduce_multi — the row-block partials stay in `workspace` as fp32 [blocks][2][cols] (dgamma row, dbeta row per block),
+ * blocks = cst_layernorm_bwd_workspace(rows, cols) / (8 * cols). */
 int64_t cst_layernorm_bwd_workspace(int64_t rows, int64_t cols);
 int cst_layernorm_bwd(const void* dy, const void* s, const void* gamma, const float* mean,
                       const float* rstd, const void* dres, void* dx, void* dgamma, void* dbeta,
@@ -161,6 +163,11 @@ typedef struct {
                                         F.linear, modules/multihead_attention.py / transformer_layer.py call sites): the weight-gradient
                                         GEMM dW = dY^T X reads every dY element exactly once per output tile column, so no separate
                                         column-sum pass over dY is needed.  Fixed summation order (bit-reproducible). */
+  int defer_reduce;                  /* split-K launches only (ABI 5): 1 = do not launch the reduce; the fp32 slabs [split][M][N] (and the
+                                        colsum slices [split][M] behind them) stay in `workspace`, which the caller keeps alive and
+                                        hands to cst_reduce_multi later.  Needs a plain epilogue (alpha 1, no bias / activation /
+                                        operand), an unbatched problem and a caller-owned workspace.  Ignored when the launch does
+                                        not split K (cst_gemm_splits tells). */
 } cst_gemm_desc;
 
 int64_t cst_gemm_workspace(const cst_gemm_desc* d);
@@ -168,6 +175,8 @@ int64_t cst_gemm_workspace(const cst_gemm_desc* d);
  * two-launch column sum behind it (the 16-wave / DMA configurations): a caller that can get the sums cheaper elsewhere — e.g. from
  * the dropout pass that has to read dY anyway, cst_dropout_colsum — asks first. */
 int cst_gemm_colsum_is_fused(const cst_gemm_desc* d);
+/* The number of K slices cst_gemm will use for this descriptor (1 = no split, no workspace slabs). */
+int cst_gemm_splits(const cst_gemm_desc* d);
 /* Persistent GEMM launches use (CUs - n) workgroups from now on (n < 0: query only); returns the previous value.  The data-parallel
  * reducer sets it while bucket all-reduces are in flight under the backward pass, so that the RCCL kernels on the side stream find free
  * CUs instead of waiting for a launch boundary (legacy_distributed_data_parallel.py has no overlap to protect).  Initial value:
@@ -333,6 +342,21 @@ typedef struct cst_transpose_item {
   int64_t tile0;
 } cst_transpose_item;
 int cst_transpose2d_multi(const cst_transpose_item* items_dev, int n, int64_t total_tiles, int dtype, cst_stream stream);
+/* The second stage of many fixed-order reductions in ONE launch (ABI 5).  The reference has no counterpart: its weight / bias /
+ * LayerNorm gradients come out of single ATen calls (F.linear / F.layer_norm backward at modules/transformer_layer.py:105-155,
+ * multihead_attention.py:326-361); here the weight-gradient GEMMs of the small layers split K, the LayerNorm backward reduces over
+ * row blocks, and each used to finish with a launch of its own.  cst_gemm (desc.defer_reduce) and cst_layernorm_bwd (dgamma = dbeta
+ * = NULL) leave their fp32 partials in the caller's workspace; this call finishes up to CST_REDUCE_MAX_ITEMS of them:
+ *   dst[i] = sum_{p < P} src[p * stride + i],  i < L      (L % 8 == 0, src / dst 16-byte aligned, stride % 4 == 0)
+ * in a fixed order (partials p = s, s + 8, ... per slice s, slices 0..7), dst in dst_dtype (fp32 or bf16).  `items` is a HOST array
+ * (it travels in the kernel arguments: no host-to-device copy, no synchronisation); block0 is filled in by the library. */
+#define CST_REDUCE_MAX_ITEMS 64
+typedef struct cst_reduce_item {
+  const float* src; void* dst;
+  int64_t stride, L;
+  int32_t P, dst_dtype, block0, pad_;
+} cst_reduce_item;
+int cst_reduce_multi(const cst_reduce_item* items, int n, cst_stream stream);
 /* y[r,:] = mask[r] ? 0 : x[r,:]   (x[padding_mask] = 0, wav2vec2.py:820-821) */
 int cst_mask_rows(const void* x, const uint8_t* mask, void* y, int64_t rows, int64_t cols, int dtype, cst_stream stream);
 

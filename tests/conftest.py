@@ -11,6 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# deferred reductions (kernels.DEFER): every deferred gradient holds NaN until the flush has written it, in every test of the suite
+# (and in the processes the tests spawn) — a gradient that is read too early cannot pass for a stale but plausible value
+os.environ.setdefault("CST_DEFER_POISON", "1")
 
 
 def pytest_configure(config):

@@ -1278,3 +1278,71 @@ def test_gemm_colsum_is_the_bias_gradient_next_to_dw(K, dt, n_out, k_in, tokens)
         k.gemm(dy, x, dw2, n_out, k_in, tokens, a_kmajor=0, b_kmajor=0, lda=n_out, ldb=k_in, ldc=k_in, split_k=-1, k_live=(stamps, epoch), colsum=db2)
         check(db2, ref, dt, "db with stamps", scale=float(ref.abs().max()))
         check(dw2, dy.float().t() @ x.float(), dt, "dW with stamps")
+
+
+def test_reduce_multi_finishes_many_reductions_in_one_launch(K):
+    """cst_reduce_multi: dst[i] = sum_p src[p * stride + i] for a table of items of different lengths, partial counts, strides and
+    output types in ONE launch (more than 64 items: two launches), against fp64 sums; run twice: the same bits."""
+    k, L = K
+    torch.manual_seed(3)
+    specs = [(768, 1024, 2 * 768, torch.bfloat16), (768, 1024, 2 * 768, torch.bfloat16), (512 * 512, 15, 512 * 512, torch.bfloat16),
+             (512, 15, 512, torch.bfloat16), (8, 1, 8, torch.float32), (2048 * 512, 4, 2048 * 512, torch.float32), (1000 * 8, 7, 9000, torch.bfloat16)]
+    specs = specs + [(64 * (i + 1), 3 + i % 9, 64 * (i + 1) + 8, torch.bfloat16) for i in range(70)]
+    srcs, dsts, items = [], [], []
+    for Lr, P, stride, dt in specs:
+        src = torch.randn(P * stride + 64, device="cuda")
+        dst = torch.full((Lr,), float("nan"), dtype=dt, device="cuda")
+        srcs.append(src); dsts.append(dst)
+        items.append((src.data_ptr(), dst.data_ptr(), stride, Lr, P, L.dtype_code(dt)))
+    k.reduce_multi(items)
+    first = [d.clone() for d in dsts]
+    k.reduce_multi(items)
+    for (Lr, P, stride, dt), src, dst, f in zip(specs, srcs, dsts, first):
+        ref = torch.as_strided(src, (P, Lr), (stride, 1)).double().sum(0)
+        check(dst, ref.float(), dt, "reduce_multi L=%d P=%d" % (Lr, P), scale=float(ref.abs().max()))
+        assert torch.equal(dst, f)
+
+
+def test_deferred_reductions_give_the_gradients_of_the_immediate_route():
+    """kernels.DEFER (split-K slabs of the small weight-gradient GEMMs + their bias-gradient slices + LayerNorm dgamma / dbeta
+    partials finished by one cst_reduce_multi launch at the end of the backward pass): the same gradients as the launch-each route to
+    fp32 summation order, every deferred destination written (the suite runs with CST_DEFER_POISON=1: an unwritten one is NaN),
+    nothing deferred for a parameter that is shared, has a gradient already, or outside the mode."""
+    from importlib import import_module
+    load_pkg()
+    CF = import_module("chimera-st_amd.functional")
+    Kk = import_module("chimera-st_amd.kernels")
+    torch.manual_seed(0)
+    dt = torch.bfloat16
+    lin1, lin2 = torch.nn.Linear(512, 2048).cuda().to(dt), torch.nn.Linear(2048, 512).cuda().to(dt)
+    ln = torch.nn.LayerNorm(512).cuda().to(dt)
+    proj = torch.nn.Linear(512, 512).cuda().to(dt)
+    params = list(lin1.parameters()) + list(lin2.parameters()) + list(ln.parameters()) + list(proj.parameters())
+    x = torch.randn(4064, 512, device="cuda").to(dt)
+
+    def run(defer):
+        for p in params:
+            p.grad = None
+        with Kk.deferred_reductions(defer):
+            h = CF.layer_norm(x, ln.weight, ln.bias)
+            y = CF.ffn(h, lin1.weight, lin1.bias, lin2.weight, lin2.bias, "relu", resid=h)
+            z = CF.linear(y, proj.weight, proj.bias)
+            n0 = Kk.DEFER.flushes
+            z.float().pow(2).sum().backward()
+            pending = len(Kk.DEFER.items)
+        return [p.grad.clone() for p in params], pending, Kk.DEFER.flushes - n0
+
+    g0, pend0, fl0 = run(False)
+    g1, pend1, fl1 = run(True)
+    assert pend0 == 0 and fl0 == 0 and pend1 >= 6 and fl1 == 1  # 3 split weight gradients (+ bias slices) + dgamma / dbeta, one flush
+    for a, b, p in zip(g0, g1, params):
+        assert torch.isfinite(b.float()).all()
+        check(b, a.float(), dt, "deferred gradient %s" % (tuple(p.shape),), scale=float(a.float().abs().max()))
+    # a parameter that already holds a gradient (a later micro-batch) or is marked shared takes the immediate route
+    proj.weight._cst_shared = True
+    with Kk.deferred_reductions(True):
+        h = CF.layer_norm(x, ln.weight, ln.bias)  # ln.weight.grad is not None: accumulation
+        z = CF.linear(h, proj.weight, proj.bias)
+        z.float().pow(2).sum().backward()
+        assert len(Kk.DEFER.items) == 0
+    assert all(torch.isfinite(p.grad.float()).all() for p in params)
