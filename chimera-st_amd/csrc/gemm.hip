@@ -1077,9 +1077,9 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
   if (rc != CST_OK) return rc;
   if (p.splits > 1 && d->defer_reduce) {
     // the slabs stay in the caller's workspace for cst_reduce_multi: only epilogues that are a plain conversion can be finished there
-    CST_REQUIRE(nbatch == 1 && d->alpha == 1.0f && !d->bias && !d->act && !d->dact && !d->aux_out && !d->resid && d->drop_p == 0.0f && d->ldc == d->N &&
+    CST_REQUIRE((nbatch == 1 || !d->colsum) && d->alpha == 1.0f && !d->bias && !d->act && !d->dact && !d->aux_out && !d->resid && d->drop_p == 0.0f && d->ldc == d->N &&
                     d->N % 8 == 0 && (!d->colsum || cs_fused),
-                "cst_gemm: defer_reduce needs a plain epilogue, a dense C and an unbatched problem");
+                "cst_gemm: defer_reduce needs a plain epilogue and a dense C (batched: no colsum; the slabs are [batch][split][M][N])");
     return rc;
   }
   if (p.splits > 1) {

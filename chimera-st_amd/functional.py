@@ -527,6 +527,48 @@ class _AttnFn(torch.autograd.Function):
         return dq, dk, dv, None, None, None, None, None, None, None, None, None
 
 
+class _AttnKVFn(torch.autograd.Function):
+    """Attention whose keys and values are the two channel halves of ONE projection kv [B, Tk, 2C] (cross-attention / memory
+    attention: k_proj and v_proj read the same rows, so they run as one [2C, C] GEMM).  The backward writes dk | dv into one buffer:
+    the projection's dX and dW are single GEMMs and the key/value rows receive a single gradient (no autograd sum of two)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, kpm, kvl, H, scale, drop_p, drop_key):
+        C = kv.shape[-1] // 2
+        D = C // H
+        k, v = kv[..., :C], kv[..., C:]
+        o, lse = K.attn_fwd(q, k, v, H, D, kpm, False, scale, "bt", "bt", drop_p, drop_key, kvl)
+        ctx.save_for_backward(q, kv, o, lse, kpm, kvl)
+        ctx.cfg = (H, D, C, scale, drop_p, drop_key)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, kv, o, lse, kpm, kvl = ctx.saved_tensors
+        H, D, C, scale, drop_p, drop_key = ctx.cfg
+        if do.stride() != o.stride():
+            tmp = torch.empty_like(o)
+            tmp.copy_(do)
+            do = tmp
+        k, v = kv[..., :C], kv[..., C:]
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        delta = torch.empty_like(lse)
+        d = K.attn_desc(q, k, v, o, lse, H, D, kpm, False, scale, "bt", "bt", drop_p, drop_key, kvl)
+        K.attn_bwd_fill(d, do, dq, dkv[..., :C], dkv[..., C:], delta, D, "bt", "bt")
+        K.attn_bwd_desc(d)
+        return dq, dkv, None, None, None, None, None, None
+
+
+def attention_kv(q, kv, num_heads, key_padding_mask=None, scale=None, dropout_p=0.0):
+    """q [B,Tq,C], kv [B,Tk,2C] (k | v along channels, contiguous) -> [B,Tq,C]; non-causal."""
+    C = q.shape[-1]
+    if scale is None:
+        scale = (C // num_heads) ** -0.5
+    key_padding_mask, kv_len = _mask_and_len(key_padding_mask)
+    assert q.stride(-1) == 1 and kv.is_contiguous() and kv.shape[-1] == 2 * C
+    return _AttnKVFn.apply(q, kv, key_padding_mask, kv_len, num_heads, float(scale), *_drop_args(dropout_p))
+
+
 def _drop_args(dropout_p):
     """(p, key) of one dropout site: a fresh key of the process-wide stream when p > 0."""
     if dropout_p and dropout_p > 0.0:
@@ -609,33 +651,35 @@ def attention_packed(qkv, num_heads, key_padding_mask=None, causal=False, scale=
 # q | k | v parameters as one packed operand
 # ------------------------------------------------------------------------------------------------
 class _StackedRowsFn(torch.autograd.Function):
-    """Three parameters that sit back to back in memory (optim.FlatParamBuffers lays the q, k, v projections of a self-attention
-    module out that way) seen as ONE [3C, ...] tensor: a view, no copy.  backward hands each parameter its row block of the packed
-    gradient (views of the one tensor the dW GEMM wrote)."""
+    """Parameters that sit back to back in memory (optim.FlatParamBuffers lays the q, k, v projections of an attention module out
+    that way) seen as ONE [n C, ...] tensor: a view, no copy.  backward hands each parameter its row block of the packed gradient
+    (views of the one tensor the dW GEMM wrote)."""
 
     @staticmethod
-    def forward(ctx, a, b, c):
-        ctx.rows = a.shape[0]
-        return torch.as_strided(a, (3 * a.shape[0],) + tuple(a.shape[1:]), a.stride(), a.storage_offset())
+    def forward(ctx, *ts):
+        a = ts[0]
+        ctx.rows, ctx.n = a.shape[0], len(ts)
+        return torch.as_strided(a, (len(ts) * a.shape[0],) + tuple(a.shape[1:]), a.stride(), a.storage_offset())
 
     @staticmethod
     def backward(ctx, g):
         r = ctx.rows
-        return g[:r], g[r:2 * r], g[2 * r:]
+        return tuple(g[i * r:(i + 1) * r] for i in range(ctx.n))
 
 
-def stacked_rows(a, b, c):
-    """cat((a, b, c), 0) for three equal-shaped parameters; free when they are adjacent in memory."""
+def stacked_rows(*ts):
+    """cat(ts, 0) for two or three equal-shaped parameters (q | k | v, or k | v); free when they are adjacent in memory."""
+    a = ts[0]
     n = a.numel() * a.element_size()
-    if (not _os.environ.get("CST_NO_QKV_VIEW") and a.shape == b.shape == c.shape and a.is_contiguous() and b.is_contiguous() and c.is_contiguous()
-            and a.data_ptr() + n == b.data_ptr() and b.data_ptr() + n == c.data_ptr()
-            and a.untyped_storage().data_ptr() == c.untyped_storage().data_ptr()):
+    if (not _os.environ.get("CST_NO_QKV_VIEW") and all(t.shape == a.shape and t.is_contiguous() for t in ts)
+            and all(ts[i].data_ptr() + n == ts[i + 1].data_ptr() for i in range(len(ts) - 1))
+            and a.untyped_storage().data_ptr() == ts[-1].untyped_storage().data_ptr()):
         K.STATS["qkv_view"] = K.STATS.get("qkv_view", 0) + 1
-        out = _StackedRowsFn.apply(a, b, c)
-        out._cst_parts = (a.detach(), b.detach(), c.detach())  # version counters of all three (WEIGHT_TRANSPOSES, _wversion)
-        out._cst_parts_params = (a, b, c)                      # ... and the parameters themselves (optim.grad_slot)
+        out = _StackedRowsFn.apply(*ts)
+        out._cst_parts = tuple(t.detach() for t in ts)  # version counters of all of them (WEIGHT_TRANSPOSES, _wversion)
+        out._cst_parts_params = tuple(ts)               # ... and the parameters themselves (optim.grad_slot)
         return out
-    return torch.cat((a, b, c), 0)
+    return torch.cat(ts, 0)
 
 
 # ------------------------------------------------------------------------------------------------

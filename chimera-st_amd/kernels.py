@@ -31,7 +31,7 @@ class _Deferred:
     CST_DEFER_POISON=1 (the test suite sets it) fills every deferred destination with NaN until the flush writes it: a read that
     comes too early cannot go unnoticed."""
 
-    MAX_BYTES = 16 << 20  # slabs above this stay with their own reduce launch (they would have to be re-read cold from HBM)
+    MAX_BYTES = 32 << 20  # slabs above this stay with their own reduce launch (they would have to be re-read cold from HBM)
 
     def __init__(self):
         self.on, self.items, self.keep, self.flushes = 0, [], [], 0

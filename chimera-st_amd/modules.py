@@ -305,6 +305,20 @@ class MultiheadAttention(FairseqIncrementalState, nn.Module):
             return to_time_major_view(out), None
         q = self.q_proj(qb)
         k = v = None
+        if (saved_state is None and not self.self_attention and key is not None and value is key and self.kdim == self.vdim
+                and (key_padding_mask is None or key_padding_mask.dim() != 0)):
+            # training-time cross-attention: k_proj and v_proj read the same rows — ONE [2C, C] projection (a view of the flat
+            # parameter buffer when the trainer laid k | v out back to back), the kernel reads k | v as channel halves and the
+            # backward writes dk | dv into one buffer (one dX GEMM, one dW GEMM, one gradient for the encoder output per layer)
+            wkv = CF.stacked_rows(self.k_proj.weight, self.v_proj.weight)
+            bkv = CF.stacked_rows(self.k_proj.bias, self.v_proj.bias) if self.k_proj.bias is not None else None
+            kv = CF.linear(to_batch_major(key), wkv, bkv)
+            if key_padding_mask is not None:
+                assert key_padding_mask.size(0) == bsz and key_padding_mask.size(1) == kv.size(1)
+            attn = CF.attention_kv(q, kv, self.num_heads, key_padding_mask, self.scaling, dropout_p=attn_p)
+            assert not causal
+            out = self.out_proj(attn, resid=to_batch_major(resid) if resid is not None else None, dropout_p=out_dropout_p)
+            return to_time_major_view(out), None
         if self.self_attention:
             k, v = self.k_proj(qb), self.v_proj(qb)
         elif key is not None:
@@ -464,9 +478,12 @@ class TransformerEncoderLayer(nn.Module):
         """self_attn's own projections with separate query / key-value rows (memory layers)."""
         sa = self.self_attn
         qb, kb = to_batch_major(q_in), to_batch_major(kv_in)
-        q, k, v = sa.q_proj(qb), sa.k_proj(kb), sa.v_proj(kb)
         attn_p = sa.dropout_module.p if (self.training and sa.dropout_module.p > 0) else 0.0
-        attn = CF.attention(q, k, v, sa.num_heads, key_padding_mask, False, sa.scaling, "bt", "bt", dropout_p=attn_p)
+        q = sa.q_proj(qb)
+        # k | v as ONE projection of the key/value rows (adjacent in the flat parameter buffer behind q: a view)
+        wkv = CF.stacked_rows(sa.k_proj.weight, sa.v_proj.weight)
+        bkv = CF.stacked_rows(sa.k_proj.bias, sa.v_proj.bias) if sa.k_proj.bias is not None else None
+        attn = CF.attention_kv(q, CF.linear(kb, wkv, bkv), sa.num_heads, key_padding_mask, sa.scaling, dropout_p=attn_p)
         out = sa.out_proj(attn, resid=to_batch_major(resid) if resid is not None else None, dropout_p=out_dropout_p)
         return to_time_major_view(out), None
 

@@ -131,13 +131,21 @@ def grad_slot(w):
 
 
 def qkv_groups(model):
-    """Adjacency groups for FlatParamBuffers: the q, k, v projection weights (and biases) of every self-attention module."""
+    """Adjacency groups for FlatParamBuffers: the q, k, v projection weights (and biases) of every self-attention module, the k, v
+    projections of every encoder-decoder attention module (they read the same rows: one [2C, C] GEMM, functional.attention_kv)."""
     groups = []
     for m in model.modules():
-        if getattr(m, "self_attention", False) and all(hasattr(m, n) for n in ("q_proj", "k_proj", "v_proj")):
-            groups.append([m.q_proj.weight, m.k_proj.weight, m.v_proj.weight])
-            if m.q_proj.bias is not None:
-                groups.append([m.q_proj.bias, m.k_proj.bias, m.v_proj.bias])
+        if not all(hasattr(m, n) for n in ("q_proj", "k_proj", "v_proj")):
+            continue
+        if getattr(m, "self_attention", False):
+            names = ("q_proj", "k_proj", "v_proj")
+        elif getattr(m, "encoder_decoder_attention", False) and m.k_proj.weight.shape == m.v_proj.weight.shape:
+            names = ("k_proj", "v_proj")
+        else:
+            continue
+        groups.append([getattr(m, n).weight for n in names])
+        if m.q_proj.bias is not None:
+            groups.append([getattr(m, n).bias for n in names])
     return groups
 
 

@@ -42,7 +42,8 @@ class Trainer:
         for _, p in model.named_parameters(remove_duplicate=False):
             seen[id(p)] = seen.get(id(p), 0) + 1
         for p in model.parameters():
-            p._cst_shared = seen.get(id(p), 1) > 1
+            if seen.get(id(p), 1) > 1:
+                p._cst_shared = True  # (modules mark parameters they apply twice in one pass themselves: the memory layers' LayerNorm)
         self.optimizer.defer_reductions = bool(getattr(self.criterion, "single_pass", False) and getattr(model, "single_use_parameters", False))
         self.num_updates = 0
         self.dtype = dtype

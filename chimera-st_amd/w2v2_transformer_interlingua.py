@@ -105,6 +105,12 @@ class S2T_W2V2_TransformerInterlinguaEncoder(S2T_W2V2_TransformerEncoder):
         assert args.interlingua_layers >= 1
         self.interlingua_embedding = Embedding(args.interlingua_length, args.encoder_embed_dim, 0)
         self.interlingua_layers = nn.ModuleList([TransformerEncoderLayer(args) for _ in range(args.interlingua_layers)])
+        for layer in self.interlingua_layers:
+            # a memory layer normalises BOTH its query rows (the memory) and its key/value rows (h_enc) with self_attn_layer_norm:
+            # that LayerNorm receives two gradients per backward pass, which autograd adds as soon as the second exists — its
+            # reductions must not be deferred (kernels.DEFER, functional._may_defer)
+            for p in layer.self_attn_layer_norm.parameters():
+                p._cst_shared = True
         self.modal_embedding = None
 
     def upgrade_state_dict_named(self, state_dict, name):

@@ -166,7 +166,8 @@ typedef struct {
   int defer_reduce;                  /* split-K launches only (ABI 5): 1 = do not launch the reduce; the fp32 slabs [split][M][N] (and the
                                         colsum slices [split][M] behind them) stay in `workspace`, which the caller keeps alive and
                                         hands to cst_reduce_multi later.  Needs a plain epilogue (alpha 1, no bias / activation /
-                                        operand), an unbatched problem and a caller-owned workspace.  Ignored when the launch does
+                                        operand) and a caller-owned workspace; batched launches (slabs [batch][split][M][N], no colsum)
+                                        let the caller sum over the batch in the same pass.  Ignored when the launch does
                                         not split K (cst_gemm_splits tells). */
 } cst_gemm_desc;
 

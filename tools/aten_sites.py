@@ -27,6 +27,34 @@ for _ in range(3):
 torch.cuda.synchronize()
 from torch.profiler import ProfilerActivity, profile  # noqa: E402
 
+import traceback  # noqa: E402
+
+# (torch.profiler's with_stack comes back empty on this build: take the Python stack ourselves, per dispatched ATen op)
+from torch.utils._python_dispatch import TorchDispatchMode  # noqa: E402
+
+py_sites = collections.Counter()
+
+
+class _Sites(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = str(func).replace("aten.", "")
+        fr = [f for f in traceback.extract_stack() if "chimera-st_amd/" in f.filename]
+        where = "%s:%d" % (fr[-1].filename.split("chimera-st_amd/")[-1], fr[-1].lineno) if fr else "?"
+        if any(torch.is_tensor(a) and a.is_cuda for a in list(args) + list((kwargs or {}).values())) or "empty" in name or "zeros" in name:
+            py_sites[(name, where)] += 1
+        return func(*args, **(kwargs or {}))
+
+
+with _Sites():
+    trainer.train_step([sample])
+torch.cuda.synchronize()
+print("ATen ops dispatched on device tensors in one update, by call site (views and metadata ops included):")
+skip = ("view", "transpose", "permute", "as_strided", "slice", "select", "expand", "unsqueeze", "squeeze", "detach", "alias", "reshape", "t.default", "empty", "_unsafe_view", "unbind", "split", "narrow", "size", "stride", "is_")
+for (name, where), n in sorted(py_sites.items(), key=lambda kv: -kv[1]):
+    if not any(k in name for k in skip):
+        print("%5d  %-40s %s" % (n, name, where))
+print()
+
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     trainer.train_step([sample])
     torch.cuda.synchronize()
