@@ -676,15 +676,18 @@ extern "C" int cst_transpose2d_multi(const cst_transpose_item* items_dev, int n,
 // LayerNorm dgamma / dbeta row-block partials) with a tiny launch each; their results are only read when the gradients are
 // gathered, so the first stages leave their partials in place and ONE launch finishes them all (functional / kernels.py: deferred
 // reductions, flushed before anything reads a gradient).
-// Item: dst[i] = sum_{p < P} src[p * stride + i], i < L (L % 8 == 0), fp32 partials, dst in fp32 or bf16.  A block of 256 threads
-// owns 256 consecutive elements: 32 lanes x 8 elements, P dealt to 8 slices (slice s adds p = s, s + 8, ... in order, the slices
-// are added 0..7 through LDS): a fixed order whatever else shares the launch.
+// Item: dst[i] = sum_{p < P} src[p * stride + i], i < L (L % 8 == 0), fp32 partials, dst in fp32 or bf16 — in EXACTLY the order of
+// the launch-each kernel it stands in for, so that a gradient has the same bits whichever route produced it (an accumulated
+// update mixes the routes: its first micro-batch may be deferred, the later ones add into an existing gradient and are not):
+//   order 0  p = 0, 1, 2, ... one after the other                 (splitk_reduce_kernel of gemm.hip; its bias-gradient slices)
+//   order 1  64 interleaved chains p = g, g + 64, ..., then the chains 0..63 one after the other   (ln_bwd_reduce_kernel)
+// Blocks of 1024 threads: order 0 — 8 consecutive elements per thread; order 1 — 16 columns x 64 chains, as layernorm.hip lays it out.
 // ---------------------------------------------------------------------------------------------------------------------------------
 namespace {
 struct ReduceTable { cst_reduce_item it[CST_REDUCE_MAX_ITEMS]; int n; };
 
-__global__ __launch_bounds__(256) void reduce_multi_kernel(ReduceTable t) {
-  __shared__ float part[8][32][9];
+__global__ __launch_bounds__(1024) void reduce_multi_kernel(ReduceTable t) {
+  __shared__ float ra[64][17];
   const int b = blockIdx.x;
   int lo = 0, hi = t.n - 1;
   while (lo < hi) {  // last item whose first block is <= b (uniform)
@@ -692,40 +695,46 @@ __global__ __launch_bounds__(256) void reduce_multi_kernel(ReduceTable t) {
     if (t.it[mid].block0 <= b) lo = mid; else hi = mid - 1;
   }
   const cst_reduce_item& it = t.it[lo];
-  const int lane = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int64_t i0 = ((int64_t)(b - it.block0) * 32 + lane) * 8;
-  float a[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-  if (i0 < it.L) {
+  const int64_t blk = b - it.block0;
+  if (it.order == 0) {
+    const int64_t i0 = (blk * 1024 + threadIdx.x) * 8;
+    if (i0 >= it.L) return;
     const float* src = it.src + i0;
-    int p = sl;
-    for (; p + 24 < it.P; p += 32) {  // four partials of this slice in flight
-      f32x4 v[4][2];
+    float v[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    int sp = 0;
+    for (; sp + 4 <= it.P; sp += 4) {  // four partials in flight, added in order (the loop of splitk_reduce_kernel)
+      f32x4 a[4][2];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        v[u][0] = *reinterpret_cast<const f32x4*>(src + (int64_t)(p + 8 * u) * it.stride);
-        v[u][1] = *reinterpret_cast<const f32x4*>(src + (int64_t)(p + 8 * u) * it.stride + 4);
+        a[u][0] = *reinterpret_cast<const f32x4*>(src + (int64_t)(sp + u) * it.stride);
+        a[u][1] = *reinterpret_cast<const f32x4*>(src + (int64_t)(sp + u) * it.stride + 4);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { a[e] += v[u][0][e]; a[4 + e] += v[u][1][e]; }
+        for (int e = 0; e < 4; ++e) { v[e] += a[u][0][e]; v[4 + e] += a[u][1][e]; }
     }
-    for (; p < it.P; p += 8) {
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + (int64_t)p * it.stride), v1 = *reinterpret_cast<const f32x4*>(src + (int64_t)p * it.stride + 4);
+    for (; sp < it.P; ++sp) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(src + (int64_t)sp * it.stride), a1 = *reinterpret_cast<const f32x4*>(src + (int64_t)sp * it.stride + 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { a[e] += v0[e]; a[4 + e] += v1[e]; }
+      for (int e = 0; e < 4; ++e) { v[e] += a0[e]; v[4 + e] += a1[e]; }
     }
+    if (it.dst_dtype == CST_BF16) store8((bf16_t*)it.dst + i0, v);
+    else store8((float*)it.dst + i0, v);
+    return;
   }
-#pragma unroll
-  for (int e = 0; e < 8; ++e) part[sl][lane][e] = a[e];
+  const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int64_t c = blk * 16 + cl;
+  float a = 0.0f;
+  if (c < it.L)
+    for (int i = g; i < it.P; i += 64) a += it.src[(int64_t)i * it.stride + c];
+  ra[g][cl] = a;
   __syncthreads();
-  if (sl == 0 && i0 < it.L) {
-#pragma unroll
-    for (int s = 1; s < 8; ++s)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) a[e] += part[s][lane][e];
-    if (it.dst_dtype == CST_BF16) store8((bf16_t*)it.dst + i0, a);
-    else store8((float*)it.dst + i0, a);
+  if (g == 0 && c < it.L) {
+#pragma unroll 8
+    for (int k = 1; k < 64; ++k) a += ra[k][cl];
+    if (it.dst_dtype == CST_BF16) DT<bf16_t>::st((bf16_t*)it.dst + c, a);
+    else ((float*)it.dst)[c] = a;
   }
 }
 }  // namespace
@@ -739,17 +748,17 @@ extern "C" int cst_reduce_multi(const cst_reduce_item* items, int n, cst_stream 
     const cst_reduce_item& it = items[i];
     CST_REQUIRE(it.src && it.dst && it.L > 0 && it.L % 8 == 0 && it.P > 0 && it.stride % 4 == 0 && ((uintptr_t)it.src % 16) == 0 && ((uintptr_t)it.dst % 16) == 0,
                 "cst_reduce_multi: item %d: L, stride, alignment", i);
-    CST_REQUIRE(it.dst_dtype == CST_F32 || it.dst_dtype == CST_BF16, "cst_reduce_multi: item %d: bad dst_dtype", i);
+    CST_REQUIRE((it.dst_dtype == CST_F32 || it.dst_dtype == CST_BF16) && (it.order == 0 || it.order == 1), "cst_reduce_multi: item %d: bad dst_dtype / order", i);
     t.it[i] = it;
     t.it[i].block0 = (int32_t)blocks;
-    blocks += cst_ceil_div(it.L, 256);
+    blocks += it.order == 0 ? cst_ceil_div(it.L, 8192) : cst_ceil_div(it.L, 16);
     bytes += (double)it.L * ((double)it.P * 4.0 + cst_dtype_size(it.dst_dtype));
   }
   CST_REQUIRE(blocks < (1ll << 31), "cst_reduce_multi: too many blocks");
   t.n = n;
   hipStream_t s = (hipStream_t)stream;
   CstProfScope prof(CST_K_ELEMENTWISE, s, 0.0, bytes);
-  hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, s, t);
+  hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)blocks), dim3(1024), 0, s, t);
   return cst_check_launch("cst_reduce_multi");
 }
 

@@ -262,8 +262,12 @@ def _linear_backward(ctx, dy, dxp):
             dw = torch.empty(Np, Kd, dtype=w.dtype, device=w.device)
         if db_in_dw:
             db = torch.empty(Np, dtype=w.dtype, device=w.device)
-        K.gemm(dz, x2, dw, Np, Kd, M, a_kmajor=0, b_kmajor=0, lda=Np, ldb=Kd, ldc=Kd, split_k=-1, k_live=live, colsum=db,
-               defer=Np == N and _may_defer(w))
+        may = Np == N and _may_defer(w)
+        # (a small layer's weight gradient runs on the side stream, off the dX chain — kernels.side_gemm; not when dz IS the incoming
+        #  gradient that also travels on as the residual gradient: something upstream might add into it in place)
+        big = not may or not K.dw_colsum_is_fused(Np, Kd, M, w.dtype) or (dz.data_ptr() == dy.data_ptr() and ctx.has_resid)
+        K.side_gemm(big, (dz, x2, live[0] if live is not None else None), dz, x2, dw, Np, Kd, M, a_kmajor=0, b_kmajor=0, lda=Np, ldb=Kd, ldc=Kd,
+                    split_k=-1, k_live=live, colsum=db, defer=may)
         dw = dw[:N]
         if db is not None:
             db = db[:N]
@@ -361,8 +365,10 @@ class _FFNFn(torch.autograd.Function):
                 dw2 = torch.empty(dout, F_, dtype=w2.dtype, device=w2.device)
             if db2_in_dw:
                 db2 = torch.empty(dout, dtype=w2.dtype, device=w2.device)
-            K.gemm(dy2, h, dw2, dout, F_, M, a_kmajor=0, b_kmajor=0, lda=dout, ldb=F_, ldc=F_, split_k=-1, k_live=live, colsum=db2,
-                   defer=_may_defer(w2))
+            may2 = _may_defer(w2)
+            big2 = not may2 or not K.dw_colsum_is_fused(dout, F_, M, w2.dtype) or (dy2.data_ptr() == dy.data_ptr() and has_res)
+            K.side_gemm(big2, (dy2, h, live[0] if live is not None else None), dy2, h, dw2, dout, F_, M, a_kmajor=0, b_kmajor=0, lda=dout, ldb=F_,
+                        ldc=F_, split_k=-1, k_live=live, colsum=db2, defer=may2)
         if has_b2 and ctx.needs_input_grad[4] and db2 is None:
             db2 = db2_fused if db2_fused is not None else K.colsum(dy2, w2.dtype, live)
         if ctx.needs_input_grad[0]:
@@ -380,8 +386,10 @@ class _FFNFn(torch.autograd.Function):
                 dw1 = torch.empty(F_, d, dtype=w1.dtype, device=w1.device)
             if db1_in_dw:
                 db1 = torch.empty(F_, dtype=w1.dtype, device=w1.device)
-            K.gemm(dz1, x2, dw1, F_, d, M, a_kmajor=0, b_kmajor=0, lda=F_, ldb=d, ldc=d, split_k=-1, k_live=live, colsum=db1,
-                   defer=_may_defer(w1))
+            may1 = _may_defer(w1)
+            big1 = not may1 or not K.dw_colsum_is_fused(F_, d, M, w1.dtype)
+            K.side_gemm(big1, (dz1, x2, live[0] if live is not None else None), dz1, x2, dw1, F_, d, M, a_kmajor=0, b_kmajor=0, lda=F_, ldb=d,
+                        ldc=d, split_k=-1, k_live=live, colsum=db1, defer=may1)
         if has_b1 and ctx.needs_input_grad[2] and db1 is None:
             db1 = K.colsum(dz1, w1.dtype, live)
         dres = dy if has_res and ctx.needs_input_grad[5] and not (ctx.res_is_x and ctx.needs_input_grad[0]) else None

@@ -35,18 +35,28 @@ class _Deferred:
 
     def __init__(self):
         self.on, self.items, self.keep, self.flushes = 0, [], [], 0
+        self.main = None   # the stream the flush runs on (set when the mode is entered)
+        self.side = None   # side stream of the small weight-gradient GEMMs (side_gemm), created on first use
+        self.side_used = False
 
-    def push(self, src_ptr, dst, stride, Lr, P, keep):
+    def push(self, src_ptr, dst, stride, Lr, P, keep, order=0):
         if os.environ.get("CST_DEFER_POISON"):
             dst.fill_(float("nan"))
-        self.items.append((src_ptr, dst.data_ptr(), stride, Lr, P, L.dtype_code(dst.dtype)))
+        if self.main is not None and torch.is_tensor(keep) and torch.cuda.current_stream() != self.main:
+            keep.record_stream(self.main)  # allocated on the side stream's pool, read by the flush on the main stream
+        self.items.append((src_ptr, dst.data_ptr(), stride, Lr, P, L.dtype_code(dst.dtype), order))
         # (an ALIAS of dst keeps its storage alive: holding dst itself would raise its reference count, and AccumulateGrad only adopts
         #  a gradient tensor nobody else holds — otherwise it clones it on the spot, i.e. reads it before the flush has written it)
         self.keep.append((keep, dst.detach()))
-        if len(self.items) >= 64:
-            self.flush()
+
+    def join(self):
+        """The main stream waits for everything the side stream has been given (before anything reads a gradient)."""
+        if self.side_used:
+            torch.cuda.current_stream().wait_stream(self.side)
+            self.side_used = False
 
     def flush(self):
+        self.join()
         if self.items:
             reduce_multi(self.items)
             self.flushes += 1
@@ -57,13 +67,14 @@ DEFER = _Deferred()
 
 
 def reduce_multi(items):
-    """items: [(src_ptr, dst_ptr, stride, L, P, dst_dtype_code)] -> dst[i] = sum_p src[p * stride + i]: ONE launch (include/cst.h)."""
+    """items: [(src_ptr, dst_ptr, stride, L, P, dst_dtype_code, order)] -> dst[i] = sum_p src[p * stride + i]: ONE launch (include/cst.h:
+    order 0 = the split-K reduce's summation order, 1 = the LayerNorm second stage's)."""
     lib = L.load()
     for at in range(0, len(items), 64):
         chunk = items[at:at + 64]
         arr = (L.ReduceItem * len(chunk))()
-        for a, (src, dst, stride, Lr, P, dt) in zip(arr, chunk):
-            a.src, a.dst, a.stride, a.L, a.P, a.dst_dtype = src, dst, stride, Lr, P, dt
+        for a, (src, dst, stride, Lr, P, dt, order) in zip(arr, chunk):
+            a.src, a.dst, a.stride, a.L, a.P, a.dst_dtype, a.order = src, dst, stride, Lr, P, dt, order
         L.check(lib.cst_reduce_multi(arr, len(chunk), L.stream_ptr()), "cst_reduce_multi")
 
 
@@ -74,7 +85,9 @@ class deferred_reductions:
         self.enabled = bool(enabled) and not os.environ.get("CST_NO_DEFER")
 
     def __enter__(self):
-        DEFER.on += 1 if self.enabled else 0
+        if self.enabled:
+            DEFER.on += 1
+            DEFER.main = torch.cuda.current_stream()
         return self
 
     def __exit__(self, *exc):
@@ -83,6 +96,30 @@ class deferred_reductions:
             if DEFER.on == 0:
                 DEFER.flush()
         return False
+
+
+def side_gemm(big, reads, *args, **kw):
+    """A weight-gradient GEMM of a SMALL layer (`big` False: the 4-wave configurations, a few hundred workgroups that leave most
+    of every CU free) on a side stream, next to the dX chain of the backward pass it belongs to: the backward of the 512-wide
+    encoder / decoder layers is a chain of 10-50 us kernels none of which fills the chip, and the weight gradients are off its
+    critical path — nothing reads them before the update gathers them.  Only inside the trainer's backward context (DEFER.on: the
+    same guarantee — the result is a parameter gradient nobody reads yet), joined before the deferred reductions are flushed.
+    `reads`: the tensors the launch reads; they are handed to the side stream's allocator bookkeeping (record_stream) because
+    autograd frees them as soon as the backward function returns."""
+    if big or not DEFER.on or DEFER.main is None or os.environ.get("CST_NO_SIDE_STREAM") or torch.cuda.current_stream() != DEFER.main:
+        return gemm(*args, **kw)
+    if DEFER.side is None:
+        DEFER.side = torch.cuda.Stream()
+    side = DEFER.side
+    side.wait_stream(DEFER.main)  # the operands are the latest things queued on the main stream
+    with torch.cuda.stream(side):
+        out = gemm(*args, **kw)
+    for t in reads:
+        if t is not None:
+            t.record_stream(side)
+    DEFER.side_used = True
+    STATS["side_gemm"] = STATS.get("side_gemm", 0) + 1
+    return out
 
 
 def _2d(t):
@@ -195,7 +232,7 @@ def gemm(A, B, C, M, N, K, *, a_kmajor, b_kmajor, lda, ldb, ldc, bias=None, bias
         if defer and DEFER.on:
             DEFER.push(*item)
         else:
-            reduce_multi([(item[0], item[1].data_ptr(), item[2], item[3], item[4], L.dtype_code(reduce_to.dtype))])
+            reduce_multi([(item[0], item[1].data_ptr(), item[2], item[3], item[4], L.dtype_code(reduce_to.dtype), 0)])
     elif deferred:
         DEFER.push(ws.data_ptr(), C, M * N, M * N, splits, ws)
         if colsum is not None:
@@ -274,8 +311,8 @@ def layernorm_bwd(dy, s, gamma, mean, rstd, dres=None, grad_dtype=torch.float32,
                 "cst_layernorm_bwd")
     if defer:  # partials: fp32 [blocks][2][cols]
         blocks = wbytes // (8 * cols)
-        DEFER.push(ws.data_ptr(), dg, 2 * cols, cols, blocks, ws)
-        DEFER.push(ws.data_ptr() + 4 * cols, db, 2 * cols, cols, blocks, ws)
+        DEFER.push(ws.data_ptr(), dg, 2 * cols, cols, blocks, ws, order=1)
+        DEFER.push(ws.data_ptr() + 4 * cols, db, 2 * cols, cols, blocks, ws, order=1)
     return out
 
 

@@ -50,7 +50,7 @@ class GemmDesc(ctypes.Structure):
 
 class ReduceItem(ctypes.Structure):
     _fields_ = [("src", c_p), ("dst", c_p), ("stride", c_i64), ("L", c_i64), ("P", ctypes.c_int32), ("dst_dtype", ctypes.c_int32),
-                ("block0", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+                ("block0", ctypes.c_int32), ("order", ctypes.c_int32)]
 
 
 class AttnDesc(ctypes.Structure):

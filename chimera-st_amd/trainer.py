@@ -44,7 +44,8 @@ class Trainer:
         for p in model.parameters():
             if seen.get(id(p), 1) > 1:
                 p._cst_shared = True  # (modules mark parameters they apply twice in one pass themselves: the memory layers' LayerNorm)
-        self.optimizer.defer_reductions = bool(getattr(self.criterion, "single_pass", False) and getattr(model, "single_use_parameters", False))
+        self._defer_ok = lambda: bool(getattr(self.criterion, "single_pass", False) and getattr(self._model, "single_use_parameters", False))
+        self.optimizer.defer_reductions = self._defer_ok()
         self.num_updates = 0
         self.dtype = dtype
         self._dummy_batch = None
@@ -94,6 +95,7 @@ class Trainer:
             into its own slot; after the all-reduce every rank sees all of them and raises if they disagree beyond 1e-6."""
         self._set_seed()
         self.optimizer.zero_grad()
+        self.optimizer.defer_reductions = self._defer_ok()  # (read per update: the criterion is an attribute a driver may replace)
         logs, sample_size, ooms = [], 0, 0
         for i, sample in enumerate(samples):
             # an empty batch (this rank's shard ran out: ShardedIterator pads with []) runs the dummy batch with its loss zeroed

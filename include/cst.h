@@ -349,13 +349,15 @@ int cst_transpose2d_multi(const cst_transpose_item* items_dev, int n, int64_t to
  * row blocks, and each used to finish with a launch of its own.  cst_gemm (desc.defer_reduce) and cst_layernorm_bwd (dgamma = dbeta
  * = NULL) leave their fp32 partials in the caller's workspace; this call finishes up to CST_REDUCE_MAX_ITEMS of them:
  *   dst[i] = sum_{p < P} src[p * stride + i],  i < L      (L % 8 == 0, src / dst 16-byte aligned, stride % 4 == 0)
- * in a fixed order (partials p = s, s + 8, ... per slice s, slices 0..7), dst in dst_dtype (fp32 or bf16).  `items` is a HOST array
- * (it travels in the kernel arguments: no host-to-device copy, no synchronisation); block0 is filled in by the library. */
+ * in the summation order of the launch-each kernel the item stands in for — order 0: p = 0, 1, 2, ... (cst_gemm's split-K reduce
+ * and its colsum slices), order 1: 64 interleaved chains p = g, g + 64, ... added 0..63 (cst_layernorm_bwd's second stage) — so a
+ * gradient has the same bits whichever route finished it; dst in dst_dtype (fp32 or bf16).  `items` is a HOST array (it travels in
+ * the kernel arguments: no host-to-device copy, no synchronisation); block0 is filled in by the library. */
 #define CST_REDUCE_MAX_ITEMS 64
 typedef struct cst_reduce_item {
   const float* src; void* dst;
   int64_t stride, L;
-  int32_t P, dst_dtype, block0, pad_;
+  int32_t P, dst_dtype, block0, order;
 } cst_reduce_item;
 int cst_reduce_multi(const cst_reduce_item* items, int n, cst_stream stream);
 /* y[r,:] = mask[r] ? 0 : x[r,:]   (x[padding_mask] = 0, wav2vec2.py:820-821) */

@@ -25,12 +25,16 @@ def _build(batch=4):
     return trainer, bench.make_batch(tasks, task, args, 0, torch.device("cuda", 0))
 
 
-def _loss_and_grads(trainer, sample):
+def _loss_and_grads(trainer, sample, overlap=False):
+    """overlap: the trainer's backward context (deferred reductions + the small layers' weight gradients on the side stream)."""
+    from importlib import import_module
+    K = import_module("chimera-st_amd.kernels")
     trainer.optimizer.zero_grad()
     trainer._set_seed()
     s = trainer._prepare_sample(sample)
     loss, ss, log = trainer.criterion(trainer.model, s)
-    loss.backward()
+    with K.deferred_reductions(overlap):
+        loss.backward()
     trainer.buffers.gather_grads()
     return float(loss), trainer.buffers.flat_grad.clone()
 
@@ -50,6 +54,18 @@ def test_full_size_update_properties():
     finally:
         del os.environ["CST_ATTN_NO_KVLEN"]
     assert l1 == l3 and torch.equal(g1, g3), "walking the all-padding key tiles changed the result"
+    # the trainer's backward context — second stages of the small reductions deferred to one launch, the small layers' weight
+    # gradients on a side stream — is bit-reproducible too (a race between the streams would show here), every gradient is written
+    # (the suite poisons deferred destinations with NaN) and has the bits of the launch-each route (cst_reduce_multi keeps its order)
+    from importlib import import_module
+    K = import_module("chimera-st_amd.kernels")
+    assert trainer.optimizer.defer_reductions
+    K.STATS.clear()
+    l4, g4 = _loss_and_grads(trainer, sample, overlap=True)
+    assert K.STATS.get("side_gemm", 0) > 50 and K.DEFER.flushes > 0, (dict(K.STATS), K.DEFER.flushes)
+    l5, g5 = _loss_and_grads(trainer, sample, overlap=True)
+    assert l4 == l1 and l5 == l1 and torch.isfinite(g4.float()).all() and torch.equal(g4, g5)
+    assert torch.equal(g4, g1), "deferred / side-stream gradients differ from the launch-each route on %d elements" % int((g4 != g1).sum())
     # fitting the batch: 6 updates reduce the loss
     losses = [trainer.train_step([sample])["loss"] for _ in range(6)]
     assert all(l == l for l in losses) and losses[-1] < losses[0]

@@ -1289,11 +1289,11 @@ def test_reduce_multi_finishes_many_reductions_in_one_launch(K):
              (512, 15, 512, torch.bfloat16), (8, 1, 8, torch.float32), (2048 * 512, 4, 2048 * 512, torch.float32), (1000 * 8, 7, 9000, torch.bfloat16)]
     specs = specs + [(64 * (i + 1), 3 + i % 9, 64 * (i + 1) + 8, torch.bfloat16) for i in range(70)]
     srcs, dsts, items = [], [], []
-    for Lr, P, stride, dt in specs:
+    for n, (Lr, P, stride, dt) in enumerate(specs):
         src = torch.randn(P * stride + 64, device="cuda")
         dst = torch.full((Lr,), float("nan"), dtype=dt, device="cuda")
         srcs.append(src); dsts.append(dst)
-        items.append((src.data_ptr(), dst.data_ptr(), stride, Lr, P, L.dtype_code(dt)))
+        items.append((src.data_ptr(), dst.data_ptr(), stride, Lr, P, L.dtype_code(dt), 1 if n < 2 or n % 3 == 0 else 0))
     k.reduce_multi(items)
     first = [d.clone() for d in dsts]
     k.reduce_multi(items)
@@ -1335,9 +1335,8 @@ def test_deferred_reductions_give_the_gradients_of_the_immediate_route():
     g0, pend0, fl0 = run(False)
     g1, pend1, fl1 = run(True)
     assert pend0 == 0 and fl0 == 0 and pend1 >= 6 and fl1 == 1  # 3 split weight gradients (+ bias slices) + dgamma / dbeta, one flush
-    for a, b, p in zip(g0, g1, params):
-        assert torch.isfinite(b.float()).all()
-        check(b, a.float(), dt, "deferred gradient %s" % (tuple(p.shape),), scale=float(a.float().abs().max()))
+    for a, b, p in zip(g0, g1, params):  # the same bits: cst_reduce_multi adds in the order of the kernel each item stands in for
+        assert torch.isfinite(b.float()).all() and torch.equal(a, b), "deferred gradient %s" % (tuple(p.shape),)
     # a parameter that already holds a gradient (a later micro-batch) or is marked shared takes the immediate route
     proj.weight._cst_shared = True
     with Kk.deferred_reductions(True):

@@ -427,7 +427,7 @@ def test_padding_free_wav2vec2_stack_is_bit_identical(kind, fixture, dtype):
     assert torch.equal(w2v_p, w2v_d), "wav2vec2 output differs on %d elements" % int((w2v_p != w2v_d).sum())
     assert torch.equal(out_p, out_d) and torch.equal(loss_p, loss_d)
     assert grads_p.keys() == grads_d.keys()
-    tol = 2e-5 if dtype == torch.float32 else 8e-3
+    tol = 2e-5 if dtype == torch.float32 else 1.2e-2  # bf16: 1-2 units in the last place of the largest entry
     for n in grads_p:
         a, b = grads_p[n].float(), grads_d[n].float()
         # a bias gradient is the column sum of the rows whose products form its weight's gradient: its rounding noise scales with

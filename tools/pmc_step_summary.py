@@ -32,9 +32,16 @@ def load(path):
     cols = [c[1] for c in db.execute("pragma table_info('%s')" % view)]
     ix = {c: i for i, c in enumerate(cols)}
     kcol = "kernel_name" if "kernel_name" in ix else "name"
+    gcol = next((c for c in ("grid_size", "grid_size_x", "grid_x") if c in ix), None)
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in db.execute("select * from %s" % view):
-        agg[r[ix[kcol]]][r[ix["counter_name"]]].append(r[ix["value"]])
+        name = r[ix[kcol]]
+        # the attention kernels serve three shape families in one update (wav2vec2 layers: ~1500 frames x 12 heads, packed; the
+        # 512-wide encoder: ~375 frames; decoder cross-attention: <= 128 queries): one line per launch grid, so that the wav2vec2
+        # launches — the "encoder attention" of the north-star target — have their own matrix-pipe figure
+        if gcol is not None and ("fa_fwd" in name or "fa_dq" in name or "fa_dkv" in name):
+            name = "%s [grid %d]" % (name, int(r[ix[gcol]]))
+        agg[name][r[ix["counter_name"]]].append(r[ix["value"]])
     return agg
 
 
@@ -75,7 +82,7 @@ def main():
             rows.append((tot.get("GRBM_GUI_ACTIVE", 0.0), name, n, tot))
         rows.sort(reverse=True)
         gui_all = sum(r[0] for r in rows) or 1.0
-        for gui, name, n, tot in rows[:28]:
+        for gui, name, n, tot in rows[:40]:
             line = "%-96s n=%5d gui_active %6.2f%%" % (short(name), n, 100.0 * gui / gui_all)
             if "SQ_VALU_MFMA_BUSY_CYCLES" in tot and gui > 0:
                 line += "  MFMA busy %5.1f%% of SIMD-cycles" % (100.0 * tot["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui / XCDS * 1024.0))
