@@ -31,6 +31,11 @@
 //   doubling the launch time.  The last workgroup to leave zeroes the counters (sched == nullptr: static stride).
 //   After an item's K loop the first K tile of the NEXT item is already streaming into buffer 0 while the epilogue runs out of
 //   the buffer-1 region, and the epilogue's global stores drain under the next item's MFMAs.
+// Tail: with T tiles on a grid of G workgroups the last round holds r = T mod G tiles; when that round would be less than ~60 % full
+//   (N = 768 at 31 760 rows: 375 tiles = one full round and 119 tiles, i.e. 1.46 rounds of work in the time of 2) its tiles are cut
+//   into two 128-row halves — 2 r items for G workgroups.  A half item is the same pipeline with a 128-row A tile: the A1 half-tile
+//   DMAs are issued out of range (zero fill, no memory traffic: every counted vmcnt and barrier stays as it is), phases 3 and 4 skip
+//   their LDS reads and MFMAs, the epilogue runs one pass.  The K order per output element is unchanged: same bits.
 // Epilogue: MFMA operands are swapped (D = B-frag x A-frag), so a lane holds 4 CONSECUTIVE output columns of one row per
 //   register quad.  bf16 outputs: alpha/bias in registers -> one bf16 rounding (this is the pre-activation z) -> ds_write_b64
 //   into a [128][256] bf16 image (2 passes) -> row-contiguous 16-byte read-back, activation / act' / residual on the way out.
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
   const int wm = wave >> 2, wn = wave & 3;
   const int lrow = lane & 31, hi = lane >> 5;
   const int ntiles = p.tiles_m * p.tiles_n;
-  const int total = ntiles * p.nz;
+  const int total = p.nitems;
   const int ktiles = (int)((p.K + BK - 1) / BK);
   const int per = (ktiles + p.splits - 1) / p.splits;
   // The by-value argument block is re-read from the kernarg segment (scalar loads through an opaque pointer) at each use site
@@ -130,6 +135,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
   __amdgpu_buffer_rsrc_t ra, rb;
   unsigned va0 = 0, vb0 = 0;     // per-lane byte offset (half 0, group 0) from the descriptor base
   int nt = 0, krem0 = 0, mrem = 0, nrem = 0;
+  int hf = 0;                    // the streamed item is a 128-row half tile
   unsigned lda2 = 0, ldb2 = 0;   // leading dimensions in bytes
   int64_t m0 = 0, n0 = 0, cofs = 0, bofs = 0;
   int zcur = 0;
@@ -143,8 +149,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
     p.sbias0 = kp->sbias0; p.sbias1 = kp->sbias1; p.A = kp->A; p.B = kp->B; p.bias = kp->bias;
     p.splits = kp->splits; p.tiles_m = kp->tiles_m; p.tiles_n = kp->tiles_n;
     auto fdiv = [](int n, unsigned long long magic) { return (int)(((unsigned long long)(unsigned)n * magic) >> 40); };
-    const int z = kp->nz > 1 ? fdiv(v, kp->magic_ntiles) : 0;
-    int id = v - z * ntiles;
+    int half = -1, vt = v;
+    if (v >= kp->half_from) {  // (only launches with nz == 1 have half items)
+      const int o = v - kp->half_from;
+      half = o & 1;
+      vt = kp->half_from + (o >> 1);
+    }
+    hf = half >= 0 ? 1 : 0;
+    const int z = kp->nz > 1 ? fdiv(vt, kp->magic_ntiles) : 0;
+    int id = vt - z * ntiles;
     {
       const int q = ntiles >> 3, r = ntiles & 7, xcd = id & 7, loc = id >> 3;
       id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
@@ -156,7 +169,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
     int tm, tn;
     if (gsz == GROUP_M && gshift >= 0) { tm = gm0 + (rem & (GROUP_M - 1)); tn = rem >> gshift; }
     else { tm = gm0 + rem % gsz; tn = rem / gsz; }  // the last, partial group of a launch
-    m0 = (int64_t)tm * BM;
+    m0 = (int64_t)tm * BM + (half == 1 ? 128 : 0);
     n0 = (int64_t)tn * BN;
     zcur = z;
     const int split = p.splits > 1 ? z % p.splits : 0;
@@ -176,7 +189,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
       const int t0 = (int)(m0 >> 6), tn = (int)((p.M + 63) >> 6);
       bool live = false;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) live |= (t0 + i < tn) && ml[t0 + i < tn ? t0 + i : t0] == ep;
+      for (int i = 0; i < 4; ++i) live |= (i < 2 || !hf) && (t0 + i < tn) && ml[t0 + i < tn ? t0 + i : t0] == ep;
       if (!live) nt = 0;
     }
     if (kp->m_len) {  // rows of this batch from m_len[b0] on: all zero in A, unread in C
@@ -197,6 +210,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
     lda2 = (unsigned)(p.lda * 2);
     ldb2 = (unsigned)(p.ldb * 2);
     mrem = (int)(p.M - m0 < BM ? p.M - m0 : BM);
+    if (hf && mrem > 128) mrem = 128;
+    if (mrem <= 0) { mrem = 0; nt = 0; }  // the lower half of a tile that ends in its upper half: nothing to compute or store
     nrem = (int)(p.N - n0 < BN ? p.N - n0 : BN);
     va0 = AK ? (unsigned)pa * lda2 + (unsigned)kla * 2 : (unsigned)klm * lda2 + (unsigned)pa * 2;
     vb0 = BKM ? (unsigned)pb * ldb2 + (unsigned)klb * 2 : (unsigned)klm * ldb2 + (unsigned)pb * 2;
@@ -266,7 +281,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
   };
 
   // one K tile = 4 phases; BUF = the buffer holding tile t
-  auto tile_body = [&](auto bufc, int t, int S) {
+  auto tile_body = [&](auto bufc, int t, int S, const bool half) {
     constexpr int BUF = decltype(bufc)::value;
     using BC = std::integral_constant<int, BUF>;
     using BN_ = std::integral_constant<int, BUF ^ 1>;
@@ -298,17 +313,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
     mfma_quadrant(I0{}, I1{});
     __builtin_amdgcn_s_barrier();
-    // ---- phase 3: A1 -> Q11 ----
+    // ---- phase 3: A1 -> Q11 (a half item has no A1: staging, waits and barriers as ever, no reads, no MFMAs) ----
+    if (!half) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
+      for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) read_a(fa[i][kk], img + 3 * QB, i, kk);
+        for (int i = 0; i < 2; ++i) read_a(fa[i][kk], img + 3 * QB, i, kk);
+    }
     __builtin_amdgcn_sched_barrier(0);
     if (s0 + 2 < S) stage(I1{}, BC{}, t + 2);
     __builtin_amdgcn_s_barrier();
     wait_lgkm<0>();
     __builtin_amdgcn_sched_barrier(0);
-    mfma_quadrant(I1{}, I1{});
+    if (!half) mfma_quadrant(I1{}, I1{});
     __builtin_amdgcn_s_barrier();
     // ---- phase 4: no reads -> Q10; the next K tile must have landed ----
     if (s0 + 3 < S) stage(I2{}, BC{}, t + 2);
@@ -316,7 +333,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
     else wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    mfma_quadrant(I1{}, I0{});
+    if (!half) mfma_quadrant(I1{}, I0{});
     __builtin_amdgcn_s_barrier();
   };
 
@@ -372,6 +389,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
     // ---- the item being computed (its first K tile is in flight or landed) ----
     const int64_t e_m0 = m0, e_n0 = n0, e_cofs = cofs, e_bofs = bofs;
     const int e_z = zcur, e_nt = nt;
+    const bool e_hf = hf != 0;
     const int S = 4 * e_nt;
     if (4 < S) stage(I0{}, I1{}, 1);
     if (5 < S) stage(I1{}, I1{}, 1);
@@ -404,8 +422,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
     if (wm == 1) __builtin_amdgcn_s_barrier();  // stagger: the wm = 1 waves run one barrier behind
     CST_STAMP(1);
     for (int t = 0; t < e_nt; t += 2) {
-      tile_body(I0{}, t, S);
-      if (t + 1 < e_nt) tile_body(I1{}, t + 1, S);
+      tile_body(I0{}, t, S, e_hf);
+      if (t + 1 < e_nt) tile_body(I1{}, t + 1, S, e_hf);
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();
     CST_STAMP(2);
@@ -440,7 +458,27 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
     q.aux_out = kp->aux_out; q.ld_aux_out = kp->ld_aux_out; q.dact = kp->dact; q.aux_in = kp->aux_in; q.ld_aux_in = kp->ld_aux_in;
     q.resid = kp->resid; q.ld_resid = kp->ld_resid; q.alpha = kp->alpha; q.splits = kp->splits; q.ws = kp->ws;
     q.c_f32 = kp->c_f32; q.vec_epi = kp->vec_epi; q.drop_thr = kp->drop_thr; q.drop_key = kp->drop_key; q.drop_scale = kp->drop_scale; q.drop_row0 = kp->drop_row0;
-    if (fast_epi) {
+    if (fast_epi && e_nt == 0 && q.bias_mode == CST_BIAS_NONE && !q.resid) {
+      // A tile whose K loop was skipped (cst_gemm_desc.m_len / m_live: its rows of A are all zero) with an epilogue that maps 0 to 0
+      // — no bias, no residual; act(0) = 0, 0 * act'(z) = 0, 0 * mask = 0 — stores zeros straight from registers: no accumulator
+      // image, no read-back, no operand loads, no activation arithmetic (the conv stack's frames past an utterance's end: a third
+      // of the layer-1 items at the bench's lengths, each of which paid the full 17 k-cycle GELU epilogue to write zeros).
+      if (has_next) claim_land();
+      const u32x4 z4 = {0u, 0u, 0u, 0u};
+      const int64_t col = e_n0 + (tid & 31) * 8;
+      if (col < q.N) {
+        T* const cb = (T*)q.C + e_cofs + col;
+        T* const xb = q.aux_out ? (T*)q.aux_out + e_cofs + col : nullptr;
+#pragma unroll 4
+        for (int it = 0; it < (e_hf ? 8 : 16); ++it) {
+          const int64_t row = e_m0 + (tid >> 5) + 16 * it;
+          if (row < q.M) {
+            __builtin_nontemporal_store(z4, reinterpret_cast<u32x4*>(cb + row * q.ldc));
+            if (xb) __builtin_nontemporal_store(z4, reinterpret_cast<u32x4*>(xb + row * q.ld_aux_out));
+          }
+        }
+      }
+    } else if (fast_epi) {
       // bf16 image [128 rows][256 cols], row stride 528 B; pass hm = rows [128 hm, 128 hm + 128) of the tile.
       // Global LOADS and global STORES never share a loop: with stores pending, waiting for a load costs a full vmcnt(0)
       // (loads and stores retire out of order with respect to each other), i.e. one store round trip per iteration.
@@ -470,6 +508,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
       }
 #pragma unroll
       for (int hm = 0; hm < 2; ++hm) {
+        if (hm && e_hf) break;                 // a half item has one pass (rows 128.. belong to the other half's item)
         if (hm) __builtin_amdgcn_s_barrier();  // previous pass fully read back
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -594,7 +633,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
               for (int e = 0; e < 8; ++e) ob[e] = static_cast<__bf16>(x[e]);
               zr[it] = __builtin_bit_cast(u32x4, ob);
             }
-            if (hm == 0) {  // pass 1's operand vectors, ahead of pass 0's stores
+            if (hm == 0 && !e_hf) {  // pass 1's operand vectors, ahead of pass 0's stores
 #pragma unroll
               for (int it = 0; it < 8; ++it) {
                 int64_t row = e_m0 + 128 + (tid >> 5) + 16 * it;
@@ -653,6 +692,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
       const bool ws_vec = (q.N % 4) == 0;
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) {
+        if (ps == 2 && e_hf) break;  // a half item: rows [0, 128) only
         if (ps) __builtin_amdgcn_s_barrier();
         if (wm == (ps & 1)) {
 #pragma unroll
@@ -772,12 +812,24 @@ int launch8p(GemmParams p, int64_t nbatch, hipStream_t s) {
   // a persistent grid one workgroup per CU otherwise holds the whole chip for the length of a launch.  Multiples of 8 keep the
   // per-XCD work claims on.
   const int avail = ncu - g_reserved_cus.load(std::memory_order_relaxed) > 8 ? ncu - g_reserved_cus.load(std::memory_order_relaxed) : 8;
-  dim3 grid((unsigned)(total < avail ? total : avail), 1, 1);
+  // the last, partly filled round as half-height items (see the header): unbatched launches whose tail round is 1-62 % full
+  const bool no_halves = getenv("CST_GEMM8P_NO_HALVES") != nullptr;  // (read per launch: the tests toggle it in-process)
+  int64_t nitems = total;
+  p.half_from = 0x7fffffff;
+  if (!no_halves && p.nz == 1 && total > avail) {
+    const int64_t r = total % avail;
+    if (r > 0 && r * 100 <= avail * 62) {
+      p.half_from = (int)(total - r);
+      nitems = total + r;
+    }
+  }
+  p.nitems = (int)nitems;
+  dim3 grid((unsigned)(nitems < avail ? nitems : avail), 1, 1);
   static const bool static_walk = getenv("CST_GEMM8P_STATIC") != nullptr;
   // (not under stream capture: a captured launch would pin one slot of the ring for every replay of the graph)
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   const bool capturing = hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
-  p.sched = (!static_walk && !capturing && total > avail && grid.x % 8 == 0) ? sched_slot() : nullptr;
+  p.sched = (!static_walk && !capturing && nitems > avail && grid.x % 8 == 0) ? sched_slot() : nullptr;
   hipLaunchKernelGGL((gemm8p_kernel<AK, BKM, MODE>), grid, dim3(NTHREADS), LDS_BYTES + 1024 + 64, s, p);
   return cst_check_launch("cst_gemm (8-phase)");
 }

@@ -31,6 +31,9 @@ struct GemmParams {
   int vec_epi;  // all epilogue operands 16-byte aligned -> staged, vectorised epilogue
   int tiles_m, tiles_n;
   int nz;  // persistent kernels: number of (batch, split) slices
+  // gemm8p: work items [0, half_from) are whole 256 x 256 tiles; item half_from + 2 j + h is the 128-row half h of tile half_from + j
+  // (the tiles of a launch's last, partly filled round of the persistent grid: twice as many items of half the height); nitems in all
+  int half_from, nitems;
   int group_m;      // gemm8p: m tiles per group of the tile walk (the patch of tiles an XCD works on concurrently)
   // gemm8p: the item -> tile map runs once per work item on the CU's one scalar unit for all eight waves; its divisions by launch
   // constants are multiplications by these (q = (n * magic) >> 40, exact for n * d < 2^40)

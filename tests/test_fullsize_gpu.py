@@ -61,11 +61,22 @@ def test_full_size_update_properties():
     K = import_module("chimera-st_amd.kernels")
     assert trainer.optimizer.defer_reductions
     K.STATS.clear()
+    n0 = K.DEFER.flushes
     l4, g4 = _loss_and_grads(trainer, sample, overlap=True)
-    assert K.STATS.get("side_gemm", 0) > 50 and K.DEFER.flushes > 0, (dict(K.STATS), K.DEFER.flushes)
+    assert K.DEFER.flushes > n0
     l5, g5 = _loss_and_grads(trainer, sample, overlap=True)
     assert l4 == l1 and l5 == l1 and torch.isfinite(g4.float()).all() and torch.equal(g4, g5)
-    assert torch.equal(g4, g1), "deferred / side-stream gradients differ from the launch-each route on %d elements" % int((g4 != g1).sum())
+    assert torch.equal(g4, g1), "deferred gradients differ from the launch-each route on %d elements" % int((g4 != g1).sum())
+    # ... and with the small layers' weight-gradient GEMMs on the side stream (CST_SIDE_STREAM=1: a switch, off by default — it
+    # measured no faster): still the same bits, run to run and against the single-stream route
+    os.environ["CST_SIDE_STREAM"] = "1"
+    try:
+        l6, g6 = _loss_and_grads(trainer, sample, overlap=True)
+        l7, g7 = _loss_and_grads(trainer, sample, overlap=True)
+    finally:
+        del os.environ["CST_SIDE_STREAM"]
+    assert K.STATS.get("side_gemm", 0) > 50, dict(K.STATS)
+    assert l6 == l1 and torch.equal(g6, g7) and torch.equal(g6, g1)
     # fitting the batch: 6 updates reduce the loss
     losses = [trainer.train_step([sample])["loss"] for _ in range(6)]
     assert all(l == l for l in losses) and losses[-1] < losses[0]

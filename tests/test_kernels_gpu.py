@@ -1345,3 +1345,40 @@ def test_deferred_reductions_give_the_gradients_of_the_immediate_route():
         z.float().pow(2).sum().backward()
         assert len(Kk.DEFER.items) == 0
     assert all(torch.isfinite(p.grad.float()).all() for p in params)
+
+
+@pytest.mark.parametrize("M,N,K_,epi", [(31760, 768, 3072, "resid"), (31760, 768, 768, "bias"), (31760, 2304, 768, "bias"), (24100, 768, 1024, "dact"),
+                                        (31744 + 16, 768, 512, "plain")])
+def test_gemm8p_half_height_tail_items_keep_the_bits(K, M, N, K_, epi):
+    """The persistent kernel cuts the tiles of a thinly filled last round into two 128-row items (gemm8p.hip, 'Tail'): the K order per
+    output element is unchanged, so C (and a pre-activation output) have the bits of the whole-tile walk (CST_GEMM8P_NO_HALVES=1) —
+    on the N = 768 family of the wav2vec2 layers, with each epilogue kind, incl. a last tile that ends inside its upper half."""
+    import os
+    k, L = K
+    dt = torch.bfloat16
+    A, B = rnd(M, K_, dt=dt, seed=71), rnd(N, K_, dt=dt, seed=72, scale=K_ ** -0.5)
+    kw = {}
+    if epi == "resid":
+        kw = dict(bias=rnd(N, dt=dt, seed=73), resid=rnd(M, N, dt=dt, seed=74), ld_resid=N, drop_p=0.1, drop_key=99)
+    elif epi == "bias":
+        kw = dict(bias=rnd(N, dt=dt, seed=73), act=L.ACT_GELU, aux_out=torch.empty(M, N, dtype=dt, device="cuda"), ld_aux_out=N)
+    elif epi == "dact":
+        kw = dict(dact=L.ACT_GELU, aux_in=rnd(M, N, dt=dt, seed=75), ld_aux_in=N)
+    outs = []
+    for no_halves in ("", "1"):
+        if no_halves:
+            os.environ["CST_GEMM8P_NO_HALVES"] = "1"
+        try:
+            C = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
+            if "aux_out" in kw:
+                kw["aux_out"] = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
+            k.gemm(A, B, C, M, N, K_, a_kmajor=1, b_kmajor=1, lda=K_, ldb=K_, ldc=N, split_k=1, **kw)
+            outs.append((C, kw.get("aux_out")))
+        finally:
+            os.environ.pop("CST_GEMM8P_NO_HALVES", None)
+    assert torch.isfinite(outs[0][0].float()).all()
+    assert torch.equal(outs[0][0], outs[1][0])
+    if outs[0][1] is not None:
+        assert torch.equal(outs[0][1], outs[1][1])
+    if epi == "plain":
+        check(outs[0][0], A.float() @ B.float().t(), dt, "half-height tail items")
