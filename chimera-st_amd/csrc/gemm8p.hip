@@ -31,7 +31,7 @@
 //   doubling the launch time.  The last workgroup to leave zeroes the counters (sched == nullptr: static stride).
 //   After an item's K loop the first K tile of the NEXT item is already streaming into buffer 0 while the epilogue runs out of
 //   the buffer-1 region, and the epilogue's global stores drain under the next item's MFMAs.
-// Tail: with T tiles on a grid of G workgroups the last round holds r = T mod G tiles; when that round would be less than ~60 % full
+// Tail: with T tiles on a grid of G workgroups the last round holds r = T mod G tiles; when that round would be at most half full
 //   (N = 768 at 31 760 rows: 375 tiles = one full round and 119 tiles, i.e. 1.46 rounds of work in the time of 2) its tiles are cut
 //   into two 128-row halves — 2 r items for G workgroups.  A half item is the same pipeline with a 128-row A tile: the A1 half-tile
 //   DMAs are issued out of range (zero fill, no memory traffic: every counted vmcnt and barrier stays as it is), phases 3 and 4 skip
@@ -812,13 +812,13 @@ int launch8p(GemmParams p, int64_t nbatch, hipStream_t s) {
   // a persistent grid one workgroup per CU otherwise holds the whole chip for the length of a launch.  Multiples of 8 keep the
   // per-XCD work claims on.
   const int avail = ncu - g_reserved_cus.load(std::memory_order_relaxed) > 8 ? ncu - g_reserved_cus.load(std::memory_order_relaxed) : 8;
-  // the last, partly filled round as half-height items (see the header): unbatched launches whose tail round is 1-62 % full
+  // the last, partly filled round as half-height items (see the header): unbatched launches whose tail round is at most half full
   const bool no_halves = getenv("CST_GEMM8P_NO_HALVES") != nullptr;  // (read per launch: the tests toggle it in-process)
   int64_t nitems = total;
   p.half_from = 0x7fffffff;
   if (!no_halves && p.nz == 1 && total > avail) {
     const int64_t r = total % avail;
-    if (r > 0 && r * 100 <= avail * 62) {
+    if (r > 0 && 2 * r <= avail) {  // (the halves must fit ONE round: 137 tiles as 274 halves on 256 CUs run two rounds — 33 500 x 768 x 3072: 0.146 -> 0.193 ms)
       p.half_from = (int)(total - r);
       nitems = total + r;
     }
