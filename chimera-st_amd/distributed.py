@@ -94,8 +94,19 @@ class BucketedGradAllReduce:
         self._offsets = list(offsets)
         self._hooks = []
         self._index = {id(p): idx for idx, p in enumerate(self.params)}
-        for idx, p in enumerate(self.params):
-            self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(idx)))
+        # Gradient hooks on a FEW parameters per bucket only — the ones expected to arrive last (lowest offsets: gradients arrive
+        # roughly in reverse parameter order) — each of which re-examines the buckets in launch order.  A Python hook on each of the
+        # ~300 parameters cost the backward pass of the 512-wide layers 10-15 us of host time per parameter, in the phase where the
+        # host is the bound (1-rank RCCL run: 63.0 -> 66.5 ms per update; profiles/r04_ddp1_idle_gaps.txt).  A bucket is ready when
+        # every member has a gradient or was reported unused; if the order of arrival is not the expected one the bucket simply
+        # leaves with a later trigger (or in finish()) — correct either way.
+        per_bucket = int(os.environ.get("CST_DDP_HOOKS_PER_BUCKET", "3"))
+        self._hooked = set()
+        for bk in self.buckets:
+            by_off = sorted(bk["members"], key=lambda i: self._offsets[i])
+            self._hooked.update(by_off if per_bucket <= 0 else by_off[:per_bucket])
+        for idx in sorted(self._hooked):
+            self._hooks.append(self.params[idx].register_post_accumulate_grad_hook(self._make_hook(idx)))
         _UNUSED_LISTENERS.append(self._on_unused)
         self.reset()
 
@@ -104,49 +115,49 @@ class BucketedGradAllReduce:
             return
         for p in params:
             idx = self._index.get(id(p))
-            if idx is not None and idx not in self._skipped:
-                self._skipped.add(idx)
-                b = self.param_bucket[idx]
-                self._pending[b] -= 1
-                if self._pending[b] == 0:
-                    self._ready[b] = True  # launched from the next gradient hook (never during forward)
+            if idx is not None:
+                self._skipped.add(idx)  # (a bucket is never launched from here: only from a gradient hook, i.e. during backward)
 
     def reset(self):
         if getattr(self, "_reserved", False):  # a backward pass that raised before finish(): the reservation is process-global
             self._set_reserved(False)
-        self._pending = [len(b["members"]) for b in self.buckets]
-        self._ready = [False] * len(self.buckets)
+        for idx in getattr(self, "_frozen", ()):
+            self.params[idx]._cst_slot_frozen = False
+        self._frozen = []          # parameters whose flat-buffer slot travelled without their gradient (optim.grad_slot must not hand it out)
+        self._without = []         # per launched bucket: the reported-unused members that had no gradient when it left
         self._next = 0
         self._works = []
         self._skipped = set()
         self._fired = set()
-        self._late = set()  # parameters whose bucket's all-reduce went out before their gradient existed (reduced again, alone)
+        self._base = {}
+
+    def arm(self):
+        """Called when the reducer is (re-)enabled for the LAST backward pass of an update: gradients accumulated by earlier
+        micro-batches (no_sync) are already there, so "this parameter has arrived" means its gradient was ADDED to since now —
+        autograd accumulates in place, which bumps the tensor's version.  Nothing to remember in the common case (no gradient yet)."""
+        self._base = {i: p.grad._version for i, p in enumerate(self.params) if p.grad is not None}
+
+    def _arrived(self, i):
+        g = self.params[i].grad
+        return g is not None and (i not in self._base or g._version != self._base[i])
+
+    def _bucket_ready(self, b):
+        sk = self._skipped
+        return all(i in sk or self._arrived(i) for i in self.buckets[b]["members"])
 
     def _make_hook(self, idx):
         def hook(param):
             if not self.enabled or not self.active:
                 return
             b = self.param_bucket[idx]
-            again = idx in self._fired  # a second backward pass through the same parameter accumulates into its gradient
+            if idx in self._fired and b < self._next:
+                # a second backward pass through the same parameter after its bucket has left: p.grad IS the flat-buffer slice the
+                # asynchronous all-reduce is writing (gather_grads re-points it), so autograd's in-place accumulation races with the
+                # collective and the slice already holds the mean.  Accumulate under no_sync() instead (update_freq micro-batches
+                # do exactly that: only the last backward runs with the reducer enabled).
+                raise RuntimeError("gradient of parameter %d arrived a second time after its bucket's all-reduce was launched: "
+                                   "run every backward pass but the last one under DistributedFairseqModel.no_sync()" % idx)
             self._fired.add(idx)
-            if again:
-                # Not supported once the bucket has left: after the launch p.grad IS the flat-buffer slice the asynchronous
-                # all-reduce is writing (gather_grads re-points it), so autograd's in-place accumulation of a second gradient
-                # races with the collective and the slice already holds the mean.  Accumulate under no_sync() instead
-                # (update_freq micro-batches do exactly that: only the last backward runs with the reducer enabled).
-                if b < self._next:
-                    raise RuntimeError("gradient of parameter %d arrived a second time after its bucket's all-reduce was launched: "
-                                       "run every backward pass but the last one under DistributedFairseqModel.no_sync()" % idx)
-                return
-            if idx in self._skipped:
-                # reported unused by the forward pass (layerdrop) but it took part after all: it was already counted.  If its
-                # bucket has left, that all-reduce carried zeros for it: this parameter is reduced again, alone (late_reduce)
-                if b < self._next:
-                    self._late.add(idx)
-                return
-            self._pending[b] -= 1
-            if self._pending[b] == 0:
-                self._ready[b] = True
             self._launch_ready()
 
         return hook
@@ -156,6 +167,14 @@ class BucketedGradAllReduce:
         if self.flat_grad.is_cuda:  # gradients whose last reduction stage was deferred (kernels.DEFER) are finished before they travel
             from . import kernels as K
             K.DEFER.flush()
+        # members that travel without a gradient (reported unused, or never used): should one of them get a gradient after all
+        # (layerdrop reported it and it took part anyway) it is reduced again, alone (late_reduce) — and must not be written into
+        # its slot of the flat buffer while the collective owns that memory (optim.grad_slot)
+        absent = [i for i in bk["members"] if not self._arrived(i)]
+        for i in absent:
+            self.params[i]._cst_slot_frozen = True
+        self._frozen.extend(absent)
+        self._without.append(absent)
         if self.gather is not None:
             self.gather(bk["members"])
         g = self.flat_grad[bk["lo"]:bk["hi"]]
@@ -184,7 +203,7 @@ class BucketedGradAllReduce:
         self._reserved = on
 
     def _launch_ready(self):
-        while self._next < len(self.buckets) and self._ready[self._next]:
+        while self._next < len(self.buckets) and self._bucket_ready(self._next):
             self._launch(self._next)
             self._next += 1
 
@@ -219,9 +238,10 @@ class BucketedGradAllReduce:
         parameters that need a second, rank-agreed reduction in `late_params` (see late_reduce)."""
         self.late_params = []
         if self.active and self.enabled:
-            # overlap bookkeeping of the update that just ended: buckets launched from hooks, parameters nobody accounted for
+            self._launch_ready()  # (a bucket whose last gradient came from a parameter without a hook)
+            # overlap bookkeeping of the update that just ended: buckets launched during backward, parameters nobody accounted for
             self.last_early = self._next
-            self.last_missing = [i for i in range(len(self.params)) if i not in self._fired and i not in self._skipped]
+            self.last_missing = [i for i in range(len(self.params)) if not self._arrived(i) and i not in self._skipped]
             while self._next < len(self.buckets):
                 self._launch(self._next)
                 self._next += 1
@@ -230,7 +250,8 @@ class BucketedGradAllReduce:
             self._works = []
             if self._reserved:
                 self._set_reserved(False)
-            self.late_params = sorted(self._late)
+            # a gradient that exists now for a member that travelled without one: reported unused, took part after its bucket had left
+            self.late_params = sorted(i for absent in self._without for i in absent if self._arrived(i))
         self.reset()
 
 
@@ -264,6 +285,8 @@ class DistributedFairseqModel(torch.nn.Module):
             yield
         finally:
             self.reducer.enabled = old
+            if old:
+                self.reducer.arm()  # what the accumulation passes left behind is not "arrived" for the pass that reduces
 
     def all_reduce(self):
         self.reducer.finish()

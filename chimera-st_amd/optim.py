@@ -109,7 +109,8 @@ def grad_slot(w):
     for p in ps:
         s = getattr(p, "_cst_grad_slot", None)
         buf = s[0]() if s is not None else None
-        if buf is None or p.grad is not None or p._cst_grad_claim == buf.epoch or not p.requires_grad:
+        if (buf is None or p.grad is not None or p._cst_grad_claim == buf.epoch or not p.requires_grad
+                or getattr(p, "_cst_slot_frozen", False)):  # (frozen: the slot is travelling in a bucket all-reduce, distributed.py)
             return None
         slots.append((buf, s[1], p))
     buf = slots[0][0]

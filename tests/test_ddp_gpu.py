@@ -122,12 +122,12 @@ def test_empty_shard_batch_contributes_zero():
     np.testing.assert_allclose(res[0][4], tr.buffers.flat_param.detach().cpu().numpy(), rtol=1e-4, atol=2e-5)
 
 
-def _worker_rccl(port, q):
+def _worker_rccl(port, q, collective="allreduce"):
     """The RCCL ("nccl") backend itself: a 1-GPU box can only form a 1-rank communicator, so CST_DDP_FORCE=1 keeps the bucketed,
     hook-launched all-reduces, the fp64 stat all-reduce and the barrier on for it — real RCCL calls on their own stream, ordered
     against this library's raw-HIP launches on torch's current stream."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", CST_DDP_FORCE="1",
-                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", CST_DDP_COLLECTIVE=collective)
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -136,7 +136,7 @@ def _worker_rccl(port, q):
     model, task, crit = _build()
     Trainer = import_module("chimera-st_amd.trainer").Trainer
     tr = Trainer(_targs(), task, model, crit, device="cuda")
-    assert tr.ddp and len(tr.model.reducer.buckets) >= 3
+    assert tr.ddp and len(tr.model.reducer.buckets) >= 3 and tr.model.reducer.collective == collective
     outs = [tr.train_step(_samples(task)) for _ in range(3)]
     # every bucket was launched from a gradient hook during backward (nothing left for finish()): the wav2vec2 pre-training heads
     # that never get a gradient are reported as unused by the forward pass
@@ -147,11 +147,13 @@ def _worker_rccl(port, q):
     dist.destroy_process_group()
 
 
-def test_rccl_backend_single_rank_collectives():
+@pytest.mark.parametrize("collective", ["allreduce", "rs_ag"])
+def test_rccl_backend_single_rank_collectives(collective):
+    """rs_ag: every bucket as RCCL reduce-scatter + all-gather in place (CST_DDP_COLLECTIVE), both queued on the communicator's stream."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_worker_rccl, args=(port, q))
+    p = ctx.Process(target=_worker_rccl, args=(port, q, collective))
     p.start()
     losses, gnorms, flat = q.get(timeout=600)
     p.join(120)
