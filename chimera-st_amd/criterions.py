@@ -127,17 +127,58 @@ class TripletSTMTContrastiveCriterion(LabelSmoothedCrossEntropyCriterion):
         """The reference reads metrics.get_smoothed_values("train")["num_updates"] (:43-45); the trainer pushes it here."""
         self.num_updates = n
 
+    @staticmethod
+    def one_decoder_pass(model):
+        """Can the audio pass and the text pass share ONE decoder call?  Both feed the decoder the same prev_output_tokens and an
+        M-slot memory of the same shape (w2v2_transformer_interlingua.py:137-146, :301-304: no padding in the memory), and every
+        decoder row depends on its own batch element only — so decoder(cat(prev, prev), cat(memory_audio, memory_text)) yields the
+        two passes' logits as its two batch halves: half the decoder launches at twice the rows, and every decoder parameter
+        receives one gradient per backward pass instead of two."""
+        import os
+        return (not os.environ.get("CST_NO_PAIR_DECODER") and hasattr(model, "encoder") and hasattr(model, "decoder")
+                and hasattr(model, "forward_with_internal") and not getattr(getattr(model, "encoder", None), "no_interlingua", True))
+
+    @staticmethod
+    def twice_used(model):
+        """The parameters BOTH passes of an update run through when the decoder is shared (one_decoder_pass): the encoder layers behind
+        the modality-specific front ends and the memory module.  They receive two gradients per backward pass (trainer.py marks them:
+        their reductions are not deferred); everything else — wav2vec2, subsampler, text embedding, decoder — receives one."""
+        if not TripletSTMTContrastiveCriterion.one_decoder_pass(model):
+            return None
+        return [p for n, p in model.encoder.named_parameters()
+                if not n.startswith(("wav2vec_model.", "subsample.", "text_embed_tokens."))]
+
+    def _two_passes_one_decoder(self, model, sample, reduce):
+        from .fairseq_model import EncoderOut
+        from .modules import to_batch_major, to_time_major_view
+        ni = sample["net_input"]
+        enc_a = model.encoder(src_tokens=ni["src_tokens"], src_lengths=ni["src_lengths"])
+        enc_t = model.encoder(src_tokens=sample["src_text"], src_lengths=sample["src_text_lengths"])
+        mem = to_time_major_view(torch.cat((to_batch_major(enc_a.encoder_out), to_batch_major(enc_t.encoder_out)), 0))  # [M, 2B, C]
+        pm = torch.cat((enc_a.encoder_padding_mask, enc_t.encoder_padding_mask), 0)
+        prev = ni["prev_output_tokens"]
+        logits, extra = model.decoder(prev_output_tokens=torch.cat((prev, prev), 0),
+                                      encoder_out=EncoderOut(encoder_out=mem, encoder_padding_mask=pm, encoder_embedding=None,
+                                                             encoder_states=None, src_tokens=None, src_lengths=None))
+        B = prev.size(0)
+        st_loss, st_nll_loss = self.compute_loss(model, (logits[:B], extra), sample, reduce=reduce)
+        mt_loss, mt_nll_loss = self.compute_loss(model, (logits[B:], extra), sample, reduce=reduce)
+        return st_loss, st_nll_loss, mt_loss, mt_nll_loss, enc_a.encoder_out, enc_t.encoder_out
+
     def forward(self, model, sample, reduce=True):
         """:68-146 — audio pass, text pass, contrastive term."""
-        st_net_output, audio_internal = model.forward_with_internal(**sample["net_input"])
-        st_loss, st_nll_loss = self.compute_loss(model, st_net_output, sample, reduce=reduce)
-        if self.loss_ratio[1] != 0:
-            mt_input = {"src_tokens": sample["src_text"], "src_lengths": sample["src_text_lengths"],
-                        "prev_output_tokens": sample["net_input"]["prev_output_tokens"], "mask": sample["net_input"]["mask"]}
-            mt_net_output, text_internal = model.forward_with_internal(**mt_input)
-            mt_loss, mt_nll_loss = self.compute_loss(model, mt_net_output, sample, reduce=reduce)
+        if self.loss_ratio[1] != 0 and self.one_decoder_pass(model):
+            st_loss, st_nll_loss, mt_loss, mt_nll_loss, audio_internal, text_internal = self._two_passes_one_decoder(model, sample, reduce)
         else:
-            mt_loss, mt_nll_loss = 0, 0
+            st_net_output, audio_internal = model.forward_with_internal(**sample["net_input"])
+            st_loss, st_nll_loss = self.compute_loss(model, st_net_output, sample, reduce=reduce)
+            if self.loss_ratio[1] != 0:
+                mt_input = {"src_tokens": sample["src_text"], "src_lengths": sample["src_text_lengths"],
+                            "prev_output_tokens": sample["net_input"]["prev_output_tokens"], "mask": sample["net_input"]["mask"]}
+                mt_net_output, text_internal = model.forward_with_internal(**mt_input)
+                mt_loss, mt_nll_loss = self.compute_loss(model, mt_net_output, sample, reduce=reduce)
+            else:
+                mt_loss, mt_nll_loss = 0, 0
         if self.loss_ratio[2] != 0:
             contrastive_loss = self.compute_contrastive(audio_internal, text_internal, reduce)
         else:

@@ -44,7 +44,21 @@ class Trainer:
         for p in model.parameters():
             if seen.get(id(p), 1) > 1:
                 p._cst_shared = True  # (modules mark parameters they apply twice in one pass themselves: the memory layers' LayerNorm)
-        self._defer_ok = lambda: bool(getattr(self.criterion, "single_pass", False) and getattr(self._model, "single_use_parameters", False))
+        def _defer_ok():
+            if not getattr(self._model, "single_use_parameters", False):
+                return False
+            if getattr(self.criterion, "single_pass", False):
+                return True
+            # two passes that share the decoder call (TripletSTMTContrastiveCriterion.one_decoder_pass): the parameters both passes run
+            # through are named by the criterion and marked; all the others receive one gradient per backward pass
+            twice = getattr(self.criterion, "twice_used", lambda m: None)(self._model)
+            if twice is None:
+                return False
+            for p in twice:
+                p._cst_shared = True
+            return True
+
+        self._defer_ok = _defer_ok
         self.optimizer.defer_reductions = self._defer_ok()
         self.num_updates = 0
         self.dtype = dtype
