@@ -145,15 +145,23 @@ class TripletSTMTContrastiveCriterion(LabelSmoothedCrossEntropyCriterion):
         their reductions are not deferred); everything else — wav2vec2, subsampler, text embedding, decoder — receives one."""
         if not TripletSTMTContrastiveCriterion.one_decoder_pass(model):
             return None
-        return [p for n, p in model.encoder.named_parameters()
-                if not n.startswith(("wav2vec_model.", "subsample.", "text_embed_tokens."))]
+        import os
+        names = ("interlingua_layers.", "interlingua_embedding.")  # with forward_pair the shared encoder layers are walked once
+        if not hasattr(model.encoder, "forward_pair") or os.environ.get("CST_NO_PAIR_ENCODER"):
+            return [p for n, p in model.encoder.named_parameters() if not n.startswith(("wav2vec_model.", "subsample.", "text_embed_tokens."))]
+        return [p for n, p in model.encoder.named_parameters() if n.startswith(names)]
 
     def _two_passes_one_decoder(self, model, sample, reduce):
         from .fairseq_model import EncoderOut
         from .modules import to_batch_major, to_time_major_view
         ni = sample["net_input"]
-        enc_a = model.encoder(src_tokens=ni["src_tokens"], src_lengths=ni["src_lengths"])
-        enc_t = model.encoder(src_tokens=sample["src_text"], src_lengths=sample["src_text_lengths"])
+        import os
+        if hasattr(model.encoder, "forward_pair") and not os.environ.get("CST_NO_PAIR_ENCODER"):
+            # ... and ONE walk through the shared encoder layers (S2T_W2V2_TransformerInterlinguaEncoder.forward_pair)
+            enc_a, enc_t = model.encoder.forward_pair(ni["src_tokens"], ni["src_lengths"], sample["src_text"], sample["src_text_lengths"])
+        else:
+            enc_a = model.encoder(src_tokens=ni["src_tokens"], src_lengths=ni["src_lengths"])
+            enc_t = model.encoder(src_tokens=sample["src_text"], src_lengths=sample["src_text_lengths"])
         mem = to_time_major_view(torch.cat((to_batch_major(enc_a.encoder_out), to_batch_major(enc_t.encoder_out)), 0))  # [M, 2B, C]
         pm = torch.cat((enc_a.encoder_padding_mask, enc_t.encoder_padding_mask), 0)
         prev = ni["prev_output_tokens"]

@@ -945,6 +945,12 @@ def conv1d_cl(x, weight, bias, stride, pad=0, act=None, prev_z=None, grad_is_dz=
 # ------------------------------------------------------------------------------------------------
 # grouped positional conv of wav2vec2 (k taps, `groups` groups, pad k//2, SamePad, GELU, + residual)
 # ------------------------------------------------------------------------------------------------
+# K slices of the positional convolution's weight-gradient GEMM (16 groups x 48 column tiles = 768 workgroups of the 64 x 128 configuration,
+# 1.5 rounds of the 512 that fit the chip): 2 or 3 slices measured the same as 1 inside the update (64.5-65.8 ms per update in all
+# three settings on one box) — a switch for the tools, default 1
+_POSCONV_DW_SPLIT = int(_os.environ.get("CST_POSCONV_DW_SPLIT", 1))
+
+
 class _PosConvFn(torch.autograd.Function):
     """Grouped conv as a batched implicit GEMM.  The input is re-staged GROUP-MAJOR ([B, G, T+k, C/G], one 74 MB copy at
     B=32) so that for one (utterance, group) the im2col row of frame t is the contiguous window starting at frame t:
@@ -1005,7 +1011,7 @@ class _PosConvFn(torch.autograd.Function):
                 # [groups][cg] = channel order (cst_gemm_desc.colsum)
                 db = torch.empty(C, dtype=dy.dtype, device=dy.device)
             K.gemm(dzg, xg, dwg, cg, k * cg, Kr, a_kmajor=0, b_kmajor=0, lda=cg, ldb=cg, ldc=k * cg, batch0=1, batch1=groups,
-                   sa=(0, B * Tp * cg), sb=(0, B * Tp * cg), sc=(0, cg * k * cg), a_off=lp * cg, split_k=1, colsum=db)
+                   sa=(0, B * Tp * cg), sb=(0, B * Tp * cg), sc=(0, cg * k * cg), a_off=lp * cg, split_k=_POSCONV_DW_SPLIT, colsum=db)
             dw = dwg.view(groups, cg, k, cg).permute(0, 1, 3, 2).reshape(C, cg, k).to(weight.dtype)
             if db is not None:
                 db = db.to(weight.dtype)

@@ -122,6 +122,67 @@ class S2T_W2V2_TransformerInterlinguaEncoder(S2T_W2V2_TransformerEncoder):
     def max_positions(self):
         return None
 
+    def _front_end(self, src_tokens, src_lengths):
+        """The modality-specific part of :207-236: batch-major rows [B, T, C] in front of the shared layers, lengths, padding mask."""
+        is_text = not src_tokens.dtype.is_floating_point
+        drop_p = self.dropout_module.p if self.training else 0.0
+        if is_text:
+            input_lengths = src_lengths
+            encoder_padding_mask = lengths_to_padding_mask(input_lengths, max_len=src_tokens.size(1))
+            xb = CF.embed_positions(tokens=src_tokens, pad_mask=encoder_padding_mask, embed=self.text_embed_tokens.weight,
+                                    pos_table=self.embed_positions.table(src_tokens.size(1), src_tokens.device),
+                                    scale=self.embed_scale, pad_idx=self.padding_idx, dropout_p=drop_p)
+        else:
+            w2v_feature, _, input_lengths = self._get_w2v_feature(src_tokens, src_lengths)
+            feature_tm, input_lengths = self.subsample(w2v_feature, input_lengths)
+            encoder_padding_mask = lengths_to_padding_mask(input_lengths, max_len=feature_tm.size(0))
+            xb = CF.embed_positions(x=to_batch_major(feature_tm), scale=self.embed_scale, pad_idx=self.padding_idx, dropout_p=drop_p)  # no positions (Q3)
+        return xb, input_lengths, encoder_padding_mask
+
+    def _memory(self, h_enc):
+        """:264-298 on one modality's encoder output h_enc [T, B, C] -> memory [M, B, C]."""
+        batch_size = h_enc.shape[1]
+        interlingua = self.interlingua_embedding.weight.unsqueeze(0).expand(batch_size, -1, -1)  # B x M x C
+        interlingua = to_time_major_view(interlingua.contiguous())
+        for layer in self.interlingua_layers:
+            # == layer(cat(h_enc, mem), no key padding (Q1), column mask hiding the memory columns (Q2))[-M:]
+            interlingua = layer(interlingua, None, kv=h_enc)
+        return interlingua
+
+    def forward_pair(self, audio_tokens, audio_lengths, text_tokens, text_lengths):
+        """The audio pass and the text pass of one triplet sample (criterions/triplet_st_mt_contrastive.py:68-100) through the SHARED
+        encoder layers as ONE row set: every row-wise operation (LayerNorm, projections, FFN) sees the audio frames of the batch — all
+        of them, padding included: the memory attention reads padded frames, quirk Q1 — followed by the text tokens, and
+        self-attention runs per sequence on that packed row set (functional.PackedRows: sequence b attends its first kv_len[b] rows,
+        which is what the length-derived key padding mask of :232 expresses).  Row for row the values of the two separate passes;
+        half the launches, and every shared-layer parameter receives one gradient.  The memory layers then run per modality (their
+        key/value rows differ in length).  Returns (EncoderOut audio, EncoderOut text)."""
+        xa, len_a, _ = self._front_end(audio_tokens, audio_lengths)   # [B, Ta, C]
+        xt, len_t, _ = self._front_end(text_tokens, text_lengths)     # [B, Tt, C]
+        B, Ta, C = xa.shape
+        Tt = xt.shape[1]
+        dev = xa.device
+        rows = torch.cat((xa.reshape(B * Ta, C), xt.reshape(B * Tt, C)), 0)
+        off = torch.cat((torch.arange(0, B * Ta + 1, Ta, dtype=torch.int32, device=dev),
+                         torch.arange(B * Ta + Tt, B * Ta + B * Tt + 1, Tt, dtype=torch.int32, device=dev))).contiguous()
+        kvl = torch.cat((torch.clamp(len_a, max=Ta), torch.clamp(len_t, max=Tt))).to(torch.int32).contiguous()
+        seq = CF.PackedRows(off, kvl, B * (Ta + Tt), max(Ta, Tt), 2 * B, max(Ta, Tt))
+        x = to_time_major_view(rows.unsqueeze(0))  # [rows, 1, C]
+        for layer in self.transformer_layers:
+            x = layer(x, None, seq=seq)
+        if self.layer_norm is not None:
+            x = self.layer_norm(x)
+        xb = to_batch_major(x)[0]
+        h_a = to_time_major_view(xb[:B * Ta].view(B, Ta, C))
+        h_t = to_time_major_view(xb[B * Ta:].view(B, Tt, C))
+        outs = []
+        for h in (h_a, h_t):
+            mem = h if self.no_interlingua else self._memory(h)
+            pm = torch.zeros(B, mem.shape[0], device=dev, dtype=torch.bool)
+            outs.append(EncoderOut(encoder_out=mem, encoder_padding_mask=pm, encoder_embedding=None, encoder_states=None,
+                                   src_tokens=None, src_lengths=None))
+        return outs[0], outs[1]
+
     def forward(self, src_tokens, src_lengths, **extra_args):
         """:207-312."""
         is_text = not src_tokens.dtype.is_floating_point
