@@ -146,28 +146,31 @@ class TripletSTMTContrastiveCriterion(LabelSmoothedCrossEntropyCriterion):
         if not TripletSTMTContrastiveCriterion.one_decoder_pass(model):
             return None
         import os
-        names = ("interlingua_layers.", "interlingua_embedding.")  # with forward_pair the shared encoder layers are walked once
-        if not hasattr(model.encoder, "forward_pair") or os.environ.get("CST_NO_PAIR_ENCODER"):
+        if not hasattr(model.encoder, "forward_pair") or os.environ.get("CST_NO_PAIR_ENCODER") or os.environ.get("CST_NO_PACK"):
             return [p for n, p in model.encoder.named_parameters() if not n.startswith(("wav2vec_model.", "subsample.", "text_embed_tokens."))]
-        return [p for n, p in model.encoder.named_parameters() if n.startswith(names)]
+        if os.environ.get("CST_NO_PAIR_MEMORY"):  # forward_pair walks the shared encoder layers once, the memory layers per modality
+            return [p for n, p in model.encoder.named_parameters() if n.startswith(("interlingua_layers.", "interlingua_embedding."))]
+        return []  # ... and, by default, the memory layers once as well: every parameter receives one gradient per backward pass
 
     def _two_passes_one_decoder(self, model, sample, reduce):
         from .fairseq_model import EncoderOut
         from .modules import to_batch_major, to_time_major_view
         ni = sample["net_input"]
         import os
-        if hasattr(model.encoder, "forward_pair") and not os.environ.get("CST_NO_PAIR_ENCODER"):
+        if hasattr(model.encoder, "forward_pair") and not os.environ.get("CST_NO_PAIR_ENCODER") and not os.environ.get("CST_NO_PACK"):
             # ... and ONE walk through the shared encoder layers (S2T_W2V2_TransformerInterlinguaEncoder.forward_pair)
-            enc_a, enc_t = model.encoder.forward_pair(ni["src_tokens"], ni["src_lengths"], sample["src_text"], sample["src_text_lengths"])
+            enc_a, enc_t, enc_both = model.encoder.forward_pair(ni["src_tokens"], ni["src_lengths"], sample["src_text"], sample["src_text_lengths"])
         else:
             enc_a = model.encoder(src_tokens=ni["src_tokens"], src_lengths=ni["src_lengths"])
             enc_t = model.encoder(src_tokens=sample["src_text"], src_lengths=sample["src_text_lengths"])
-        mem = to_time_major_view(torch.cat((to_batch_major(enc_a.encoder_out), to_batch_major(enc_t.encoder_out)), 0))  # [M, 2B, C]
-        pm = torch.cat((enc_a.encoder_padding_mask, enc_t.encoder_padding_mask), 0)
+            enc_both = None
+        if enc_both is None:
+            mem = to_time_major_view(torch.cat((to_batch_major(enc_a.encoder_out), to_batch_major(enc_t.encoder_out)), 0))  # [M, 2B, C]
+            pm = torch.cat((enc_a.encoder_padding_mask, enc_t.encoder_padding_mask), 0)
+            enc_both = EncoderOut(encoder_out=mem, encoder_padding_mask=pm, encoder_embedding=None, encoder_states=None, src_tokens=None,
+                                  src_lengths=None)
         prev = ni["prev_output_tokens"]
-        logits, extra = model.decoder(prev_output_tokens=torch.cat((prev, prev), 0),
-                                      encoder_out=EncoderOut(encoder_out=mem, encoder_padding_mask=pm, encoder_embedding=None,
-                                                             encoder_states=None, src_tokens=None, src_lengths=None))
+        logits, extra = model.decoder(prev_output_tokens=torch.cat((prev, prev), 0), encoder_out=enc_both)
         B = prev.size(0)
         st_loss, st_nll_loss = self.compute_loss(model, (logits[:B], extra), sample, reduce=reduce)
         mt_loss, mt_nll_loss = self.compute_loss(model, (logits[B:], extra), sample, reduce=reduce)

@@ -8,6 +8,7 @@ layer on the M query rows only, with K/V = the layer's self_attn_layer_norm + k/
 same numbers for the rows that are kept (Q1: padded encoder frames ARE attended; Q2: memory columns are never
 attended), 3.7x fewer FLOPs (credited as such in bench.py, never as the reference-shaped count)."""
 import logging
+import os
 
 import torch
 import torch.nn as nn
@@ -156,7 +157,8 @@ class S2T_W2V2_TransformerInterlinguaEncoder(S2T_W2V2_TransformerEncoder):
         self-attention runs per sequence on that packed row set (functional.PackedRows: sequence b attends its first kv_len[b] rows,
         which is what the length-derived key padding mask of :232 expresses).  Row for row the values of the two separate passes;
         half the launches, and every shared-layer parameter receives one gradient.  The memory layers then run per modality (their
-        key/value rows differ in length).  Returns (EncoderOut audio, EncoderOut text)."""
+        key/value rows differ in length) or — default — at once, the shorter modality's rows zero-padded and masked.
+        Returns (EncoderOut audio, EncoderOut text, EncoderOut of both as one batch of 2B or None)."""
         xa, len_a, _ = self._front_end(audio_tokens, audio_lengths)   # [B, Ta, C]
         xt, len_t, _ = self._front_end(text_tokens, text_lengths)     # [B, Tt, C]
         B, Ta, C = xa.shape
@@ -173,15 +175,33 @@ class S2T_W2V2_TransformerInterlinguaEncoder(S2T_W2V2_TransformerEncoder):
         if self.layer_norm is not None:
             x = self.layer_norm(x)
         xb = to_batch_major(x)[0]
-        h_a = to_time_major_view(xb[:B * Ta].view(B, Ta, C))
-        h_t = to_time_major_view(xb[B * Ta:].view(B, Tt, C))
-        outs = []
-        for h in (h_a, h_t):
-            mem = h if self.no_interlingua else self._memory(h)
-            pm = torch.zeros(B, mem.shape[0], device=dev, dtype=torch.bool)
-            outs.append(EncoderOut(encoder_out=mem, encoder_padding_mask=pm, encoder_embedding=None, encoder_states=None,
-                                   src_tokens=None, src_lengths=None))
-        return outs[0], outs[1]
+        h_ab, h_tb = xb[:B * Ta].view(B, Ta, C), xb[B * Ta:].view(B, Tt, C)
+
+        def out(mem):
+            pm = torch.zeros(mem.shape[1], mem.shape[0], device=dev, dtype=torch.bool)
+            return EncoderOut(encoder_out=mem, encoder_padding_mask=pm, encoder_embedding=None, encoder_states=None, src_tokens=None,
+                              src_lengths=None)
+
+        if self.no_interlingua or os.environ.get("CST_NO_PAIR_MEMORY"):
+            h_a, h_t = to_time_major_view(h_ab), to_time_major_view(h_tb)
+            return (out(h_a if self.no_interlingua else self._memory(h_a)), out(h_t if self.no_interlingua else self._memory(h_t)), None)
+        # the memory layers on both modalities at once: 2B memories of M slots; key/value rows = each sample's encoder output, the
+        # shorter modality padded with zero rows up to the longer one and those rows masked as keys (for the audio half NO frame is
+        # masked — quirk Q1; for the text half all Tt positions, padding included, stay visible: exactly the two separate passes)
+        Tk = max(Ta, Tt)
+        pad_a = torch.nn.functional.pad(h_ab, (0, 0, 0, Tk - Ta)) if Tk > Ta else h_ab
+        pad_t = torch.nn.functional.pad(h_tb, (0, 0, 0, Tk - Tt)) if Tk > Tt else h_tb
+        kvb = torch.cat((pad_a, pad_t), 0)                                   # [2B, Tk, C]
+        mask = torch.zeros(2 * B, Tk, device=dev, dtype=torch.bool)
+        if Tk > Ta:
+            mask[:B, Ta:] = True
+        if Tk > Tt:
+            mask[B:, Tt:] = True
+        mem = to_time_major_view(self.interlingua_embedding.weight.unsqueeze(0).expand(2 * B, -1, -1).contiguous())
+        for layer in self.interlingua_layers:
+            mem = layer(mem, mask, kv=to_time_major_view(kvb))
+        memb = to_batch_major(mem)                                            # [2B, M, C]
+        return out(to_time_major_view(memb[:B])), out(to_time_major_view(memb[B:])), out(mem)
 
     def forward(self, src_tokens, src_lengths, **extra_args):
         """:207-312."""
