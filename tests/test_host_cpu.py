@@ -427,3 +427,98 @@ def test_trainer_oom_flag_and_grad_norm_check_gloo_world2(mode):
     else:
         for r in res:  # every rank sees every rank's norm in the all-reduced vector: all of them stop
             assert r["raised"] is not None and "gradients are inconsistent between workers" in r["raised"] and "rank   1" in r["raised"]
+
+
+def test_grad_slot_hands_a_flat_buffer_slot_out_once_per_epoch():
+    """optim.grad_slot (backward kernels write a weight gradient straight into the flat gradient buffer): the slot is adopted by
+    autograd as p.grad (no copy in gather_grads), handed out once per zero_grad epoch and only while p.grad is None — a later
+    micro-batch accumulates into it, a second use of a shared weight in the same pass is added to it — and never while it is
+    travelling in a bucket all-reduce (`_cst_slot_frozen`, distributed.py)."""
+    lin = torch.nn.Linear(8, 4)
+    buf = optim.FlatParamBuffers(lin.parameters())
+    w = lin.weight
+    handed = []
+
+    class F(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            return x @ w.t()
+
+        @staticmethod
+        def backward(ctx, dy):
+            x, w_ = ctx.saved_tensors
+            assert w_ is lin.weight  # the Parameter itself comes back from saved_tensors: its attributes are there
+            out = optim.grad_slot(w_)
+            handed.append(out is not None)
+            g = dy.t() @ x
+            if out is not None:
+                out.copy_(g)
+                g = out
+            return dy @ w_, g
+
+    x = torch.randn(3, 8)
+    want = torch.ones(3, 4).t() @ x
+    buf.zero_grad()
+    F.apply(x, w).sum().backward()
+    assert handed == [True] and w.grad.data_ptr() == buf.grad_views[0].data_ptr() and torch.allclose(w.grad, want)
+    F.apply(x, w).sum().backward()  # accumulation into an existing gradient: not handed out, autograd adds into the slot
+    assert handed == [True, False] and torch.allclose(w.grad, 2 * want) and w.grad.data_ptr() == buf.grad_views[0].data_ptr()
+    buf.zero_grad()
+    handed.clear()
+    (F.apply(x, w).sum() + F.apply(2 * x, w).sum()).backward()  # a shared weight: two gradients in one pass, one slot
+    assert sorted(handed) == [False, True] and torch.allclose(w.grad, 3 * want)
+    buf.gather_grads()
+    assert torch.allclose(buf.grad_views[0], 3 * want)
+    buf.zero_grad()
+    handed.clear()
+    w._cst_slot_frozen = True  # what the reducer sets on members of a bucket that left without their gradient
+    F.apply(x, w).sum().backward()
+    w._cst_slot_frozen = False
+    assert handed == [False] and w.grad.data_ptr() != buf.grad_views[0].data_ptr() and torch.allclose(w.grad, want)
+
+
+def _odd_order_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", CST_DDP_FORCE="1", CST_DDP_HOOKS_PER_BUCKET="1")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    torch.manual_seed(0)
+    layers = [torch.nn.Linear(6, 6) for _ in range(6)]
+    # the flat buffer (and with it the buckets and their hooked parameters) is laid out in an order that has nothing to do with
+    # the order in which the gradients arrive
+    order = [3, 0, 5, 1, 4, 2]
+    params = [p for i in order for p in layers[i].parameters()]
+    buf = optim.FlatParamBuffers(params)
+    red = distributed.BucketedGradAllReduce(buf.params, buf.offsets, buf.flat_grad, None, bucket_cap_mb=0.0002, gather=buf.gather_grads)
+    assert red.active and len(red.buckets) >= 3 and len(red._hooked) == len(red.buckets)
+    x = torch.randn(4, 6)
+    outs = []
+    for step in range(2):
+        buf.zero_grad()
+        h = x
+        for l in layers:
+            h = torch.tanh(l(h))
+        h.pow(2).sum().backward()
+        early = red._next
+        red.finish()
+        outs.append((early, buf.flat_grad.clone()))
+    h = x
+    for l in layers:
+        h = torch.tanh(l(h))
+    ref = torch.autograd.grad(h.pow(2).sum(), buf.params)
+    err = max(float((buf.grad_views[i] - ref[i]).abs().max()) for i in range(len(buf.params)))
+    q.put((outs[0][0], outs[1][0], len(red.buckets), bool(torch.equal(outs[0][1], outs[1][1])), err))
+    dist.destroy_process_group()
+
+
+def test_reducer_with_one_hook_per_bucket_and_an_unexpected_arrival_order():
+    """Hooks sit on a few parameters per bucket; when the gradients do not arrive in reverse storage order some buckets cannot leave
+    from a hook — they leave in finish().  Whatever the order: every bucket is reduced exactly once and the gradients are complete."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_odd_order_worker, args=(port, q))
+    p.start()
+    early1, early2, nb, same, err = q.get(timeout=120)
+    p.join(60)
+    assert p.exitcode == 0
+    assert 0 <= early1 <= nb and early1 == early2 and same and err < 1e-6
