@@ -832,7 +832,9 @@ class _Conv1dCLFn(torch.autograd.Function):
         B, Lin, Cin = x.shape
         Cout = w_cl.shape[0]
         if pad:
-            xp = torch.zeros(B, Lin + 2 * pad, Cin, dtype=x.dtype, device=x.device)
+            xp = torch.empty(B, Lin + 2 * pad, Cin, dtype=x.dtype, device=x.device)  # (only the pad rows are zero-filled, not the whole buffer)
+            xp[:, :pad].zero_()
+            xp[:, pad + Lin:].zero_()
             xp[:, pad:pad + Lin] = x
         elif x.stride(2) == 1 and x.stride(1) == Cin:
             xp = x  # contiguous or an interior view of a row-padded allocation: only the batch stride differs
@@ -966,7 +968,9 @@ class _PosConvFn(torch.autograd.Function):
         Tp = T + k - 1 + (1 if k % 2 == 0 else 0)  # even k: torch pads k//2 both sides, SamePad drops the last output
         # [G, B, Tp, C/G]: group-major OUTSIDE the batch, so that one group's frames of all utterances are one [B * Tp, C/G] matrix
         # (the weight-gradient GEMM below runs over it with K = every frame of the batch)
-        xg = torch.zeros(groups, B, Tp, cg, dtype=x.dtype, device=x.device)
+        xg = torch.empty(groups, B, Tp, cg, dtype=x.dtype, device=x.device)  # (zero rows around the frames: only those are filled)
+        xg[:, :, :padl].zero_()
+        xg[:, :, padl + T:].zero_()
         xg[:, :, padl:padl + T] = x.view(B, T, groups, cg).permute(2, 0, 1, 3)
         wg = weight.view(groups, cg, cg, k).permute(0, 1, 3, 2).contiguous()  # [g][co][j][ci]
         y = torch.empty(B, T, C, dtype=x.dtype, device=x.device)
@@ -990,7 +994,9 @@ class _PosConvFn(torch.autograd.Function):
         lp = k - 1 - padl
         dzg = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            dzg = torch.zeros(groups, B, Tp, cg, dtype=dy.dtype, device=dy.device)
+            dzg = torch.empty(groups, B, Tp, cg, dtype=dy.dtype, device=dy.device)
+            dzg[:, :, :lp].zero_()
+            dzg[:, :, lp + T:].zero_()
             dzg[:, :, lp:lp + T] = dz.view(B, T, groups, cg).permute(2, 0, 1, 3)
         if ctx.needs_input_grad[0]:
             # dx[m] = dy[m] + sum_j dz[m + padl - j] w_j  = dy[m] + sum_j' dzp[m + j'] wflip[j'],  dzp[(k-1-padl) + t] = dz[t]
