@@ -13,7 +13,7 @@ STATS = {}  # light counters for tests / tools (e.g. how many GEMM launches carr
 
 def workspace(nbytes: int, device) -> torch.Tensor:
     """Grow-only scratch buffer, stream-ordered reuse (all product kernels run on the current stream)."""
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    key = (device.index, L.stream_ptr().value)  # (the raw-stream getter: torch.cuda.current_stream() costs ~20 us of Python per call)
     t = _ws.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -38,11 +38,13 @@ class _Deferred:
         self.main = None   # the stream the flush runs on (set when the mode is entered)
         self.side = None   # side stream of the small weight-gradient GEMMs (side_gemm), created on first use
         self.side_used = False
+        self.poison = False
 
     def push(self, src_ptr, dst, stride, Lr, P, keep, order=0):
-        if os.environ.get("CST_DEFER_POISON"):
+        if self.poison:
             dst.fill_(float("nan"))
-        if self.main is not None and torch.is_tensor(keep) and torch.cuda.current_stream() != self.main:
+        # (side-stream launches only — torch.cuda.current_stream() costs ~20 us of Python, 320 pushes per update: never in the default path)
+        if self.side_used and torch.is_tensor(keep) and torch.cuda.current_stream() != self.main:
             keep.record_stream(self.main)  # allocated on the side stream's pool, read by the flush on the main stream
         self.items.append((src_ptr, dst.data_ptr(), stride, Lr, P, L.dtype_code(dst.dtype), order))
         # (an ALIAS of dst keeps its storage alive: holding dst itself would raise its reference count, and AccumulateGrad only adopts
@@ -88,6 +90,7 @@ class deferred_reductions:
         if self.enabled:
             DEFER.on += 1
             DEFER.main = torch.cuda.current_stream()
+            DEFER.poison = bool(os.environ.get("CST_DEFER_POISON"))
         return self
 
     def __exit__(self, *exc):
@@ -114,12 +117,12 @@ def side_gemm(big, reads, *args, **kw):
         DEFER.side = torch.cuda.Stream()
     side = DEFER.side
     side.wait_stream(DEFER.main)  # the operands are the latest things queued on the main stream
+    DEFER.side_used = True        # (before the launch: the pushes inside gemm() look at it)
     with torch.cuda.stream(side):
         out = gemm(*args, **kw)
     for t in reads:
         if t is not None:
             t.record_stream(side)
-    DEFER.side_used = True
     STATS["side_gemm"] = STATS.get("side_gemm", 0) + 1
     return out
 
