@@ -151,17 +151,45 @@ class Trainer:
             assert logs, "out of memory before any update completed and the criterion does not declare logging_keys()"
             self._log_keys = sorted(logs[0].keys())
         keys = self._log_keys
-        zero = torch.zeros((), dtype=torch.float64, device=self.device)
-        stats = [sum((torch.as_tensor(l[k], dtype=torch.float64, device=self.device) for l in logs), zero) for k in keys]
         late = list(self.model.reducer.late_params) if self.ddp else []
+        # layout: [one slot per logging key | OOM flag | late-gradient count | one gradient-norm slot per rank].  Host-side numbers
+        # (token / sentence counts, the flags) travel in ONE pinned buffer, copied asynchronously — a Python scalar turned into a
+        # device tensor is a pageable copy, i.e. a stream synchronisation each (five per update until round 4: the gradient-norm
+        # kernel and this vector's assembly were then enqueued on an idle GPU); device-side numbers (losses, the gradient's sum of
+        # squares) are scattered into their slots by one kernel.
+        nk = len(keys)
+        n = nk + 2 + self.world
+        host = getattr(self, "_stat_host", None)
+        if host is None or host.numel() != n:
+            host = torch.zeros(n, dtype=torch.float64)
+            self._stat_host = host = host.pin_memory() if self.device.type == "cuda" else host
+        host.zero_()
+        dev_idx, dev_val = [], []
+        for i, k in enumerate(keys):
+            parts = [l[k] for l in logs]
+            if any(torch.is_tensor(v) for v in parts):
+                dev_idx.append(i)
+                dev_val.append(sum((v.to(torch.float64) if torch.is_tensor(v) else v for v in parts)))
+            else:
+                host[i] = float(sum(parts))
+        host[nk], host[nk + 1] = float(ooms), float(len(late))
+
+        def assemble():
+            vec = host.to(self.device, non_blocking=True) if self.device.type == "cuda" else host.clone()
+            idx = dev_idx + [nk + 2 + self.rank]
+            val = dev_val + [self.optimizer.grad_sumsq()[0].double()]
+            cache = getattr(self, "_stat_idx", None)
+            if cache is None or cache[0] != idx:
+                cache = self._stat_idx = (idx, torch.tensor(idx, dtype=torch.int64).to(self.device))
+            vec[cache[1]] = torch.stack([v.reshape(()).to(self.device) for v in val])
+            return vec
 
         def norm_slots():
             slots = torch.zeros(self.world, dtype=torch.float64, device=self.device)
             slots[self.rank] = self.optimizer.grad_sumsq()[0].double()
             return slots
 
-        vec = torch.cat([torch.stack(stats), torch.tensor([float(ooms), float(len(late))], dtype=torch.float64, device=self.device),
-                         norm_slots()])
+        vec = assemble()
         if self.ddp:
             dist.all_reduce(vec)
         vals = vec.tolist()  # the step's only host sync
