@@ -1382,3 +1382,34 @@ def test_gemm8p_half_height_tail_items_keep_the_bits(K, M, N, K_, epi):
         assert torch.equal(outs[0][1], outs[1][1])
     if epi == "plain":
         check(outs[0][0], A.float() @ B.float().t(), dt, "half-height tail items")
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("drop", [0.0, 0.1])
+def test_attention_kv_packed_projection_equals_separate_k_and_v(K, dt, drop):
+    """functional.attention_kv (k | v as the two channel halves of ONE projection; dk | dv written into one buffer) against
+    functional.attention on separate k and v tensors: the same kernels on the same values through different strides — outputs and
+    all gradients bit for bit, with a key padding mask and with probability dropout (the mask depends on (row, key) only)."""
+    from importlib import import_module
+    CF = import_module("chimera-st_amd.functional")
+    rng = import_module("chimera-st_amd.rng")
+    B, Tq, Tk, H, D = 3, 40, 150, 4, 64
+    C = H * D
+    q0, kv0 = rnd(B, Tq, C, dt=dt, seed=81), rnd(B, Tk, 2 * C, dt=dt, seed=82)
+    do = rnd(B, Tq, C, dt=dt, seed=83)
+    lens = torch.tensor([150, 97, 64])
+    kpm = (torch.arange(Tk)[None] >= lens[:, None]).cuda()
+    outs = []
+    for packed in (True, False):
+        rng.reseed(7)
+        q = q0.clone().requires_grad_(True)
+        kv = kv0.clone().requires_grad_(True)
+        if packed:
+            o = CF.attention_kv(q, kv, H, kpm, dropout_p=drop)
+        else:
+            k, v = kv[..., :C].contiguous(), kv[..., C:].contiguous()
+            o = CF.attention(q, k, v, H, kpm, dropout_p=drop)
+        gq, gkv = torch.autograd.grad(o, (q, kv), do)
+        outs.append((o.detach(), gq, gkv))
+    for a, b, name in zip(outs[0], outs[1], ("o", "dq", "dkv")):
+        assert torch.equal(a, b), name

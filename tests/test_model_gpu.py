@@ -437,3 +437,35 @@ def test_padding_free_wav2vec2_stack_is_bit_identical(kind, fixture, dtype):
             scale = max(scale, float(grads_d[n[:-5] + ".weight"].float().abs().max()))
         err = float((a - b).abs().max()) / max(scale, 1e-30)
         assert err <= tol, "gradient %s: %.3e of its largest entry" % (n, err)
+
+
+def test_triplet_passes_as_one_walk_equal_the_two_separate_passes():
+    """TripletSTMTContrastiveCriterion on the Chimera fixture: the default route — both passes through the shared encoder layers as
+    one packed row set, the memory layers on both modalities at once, one decoder call on 2B rows — against the reference-shaped
+    route of two forward_with_internal calls (CST_NO_PAIR_DECODER=1): same losses (1e-5), same logits-derived terms, every
+    gradient within 1e-4 of its tensor's largest entry (the two routes reduce the weight gradients over differently ordered rows)."""
+    g = load_golden("chimera_tiny.npz")
+    crit_mod = import_module("chimera-st_amd.criterions")
+    sample = to_cuda(golden_sample(g))
+    res = []
+    for env in ("", "1"):
+        if env:
+            os.environ["CST_NO_PAIR_DECODER"] = "1"
+        try:
+            model, task, args = build_from_golden(g, "chimera", torch.float32)
+            crit = crit_mod.TripletSTMTContrastiveCriterion(task, False, 0.1, [1.0, 1.0, 1.0], 0.1)
+            model.train()
+            loss, ss, log = crit(model, sample)
+            loss.backward()
+            res.append((float(loss), {k: float(v) for k, v in log.items() if torch.is_tensor(v)},
+                        {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+        finally:
+            os.environ.pop("CST_NO_PAIR_DECODER", None)
+    (l1, log1, g1), (l2, log2, g2) = res
+    assert abs(l1 - l2) <= 1e-5 * abs(l2)
+    for k in ("st_loss", "mt_loss", "contrastive_loss"):
+        assert abs(log1[k] - log2[k]) <= 1e-5 * abs(log2[k]) + 1e-6, k
+    assert g1.keys() == g2.keys()
+    for n in g1:
+        err = float((g1[n] - g2[n]).abs().max()) / max(1.0, float(g2[n].abs().max()))
+        assert err <= 1e-4, "%s: %.3e" % (n, err)
