@@ -773,14 +773,18 @@ extern "C" int cst_attn_bwd(const cst_attn_desc* d, cst_stream stream) {
   if (attn_fast_bwd_ok(d)) {
     const int64_t Tq64 = cst_ceil_div(d->Tq, 64) * 64;
     float* ws = (float*)d->bwd_ws;
-    hipLaunchKernelGGL(fa_delta_kernel, dim3((unsigned)(Tq64 / 64), (unsigned)d->H, (unsigned)d->B), dim3(64), 0, s, p, ws, Tq64);
+    // (no pre-pass launch: the dQ kernel computes delta / -lse2 / the live-tile flags of its own 128 queries and leaves them in `ws` /
+    //  q_flags for the dK / dV kernel behind it; CST_ATTN_DELTA_PASS=1 keeps the separate launch in front for A/B runs — the dQ kernel
+    //  then rewrites the same values)
+    static const bool delta_pass = getenv("CST_ATTN_DELTA_PASS") != nullptr;
+    if (delta_pass) hipLaunchKernelGGL(fa_delta_kernel, dim3((unsigned)(Tq64 / 64), (unsigned)d->H, (unsigned)d->B), dim3(64), 0, s, p, ws, Tq64);
     const unsigned nq = fa_grid(d->Tq, d->B, d->H), nk = fa_grid(d->Tk, d->B, d->H);
-    const size_t lds_q = FA_NSLOT * FA_SLOT + 8 * (size_t)cst_ceil_div(d->Tk, 64) + (p.drop_thr ? 4096 : 0), lds_k = FA_NSLOT * (FA_SLOT + FA_STATS);
+    const size_t lds_q = FA_NSLOT * FA_SLOT + 8 * (size_t)cst_ceil_div(d->Tk, 64) + (p.drop_thr ? 4096 : 0) + 16, lds_k = FA_NSLOT * (FA_SLOT + FA_STATS);
     if (p.drop_thr) {
-      hipLaunchKernelGGL((fa_dq_kernel<true>), dim3(nq), dim3(256), lds_q, s, p, (const float*)ws, Tq64);
+      hipLaunchKernelGGL((fa_dq_kernel<true>), dim3(nq), dim3(256), lds_q, s, p, ws, Tq64);
       hipLaunchKernelGGL((fa_dkv_kernel<true>), dim3(nk), dim3(256), lds_k, s, p, (const float*)ws, Tq64);
     } else {
-      hipLaunchKernelGGL((fa_dq_kernel<false>), dim3(nq), dim3(256), lds_q, s, p, (const float*)ws, Tq64);
+      hipLaunchKernelGGL((fa_dq_kernel<false>), dim3(nq), dim3(256), lds_q, s, p, ws, Tq64);
       hipLaunchKernelGGL((fa_dkv_kernel<false>), dim3(nk), dim3(256), lds_k, s, p, (const float*)ws, Tq64);
     }
     return cst_check_launch("cst_attn_bwd");

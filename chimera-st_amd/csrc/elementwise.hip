@@ -368,7 +368,8 @@ extern "C" int64_t cst_colsum_workspace(int64_t rows, int64_t cols) {
 
 static int colsum_typed_impl(const void* x, int64_t ldx, void* out, void* workspace, int64_t rows, int64_t cols, int dtype,
                              int out_dtype, const uint32_t* row_live, uint32_t epoch, cst_stream stream) {
-  CST_REQUIRE(x && out && workspace && rows > 0 && cols > 0 && cols % 8 == 0 && ldx % 8 == 0, "cst_colsum_typed: cols/ldx must be multiples of 8");
+  // out == NULL: the row-chunk partials stay in `workspace` ([cst_colsum_workspace / (4 cols)][cols] fp32) for cst_reduce_multi, order 1
+  CST_REQUIRE(x && workspace && rows > 0 && cols > 0 && cols % 8 == 0 && ldx % 8 == 0, "cst_colsum_typed: cols/ldx must be multiples of 8");
   CST_REQUIRE((dtype == CST_F32 || dtype == CST_BF16) && (out_dtype == CST_F32 || out_dtype == CST_BF16), "cst_colsum_typed: bad dtype");
   hipStream_t s = (hipStream_t)stream;
   CstProfScope prof(CST_K_ELEMENTWISE, s, 0.0, (double)rows * cols * cst_dtype_size(dtype));
@@ -378,6 +379,7 @@ static int colsum_typed_impl(const void* x, int64_t ldx, void* out, void* worksp
   float* part = (float*)workspace;
   if (dtype == CST_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)x, ldx, part, rows, cols, rows_per, row_live, epoch);
   else hipLaunchKernelGGL((colsum_kernel<float, true>), grid, dim3(256), 0, s, (const float*)x, ldx, part, rows, cols, rows_per, row_live, epoch);
+  if (!out) return cst_check_launch("cst_colsum_typed");
   const dim3 rgrid((unsigned)cst_ceil_div(cols, 16));
   if (out_dtype == CST_BF16) hipLaunchKernelGGL(colsum_reduce_kernel<bf16_t>, rgrid, dim3(1024), 0, s, (const float*)part, (bf16_t*)out, (int)nchunks, cols);
   else hipLaunchKernelGGL(colsum_reduce_kernel<float>, rgrid, dim3(1024), 0, s, (const float*)part, (float*)out, (int)nchunks, cols);
@@ -386,7 +388,7 @@ static int colsum_typed_impl(const void* x, int64_t ldx, void* out, void* worksp
 
 extern "C" int cst_dropout_colsum(const void* x, void* xd, void* out, void* workspace, int64_t rows, int64_t cols, int dtype, int out_dtype,
                                   float p, uint32_t key, const uint32_t* row_live, uint32_t epoch, cst_stream stream) {
-  CST_REQUIRE(x && xd && out && workspace && rows > 0 && cols > 0 && cols % 8 == 0, "cst_dropout_colsum: cols must be a multiple of 8");
+  CST_REQUIRE(x && xd && workspace && rows > 0 && cols > 0 && cols % 8 == 0, "cst_dropout_colsum: cols must be a multiple of 8");
   CST_REQUIRE((dtype == CST_F32 || dtype == CST_BF16) && (out_dtype == CST_F32 || out_dtype == CST_BF16), "cst_dropout_colsum: bad dtype");
   CST_REQUIRE(p > 0.0f && p < 1.0f, "cst_dropout_colsum: p must be in (0, 1)");
   CST_REQUIRE(!row_live || epoch != 0, "cst_dropout_colsum: stamps need a non-zero epoch");
@@ -400,6 +402,7 @@ extern "C" int cst_dropout_colsum(const void* x, void* xd, void* out, void* work
   const float scale = 1.0f / (1.0f - p);
   if (dtype == CST_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t, true, true>), grid, dim3(256), 0, s, (const bf16_t*)x, cols, part, rows, cols, rows_per, row_live, epoch, (bf16_t*)xd, key, thr, scale);
   else hipLaunchKernelGGL((colsum_kernel<float, true, true>), grid, dim3(256), 0, s, (const float*)x, cols, part, rows, cols, rows_per, row_live, epoch, (float*)xd, key, thr, scale);
+  if (!out) return cst_check_launch("cst_dropout_colsum");  // partials left for cst_reduce_multi (order 1), as in cst_colsum_typed
   const dim3 rgrid((unsigned)cst_ceil_div(cols, 16));
   if (out_dtype == CST_BF16) hipLaunchKernelGGL(colsum_reduce_kernel<bf16_t>, rgrid, dim3(1024), 0, s, (const float*)part, (bf16_t*)out, (int)nchunks, cols);
   else hipLaunchKernelGGL(colsum_reduce_kernel<float>, rgrid, dim3(1024), 0, s, (const float*)part, (float*)out, (int)nchunks, cols);
@@ -681,13 +684,14 @@ extern "C" int cst_transpose2d_multi(const cst_transpose_item* items_dev, int n,
 // update mixes the routes: its first micro-batch may be deferred, the later ones add into an existing gradient and are not):
 //   order 0  p = 0, 1, 2, ... one after the other                 (splitk_reduce_kernel of gemm.hip; its bias-gradient slices)
 //   order 1  64 interleaved chains p = g, g + 64, ..., then the chains 0..63 one after the other   (ln_bwd_reduce_kernel)
-// Blocks of 1024 threads: order 0 — 8 consecutive elements per thread; order 1 — 16 columns x 64 chains, as layernorm.hip lays it out.
+// Blocks of 1024 threads: order 0 — 8 consecutive elements per thread; order 1 — 64 columns (16 lanes x 4) x 64 chains: the per-column
+// order of layernorm.hip's / colsum's second stage, with 16-byte loads.
 // ---------------------------------------------------------------------------------------------------------------------------------
 namespace {
 struct ReduceTable { cst_reduce_item it[CST_REDUCE_MAX_ITEMS]; int n; };
 
 __global__ __launch_bounds__(1024) void reduce_multi_kernel(ReduceTable t) {
-  __shared__ float ra[64][17];
+  __shared__ float ra[64][65];
   const int b = blockIdx.x;
   int lo = 0, hi = t.n - 1;
   while (lo < hi) {  // last item whose first block is <= b (uniform)
@@ -723,18 +727,37 @@ __global__ __launch_bounds__(1024) void reduce_multi_kernel(ReduceTable t) {
     else store8((float*)it.dst + i0, v);
     return;
   }
+  // order 1: 64 columns per block — 16 lanes x 4 consecutive columns (one 16-byte load each: 256-byte row segments) x 64 chains
   const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
-  const int64_t c = blk * 16 + cl;
-  float a = 0.0f;
-  if (c < it.L)
-    for (int i = g; i < it.P; i += 64) a += it.src[(int64_t)i * it.stride + c];
-  ra[g][cl] = a;
+  const int64_t c = blk * 64 + cl * 4;
+  f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (c < it.L) {
+    const float* src = it.src + c;
+    int i = g;
+    for (; i + 192 < it.P; i += 256) {  // four loads of this chain in flight, added in chain order
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + (int64_t)i * it.stride), v1 = *reinterpret_cast<const f32x4*>(src + (int64_t)(i + 64) * it.stride);
+      const f32x4 v2 = *reinterpret_cast<const f32x4*>(src + (int64_t)(i + 128) * it.stride), v3 = *reinterpret_cast<const f32x4*>(src + (int64_t)(i + 192) * it.stride);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] = (((a[e] + v0[e]) + v1[e]) + v2[e]) + v3[e];
+    }
+    for (; i < it.P; i += 64) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + (int64_t)i * it.stride);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] += v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) ra[g][cl * 4 + e] = a[e];
   __syncthreads();
-  if (g == 0 && c < it.L) {
+  if (threadIdx.x < 64) {
+    const int64_t cc = blk * 64 + threadIdx.x;
+    if (cc < it.L) {
+      float t = ra[0][threadIdx.x];
 #pragma unroll 8
-    for (int k = 1; k < 64; ++k) a += ra[k][cl];
-    if (it.dst_dtype == CST_BF16) DT<bf16_t>::st((bf16_t*)it.dst + c, a);
-    else ((float*)it.dst)[c] = a;
+      for (int k = 1; k < 64; ++k) t += ra[k][threadIdx.x];
+      if (it.dst_dtype == CST_BF16) DT<bf16_t>::st((bf16_t*)it.dst + cc, t);
+      else ((float*)it.dst)[cc] = t;
+    }
   }
 }
 }  // namespace
@@ -751,7 +774,7 @@ extern "C" int cst_reduce_multi(const cst_reduce_item* items, int n, cst_stream 
     CST_REQUIRE((it.dst_dtype == CST_F32 || it.dst_dtype == CST_BF16) && (it.order == 0 || it.order == 1), "cst_reduce_multi: item %d: bad dst_dtype / order", i);
     t.it[i] = it;
     t.it[i].block0 = (int32_t)blocks;
-    blocks += it.order == 0 ? cst_ceil_div(it.L, 8192) : cst_ceil_div(it.L, 16);
+    blocks += it.order == 0 ? cst_ceil_div(it.L, 8192) : cst_ceil_div(it.L, 64);
     bytes += (double)it.L * ((double)it.P * 4.0 + cst_dtype_size(it.dst_dtype));
   }
   CST_REQUIRE(blocks < (1ll << 31), "cst_reduce_multi: too many blocks");

@@ -186,6 +186,7 @@ class _LinearFn(torch.autograd.Function):
         M, Kd = x2.shape
         N = weight.shape[0]
         w = weight if weight.is_contiguous() else weight.contiguous()
+        ctx.bias_obj = bias  # (the Parameter / stacked view itself: _may_defer looks at its .grad and marks in backward)
         # odd output widths (e.g. a 60-symbol test vocabulary in bf16): zero-pad the rows of W up to the 16-byte vector
         # the dX / dW loaders need; real shapes (512/768/1024/2048/3072/10000) never take this branch.
         Np = (N + _vec(x.dtype) - 1) // _vec(x.dtype) * _vec(x.dtype)
@@ -234,10 +235,11 @@ def _linear_backward(ctx, dy, dxp):
     want_db = ctx.has_bias and ctx.needs_input_grad[2]
     # the bias gradient rides in the weight-gradient GEMM when that GEMM's kernel builds it for free (cst_gemm_desc.colsum)
     db_in_dw = want_db and ctx.needs_input_grad[1] and Np % 8 == 0 and not _os.environ.get("CST_NO_GEMM_COLSUM") and K.dw_colsum_is_fused(Np, Kd, M, w.dtype)
+    may_b = want_db and Np == N and _may_defer(w, ctx.bias_obj)  # the bias gradient's second stage may wait for the flush
     if ctx.drop[0] > 0.0:  # gradient of the dropped branch: the same mask, regenerated
         dyc = dy2 if dy2.is_contiguous() else dy2.contiguous()
         if not db_in_dw and ctx.act == L.ACT_NONE and want_db and Np == N and N % 8 == 0 and not _os.environ.get("CST_NO_DROP_COLSUM"):
-            dy2, db_fused = K.dropout_colsum(dyc, ctx.drop[0], ctx.drop[1], w.dtype, live)  # mask + bias gradient in one pass
+            dy2, db_fused = K.dropout_colsum(dyc, ctx.drop[0], ctx.drop[1], w.dtype, live, defer=may_b)  # mask + bias gradient in one pass
         else:
             dy2 = K.dropout(dyc, *ctx.drop)
     dz = K.act_bwd(dy2, z, ctx.act) if ctx.act != L.ACT_NONE else dy2
@@ -262,7 +264,7 @@ def _linear_backward(ctx, dy, dxp):
             dw = torch.empty(Np, Kd, dtype=w.dtype, device=w.device)
         if db_in_dw:
             db = torch.empty(Np, dtype=w.dtype, device=w.device)
-        may = Np == N and _may_defer(w)
+        may = Np == N and _may_defer(w, ctx.bias_obj if db_in_dw else None)
         # (a small layer's weight gradient runs on the side stream, off the dX chain — kernels.side_gemm; not when dz IS the incoming
         #  gradient that also travels on as the residual gradient: something upstream might add into it in place)
         big = not may or not K.dw_colsum_is_fused(Np, Kd, M, w.dtype) or (dz.data_ptr() == dy.data_ptr() and ctx.has_resid)
@@ -272,7 +274,7 @@ def _linear_backward(ctx, dy, dxp):
         if db is not None:
             db = db[:N]
     if want_db and db is None:
-        db = db_fused if db_fused is not None else K.colsum(dz, w.dtype, live)[:N]
+        db = db_fused if db_fused is not None else K.colsum(dz, w.dtype, live, defer=may_b)[:N]
     if ctx.has_resid and ctx.needs_input_grad[3]:
         dres = dy
     return dx, dw, db, dres, None, None, None
@@ -329,6 +331,7 @@ class _FFNFn(torch.autograd.Function):
         ctx.res_is_x = (resid is not None and resid.data_ptr() == x.data_ptr() and resid.shape == x.shape
                         and resid.stride() == x.stride() and dout == d)
         ctx.drop = (p_act, key_act, p_out, key_out)
+        ctx.bias_objs = (b1, b2)
         return y.view(*x.shape[:-1], dout)
 
     @staticmethod
@@ -340,6 +343,7 @@ class _FFNFn(torch.autograd.Function):
         dy2 = _flat2d(dy)
         live = _tiles_of(dy, M)  # zero rows of dy are zero rows of dy2 (mask) and of dz1 (row-wise GEMM, act', mask)
         p_act, key_act, p_out, key_out = ctx.drop
+        b1, b2 = ctx.bias_objs
         db2_fused = None
         gcs = not _os.environ.get("CST_NO_GEMM_COLSUM")
         db2_in_dw = gcs and has_b2 and ctx.needs_input_grad[4] and ctx.needs_input_grad[3] and dout % 8 == 0 and K.dw_colsum_is_fused(dout, F_, M, w2.dtype)
@@ -347,7 +351,7 @@ class _FFNFn(torch.autograd.Function):
         if p_out > 0.0:  # d(fc2 output) = dy * mask_out
             dyc = dy2 if dy2.is_contiguous() else dy2.contiguous()
             if not db2_in_dw and has_b2 and ctx.needs_input_grad[4] and dout % 8 == 0 and not _os.environ.get("CST_NO_DROP_COLSUM"):
-                dy2, db2_fused = K.dropout_colsum(dyc, p_out, key_out, w2.dtype, live)  # mask + fc2 bias gradient in one pass
+                dy2, db2_fused = K.dropout_colsum(dyc, p_out, key_out, w2.dtype, live, defer=_may_defer(w2, b2))  # mask + fc2 bias gradient in one pass
             else:
                 dy2 = K.dropout(dyc, p_out, key_out)
         dz1 = torch.empty(M, F_, dtype=dy2.dtype, device=dy2.device)
@@ -365,12 +369,12 @@ class _FFNFn(torch.autograd.Function):
                 dw2 = torch.empty(dout, F_, dtype=w2.dtype, device=w2.device)
             if db2_in_dw:
                 db2 = torch.empty(dout, dtype=w2.dtype, device=w2.device)
-            may2 = _may_defer(w2)
+            may2 = _may_defer(w2, b2 if db2_in_dw else None)
             big2 = not may2 or not K.dw_colsum_is_fused(dout, F_, M, w2.dtype) or (dy2.data_ptr() == dy.data_ptr() and has_res)
             K.side_gemm(big2, (dy2, h, live[0] if live is not None else None), dy2, h, dw2, dout, F_, M, a_kmajor=0, b_kmajor=0, lda=dout, ldb=F_,
                         ldc=F_, split_k=-1, k_live=live, colsum=db2, defer=may2)
         if has_b2 and ctx.needs_input_grad[4] and db2 is None:
-            db2 = db2_fused if db2_fused is not None else K.colsum(dy2, w2.dtype, live)
+            db2 = db2_fused if db2_fused is not None else K.colsum(dy2, w2.dtype, live, defer=_may_defer(w2, b2))
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, d, dtype=x2.dtype, device=x2.device)
             if wt:
@@ -386,12 +390,12 @@ class _FFNFn(torch.autograd.Function):
                 dw1 = torch.empty(F_, d, dtype=w1.dtype, device=w1.device)
             if db1_in_dw:
                 db1 = torch.empty(F_, dtype=w1.dtype, device=w1.device)
-            may1 = _may_defer(w1)
+            may1 = _may_defer(w1, b1 if db1_in_dw else None)
             big1 = not may1 or not K.dw_colsum_is_fused(F_, d, M, w1.dtype)
             K.side_gemm(big1, (dz1, x2, live[0] if live is not None else None), dz1, x2, dw1, F_, d, M, a_kmajor=0, b_kmajor=0, lda=F_, ldb=d,
                         ldc=d, split_k=-1, k_live=live, colsum=db1, defer=may1)
         if has_b1 and ctx.needs_input_grad[2] and db1 is None:
-            db1 = K.colsum(dz1, w1.dtype, live)
+            db1 = K.colsum(dz1, w1.dtype, live, defer=_may_defer(w1, b1))
         dres = dy if has_res and ctx.needs_input_grad[5] and not (ctx.res_is_x and ctx.needs_input_grad[0]) else None
         return dx, dw1, db1, dw2, db2, dres, None, None, None, None, None
 

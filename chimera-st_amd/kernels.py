@@ -531,39 +531,49 @@ def act_fwd(x, act):
     return y
 
 
-def colsum(x, out_dtype=torch.float32, live=None):
+def colsum(x, out_dtype=torch.float32, live=None, defer=False):
     """Column sums (bias gradients) in `out_dtype`: row-chunk fp32 partials + a fixed-order reduce that writes the parameter
     dtype (cst_colsum_typed) — deterministic, and two launches where the atomics version needs three (zero-fill, kernel, dtype
     conversion).  (A single-launch variant with a last-arriving-block finalize was measured earlier: the agent-scope release
-    every workgroup needs before its ticket made it slower, elementwise 4.4 -> 7.4 ms per update.)"""
+    every workgroup needs before its ticket made it slower, elementwise 4.4 -> 7.4 ms per update.)
+    defer: the caller allows the second stage to wait for the deferred-reduction flush (the result is a parameter gradient)."""
     x = _2d(x)
     rows, cols = x.shape
     lib = L.load()
     out = torch.empty(cols, dtype=out_dtype, device=x.device)
-    ws = workspace(lib.cst_colsum_workspace(rows, cols), x.device)
+    wbytes = lib.cst_colsum_workspace(rows, cols)
+    defer = bool(defer) and DEFER.on > 0
+    ws = torch.empty(wbytes, dtype=torch.uint8, device=x.device) if defer else workspace(wbytes, x.device)
+    po = None if defer else L.ptr(out)
     if live is not None:  # (stamps, epoch) of x's 64-row tiles: dead tiles are all zero and skipped
         assert live[0].numel() * 64 >= rows
-        L.check(lib.cst_colsum_typed_live(L.ptr(x), x.stride(0), L.ptr(out), L.ptr(ws), rows, cols, L.dtype_code(x.dtype),
+        L.check(lib.cst_colsum_typed_live(L.ptr(x), x.stride(0), po, L.ptr(ws), rows, cols, L.dtype_code(x.dtype),
                                           L.dtype_code(out_dtype), L.ptr(live[0]), live[1], L.stream_ptr()), "cst_colsum_typed_live")
-        return out
-    L.check(lib.cst_colsum_typed(L.ptr(x), x.stride(0), L.ptr(out), L.ptr(ws), rows, cols, L.dtype_code(x.dtype), L.dtype_code(out_dtype),
-                                 L.stream_ptr()), "cst_colsum_typed")
+    else:
+        L.check(lib.cst_colsum_typed(L.ptr(x), x.stride(0), po, L.ptr(ws), rows, cols, L.dtype_code(x.dtype), L.dtype_code(out_dtype),
+                                     L.stream_ptr()), "cst_colsum_typed")
+    if defer:  # partials: fp32 [chunks][cols], the order of colsum_reduce_kernel = order 1 of cst_reduce_multi
+        DEFER.push(ws.data_ptr(), out, cols, cols, wbytes // (4 * cols), ws, order=1)
     return out
 
 
-def dropout_colsum(x, p, key, out_dtype=torch.float32, live=None):
+def dropout_colsum(x, p, key, out_dtype=torch.float32, live=None, defer=False):
     """(x * mask / (1 - p), column sums of that) in one pass (cst_dropout_colsum): the masked gradient of a dropped Linear output and
-    its bias gradient.  Same bits as dropout() followed by colsum()."""
+    its bias gradient.  Same bits as dropout() followed by colsum().  defer: as in colsum()."""
     x = _2d(x)
     assert x.is_contiguous()
     rows, cols = x.shape
     lib = L.load()
     xd = torch.empty_like(x)
     out = torch.empty(cols, dtype=out_dtype, device=x.device)
-    ws = workspace(lib.cst_colsum_workspace(rows, cols), x.device)
-    L.check(lib.cst_dropout_colsum(L.ptr(x), L.ptr(xd), L.ptr(out), L.ptr(ws), rows, cols, L.dtype_code(x.dtype), L.dtype_code(out_dtype),
-                                   float(p), int(key) & 0xFFFFFFFF, L.ptr(live[0]) if live is not None else None,
+    wbytes = lib.cst_colsum_workspace(rows, cols)
+    defer = bool(defer) and DEFER.on > 0
+    ws = torch.empty(wbytes, dtype=torch.uint8, device=x.device) if defer else workspace(wbytes, x.device)
+    L.check(lib.cst_dropout_colsum(L.ptr(x), L.ptr(xd), None if defer else L.ptr(out), L.ptr(ws), rows, cols, L.dtype_code(x.dtype),
+                                   L.dtype_code(out_dtype), float(p), int(key) & 0xFFFFFFFF, L.ptr(live[0]) if live is not None else None,
                                    live[1] if live is not None else 0, L.stream_ptr()), "cst_dropout_colsum")
+    if defer:
+        DEFER.push(ws.data_ptr(), out, cols, cols, wbytes // (4 * cols), ws, order=1)
     return xd, out
 
 

@@ -311,7 +311,10 @@ int cst_colsum(const void* x, int64_t ldx, float* out, int64_t rows, int64_t col
 int cst_dropout_colsum(const void* x, void* xd, void* out, void* workspace, int64_t rows, int64_t cols, int dtype, int out_dtype,
                        float p, uint32_t key, const uint32_t* row_live, uint32_t epoch, cst_stream stream);
 /* the same sums without atomics: row-chunk partials in `workspace` (cst_colsum_workspace bytes), reduced in a fixed order and
- * written in `out_dtype` (the bias parameter's dtype) — deterministic, no zero-fill and no conversion launch around it */
+ * written in `out_dtype` (the bias parameter's dtype) — deterministic, no zero-fill and no conversion launch around it.
+ * out == NULL (here, in cst_colsum_typed_live and in cst_dropout_colsum): the second stage is left to the caller — the partials stay in
+ * `workspace` as fp32 [cst_colsum_workspace / (4 cols)][cols], to be finished by cst_reduce_multi with order 1 (same summation order,
+ * same bits), together with the other deferred reductions of a backward pass. */
 int64_t cst_colsum_workspace(int64_t rows, int64_t cols);
 int cst_colsum_typed(const void* x, int64_t ldx, void* out, void* workspace, int64_t rows, int64_t cols, int dtype, int out_dtype,
                      cst_stream stream);

@@ -293,6 +293,7 @@ def test_attention_kv_len_skip_is_bit_identical(K, dt, Tq, Tk, drop):
     cut = Tq // 2
     do2[:, cut:] = 0
     do2[3] = 0
+    do2[0, :128] = 0  # a dead 128-query block in FRONT of live ones: the dQ kernel (which finds this out itself) writes zeros
     o, lse = k.attn_fwd(q, kk, v, H, D, kpm, False, scale, "bt", "bt", drop, 1234, kv_len=kvl)
     got = k.attn_bwd(do2, q, kk, v, o, lse, H, D, kpm, False, scale, "bt", "bt", drop, 1234, kv_len=kvl)
     dq0, dk0, dv0 = torch.empty_like(q), torch.empty_like(kk), torch.empty_like(v)
@@ -302,7 +303,7 @@ def test_attention_kv_len_skip_is_bit_identical(K, dt, Tq, Tk, drop):
     k.attn_bwd_desc(d)
     for a, b, name in zip(got, (dq0, dk0, dv0), ("dq", "dk", "dv")):
         assert torch.equal(a, b), "live-tile skip changed " + name
-    assert float(got[0][:, cut:].abs().max()) == 0.0 and float(got[0][3].abs().max()) == 0.0
+    assert float(got[0][:, cut:].abs().max()) == 0.0 and float(got[0][3].abs().max()) == 0.0 and float(got[0][0, :128].abs().max()) == 0.0
     # the host helper derives kv_len from the mask
     CF = __import__("importlib").import_module("chimera-st_amd.functional")
     u8, got = CF._mask_and_len(kpm.bool())
@@ -403,6 +404,19 @@ def test_dropout_colsum_equals_dropout_then_colsum(K, dt, rows, cols):
     ref2 = k.dropout(x2, p, key)
     assert torch.equal(xd2, ref2)
     assert torch.equal(db2, k.colsum(ref2, dt, (stamps, epoch)))
+    # second stage left to the deferred-reduction flush (out = NULL in the C ABI, cst_reduce_multi order 1): the same bits, and the
+    # destination is untouched (NaN under CST_DEFER_POISON) until the flush
+    with k.deferred_reductions(True):
+        xd3, db3 = k.dropout_colsum(x2, p, key, dt, (stamps, epoch), defer=True)
+        cs3 = k.colsum(ref, dt, defer=True)
+        cs4 = k.colsum(ref2, dt, (stamps, epoch), defer=True)
+        assert len(k.DEFER.items) == 3
+        if k.DEFER.poison:
+            assert torch.isnan(db3.float()).all() and torch.isnan(cs3.float()).all()
+    assert torch.equal(xd3, ref2) and torch.equal(db3, db2) and torch.equal(cs3, db) and torch.equal(cs4, db2)
+    assert len(k.DEFER.items) == 0
+    xd5, db5 = k.dropout_colsum(x, p, key, dt, defer=True)  # outside the mode: the immediate route
+    assert torch.equal(db5, db) and len(k.DEFER.items) == 0
 
 
 @pytest.mark.parametrize("dt", DT)
