@@ -33,6 +33,7 @@ import traceback  # noqa: E402
 from torch.utils._python_dispatch import TorchDispatchMode  # noqa: E402
 
 py_sites = collections.Counter()
+py_bytes = collections.Counter()  # bytes of the result tensors (copies, fills and elementwise ops: what the launch has to write)
 
 
 class _Sites(TorchDispatchMode):
@@ -40,9 +41,12 @@ class _Sites(TorchDispatchMode):
         name = str(func).replace("aten.", "")
         fr = [f for f in traceback.extract_stack() if "chimera-st_amd/" in f.filename]
         where = "%s:%d" % (fr[-1].filename.split("chimera-st_amd/")[-1], fr[-1].lineno) if fr else "?"
+        out = func(*args, **(kwargs or {}))
         if any(torch.is_tensor(a) and a.is_cuda for a in list(args) + list((kwargs or {}).values())) or "empty" in name or "zeros" in name:
             py_sites[(name, where)] += 1
-        return func(*args, **(kwargs or {}))
+            if torch.is_tensor(out) and out.is_cuda:
+                py_bytes[(name, where)] += out.numel() * out.element_size()
+        return out
 
 
 with _Sites():
@@ -52,7 +56,7 @@ print("ATen ops dispatched on device tensors in one update, by call site (views 
 skip = ("view", "transpose", "permute", "as_strided", "slice", "select", "expand", "unsqueeze", "squeeze", "detach", "alias", "reshape", "t.default", "empty", "_unsafe_view", "unbind", "split", "narrow", "size", "stride", "is_")
 for (name, where), n in sorted(py_sites.items(), key=lambda kv: -kv[1]):
     if not any(k in name for k in skip):
-        print("%5d  %-40s %s" % (n, name, where))
+        print("%5d  %-40s %-32s %10.3f MB written" % (n, name, where, py_bytes[(name, where)] / 1e6))
 print()
 
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
