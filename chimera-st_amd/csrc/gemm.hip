@@ -1041,6 +1041,7 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
     else if (f == "narrown") rc = launch<bf16_t, false, false, false, CfgNarrowN>(p, d->M, d->N, nbatch, s);
     else if (f == "skinny") rc = launch<bf16_t, false, false, false, CfgSkinny>(p, d->M, d->N, nbatch, s);
     else if (f == "large") rc = launch<bf16_t, false, false, false, CfgLarge>(p, d->M, d->N, nbatch, s);
+    else if (f == "big4r") rc = launch<bf16_t, false, false, false, Cfg<256, 256, 2, 2>>(p, d->M, d->N, nbatch, s);  // 4 waves x (128 x 128), register-staged
     else { cst_set_error("cst_gemm: unknown CST_GEMM_FORCE_CFG %s", force_cfg); return CST_ERR_BAD_ARG; }
   } else if (force_cfg && ak && bk && !seg && nbatch == 1 && p.splits == 1 && d->dtype == CST_BF16) {
     // tools/bench_gemm_cfg.py: one shape through every k/k configuration (CST_GEMM_EXPERIMENT=1, CST_GEMM_FORCE_CFG read per call)
@@ -1050,6 +1051,8 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
     else if (f == "small2") rc = launch_glds<bf16_t, true, true, CfgSmall, 2>(p, d->M, d->N, nbatch, s);
     else if (f == "small3") rc = launch_glds<bf16_t, true, true, CfgSmall, 3>(p, d->M, d->N, nbatch, s);
     else if (f == "big4") rc = launch_glds<bf16_t, true, true, Cfg<256, 256, 2, 2>, 2>(p, d->M, d->N, nbatch, s);  // 4 waves x (128 x 128): see tools/bench_gemm_big4.py
+    else if (f == "big4r") rc = launch<bf16_t, true, true, false, Cfg<256, 256, 2, 2>>(p, d->M, d->N, nbatch, s);          // the same, register-staged
+    else if (f == "large") rc = launch<bf16_t, true, true, false, CfgLarge>(p, d->M, d->N, nbatch, s);
     else if (f == "8p" && cst_gemm8p_supported(p, ak, bk, nbatch)) rc = cst_gemm8p_launch(p, ak, bk, nbatch, s);
     else { cst_set_error("cst_gemm: unknown CST_GEMM_FORCE_CFG %s", force_cfg); return CST_ERR_BAD_ARG; }
   } else if (!no_skinny && ak && bk && !seg && nbatch == 1 && p.splits == 1 &&

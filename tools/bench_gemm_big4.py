@@ -28,7 +28,7 @@ for (m, n, k) in [(47968, 768, 3072), (47968, 3072, 768), (47968, 2304, 768), (8
     w = (torch.rand(n, k, device="cuda") * 2 - 1).bfloat16()
     c = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
     row, ref = [], None
-    for cfg in ("8p", "big4"):
+    for cfg in ("8p", "big4", "big4r", "large"):
         os.environ["CST_GEMM_FORCE_CFG"] = cfg
         ms = t(lambda: K.gemm(a, w, c, m, n, k, a_kmajor=1, b_kmajor=1, lda=k, ldb=k, ldc=n, split_k=1))
         if ref is None:
@@ -37,3 +37,19 @@ for (m, n, k) in [(47968, 768, 3072), (47968, 3072, 768), (47968, 2304, 768), (8
     os.environ["CST_GEMM_FORCE_CFG"] = ""
     hb = t(lambda: torch.matmul(a, w.t(), out=c))
     print("%6d x %5d x %5d: %s | hipBLASLt %.3f ms (%.0f TF/s)" % (m, n, k, " | ".join(row), hb, 2.0 * m * n * k / hb / 1e9), flush=True)
+
+print("weight gradients dW[n_out, k_in] = dY^T X over `tokens` rows (both operands mn-major), split-K as the dispatcher picks it for 256 x 256 tiles:")
+for (n_out, k_in, tokens, split) in [(3072, 768, 31760, 7), (768, 3072, 31760, 7), (2304, 768, 31760, 9), (768, 768, 31760, 28), (512, 1536, 47999, 21)]:
+    dy = (torch.rand(tokens, n_out, device="cuda") * 2 - 1).bfloat16()
+    x = (torch.rand(tokens, k_in, device="cuda") * 2 - 1).bfloat16()
+    dw = torch.empty(n_out, k_in, device="cuda", dtype=torch.bfloat16)
+    row, ref = [], None
+    for cfg in ("large", "big4r"):
+        os.environ["CST_GEMM_FORCE_CFG"] = cfg
+        ms = t(lambda: K.gemm(dy, x, dw, n_out, k_in, tokens, a_kmajor=0, b_kmajor=0, lda=n_out, ldb=k_in, ldc=k_in, split_k=split))
+        if ref is None:
+            ref = dw.clone()
+        row.append("%s %.3f ms (%.0f TF/s)%s" % (cfg, ms, 2.0 * tokens * n_out * k_in / ms / 1e9, "" if torch.equal(ref, dw) else " [bits differ]"))
+    os.environ["CST_GEMM_FORCE_CFG"] = ""
+    hb = t(lambda: torch.matmul(dy.t(), x, out=dw))
+    print("%5d x %5d x %6d split %2d: %s | hipBLASLt %.3f ms (%.0f TF/s)" % (n_out, k_in, tokens, split, " | ".join(row), hb, 2.0 * tokens * n_out * k_in / hb / 1e9), flush=True)
