@@ -65,7 +65,10 @@ def build(args, device):
 
 
 def make_batch(tasks, task, args, rank, device):
-    g = torch.Generator().manual_seed(1 + rank)
+    # Every rank draws the SAME utterance / target lengths (the contents differ, seed = 1 + rank): weak scaling means a fixed amount
+    # of work per GPU, which is also what the reference's --max-tokens batching aims at (batches of about equal frame counts on every
+    # worker).  Independent draws would put a 5 % spread on the ranks' frame totals and the slowest rank's luck into the curve.
+    g = torch.Generator().manual_seed(1)
     smax = int(args.seconds * 16000)
     if args.lengths == "max":
         audio = [smax] * args.batch
@@ -521,7 +524,7 @@ def main():
                                     "Chimera s2t_transformer_w2v2_interlingua_base (6 enc + 3 memory layers, M=64) + wav2vec2-small, "
                                     "triplet_st_mt_contrastive, Adam"),
                        "batch_per_gpu": args.batch, "global_batch": world * args.batch, "max_audio_s": args.seconds,
-                       "audio_lengths": args.lengths, "target_tokens": "16-128", "vocab": 10000, "dropout": args.dropout, "w2v_layerdrop": args.layerdrop,
+                       "audio_lengths": args.lengths, "lengths_per_rank": "identical on every rank (fixed work per GPU); contents differ", "target_tokens": "16-128", "vocab": 10000, "dropout": args.dropout, "w2v_layerdrop": args.layerdrop,
                        "parallelism": "dp%d" % world, "loss": float(out["loss"]),
                        "h2d": {"included_in_value": False, "note": "inputs resident in HBM when the clock starts (bench contract); one "
                                "batch pinned host -> device measured separately; value_with_h2d = 4 updates fed from pinned host batches, "
