@@ -56,6 +56,29 @@ def test_bench_under_a_process_group():
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
 
 
+def test_bench_two_ranks_share_the_gpu_over_gloo():
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` as far as a 1-GPU box can follow it: two processes with
+    RANK 0 / 1 on cuda:0, gloo instead of RCCL (CST_DIST_BACKEND).  Rank 0 alone prints the line; value = the work of BOTH ranks over
+    the slowest rank's time; every rank trains on the same lengths (fixed work per GPU)."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for rank in range(2):
+        e = dict(os.environ)
+        e.update(RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CST_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+                                       "--seconds", "3"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=e, cwd=ROOT))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    lines0 = [l for l in outs[0][0].strip().splitlines() if l.startswith("{")]
+    assert len(lines0) == 1 and not [l for l in outs[1][0].strip().splitlines() if l.startswith("{")]
+    d = json.loads(lines0[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 8
+    assert abs(d["value"] - 8 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
+    assert d["cpu_baseline"] is None and not d.get("extra")  # the CPU baseline and the extra legs belong to the N = 1 line
+
+
 def test_bench_decode_line_contract():
     """--mode decode (BASELINE configs[4]) on a reduced workload: the same one-line contract, an HBM-bound roofline object."""
     e = dict(os.environ)
