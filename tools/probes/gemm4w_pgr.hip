@@ -112,7 +112,57 @@ __global__ __launch_bounds__(NT) void gemm4w_kernel(const bf16_t* __restrict__ A
     for (int j = 0; j < 4; ++j) fb[buf][j] = *reinterpret_cast<const bf16x8*>(base + fb0 + j * 4096 + fch[kk]);
   };
 
-  if (PF == 4) {
+  if (PF == 5) {
+    // LDS-DMA instead of register staging: the next K tile goes HBM/L2 -> LDS by 16 buffer_load ... lds per wave (1 KiB each, the lane
+    // -> (row, chunk) map carries the swizzle), issued behind every second MFMA of the first two k16 steps; nothing passes through
+    // VGPRs or the ds_write path.  Stage st ^ 1 was last read a K tile ago (barrier in between); its DMAs are waited for (vmcnt(0))
+    // in front of the barrier that ends this tile, >= 32 MFMAs after the last issue.
+    const int row0 = 8 * wave + (lane >> 3);
+    const unsigned voff = (unsigned)row0 * (unsigned)K * 2u + (unsigned)(((lane & 7) ^ ((row0 >> 1) & 7)) << 4);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(A + m0 * (int64_t)K), (short)0, (int)0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(B + n0 * (int64_t)K), (short)0, (int)0x7fffffff, 0x00020000);
+    const unsigned rstep32 = 32u * (unsigned)K * 2u;
+    auto dma = [&](int d, int kt, int stg) {  // d < 8: A group wave + 4 d; else B group wave + 4 (d - 8)
+      const int i = d & 7;
+      char* dst = smem + stg * STAGE + (d < 8 ? 0 : IMG) + (wave + 4 * i) * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(d < 8 ? rsA : rsB, (__attribute__((address_space(3))) void*)dst, 16, (int)voff,
+                                               (int)((unsigned)i * rstep32 + (unsigned)kt * 128u), 0, 0);
+    };
+    __syncthreads();  // (the prologue's register-staged tile 0 is in stage 0; tile 1 arrives by DMA now)
+    if (nkt > 1) {
+#pragma unroll
+      for (int d = 0; d < 16; ++d) dma(d, 1, 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int st = kt & 1;
+      const int ktn = kt + 2 < nkt ? kt + 2 : nkt - 1;
+      fread(st, 0, 0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (kk < 3) fread(st, kk + 1, (kk + 1) & 1);
+        if (kk < 2 && kt > 0) {  // (tile 1 was fetched in the prologue: the first pass of the loop has nothing to stage)
+#pragma unroll
+          for (int u = 0; u < 8; ++u) dma(kk * 8 + u, kt + 1 < nkt ? kt + 1 : nkt - 1, st ^ 1);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk & 1][j], fa[kk & 1][i], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (m < 8 && kk < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if ((m & 1) && kk < 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+      }
+      (void)ktn;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  } else if (PF == 4) {
     // hand-placed issue order: every k16 step = 16 MFMAs with ONE filler behind each — the 8 fragment reads of the next step, then a
     // quarter of the staged tile's ds_writes (4), then a quarter of the next tile's global loads (4).  No branches inside the K tile
     // (the last tiles re-fetch a clamped tile into the stage nobody reads), so the whole tile is one scheduling region.
@@ -234,10 +284,10 @@ int main() {
     hipMalloc(&dA, hA.size() * 2); hipMalloc(&dB, hB.size() * 2); hipMalloc(&dC, hC.size() * 2);
     hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice);
     hipMemcpy(dB, hB.data(), hB.size() * 2, hipMemcpyHostToDevice);
-    for (int pf = 0; pf < 5; ++pf) {
+    for (int pf = 0; pf < 6; ++pf) {
       if (pf == 3) continue;
       hipMemset(dC, 0, hC.size() * 2);
-      const double ms = pf == 0 ? run<0>(dA, dB, dC, M, N, K, 20) : pf == 1 ? run<1>(dA, dB, dC, M, N, K, 20) : pf == 2 ? run<2>(dA, dB, dC, M, N, K, 20) : run<4>(dA, dB, dC, M, N, K, 20);
+      const double ms = pf == 0 ? run<0>(dA, dB, dC, M, N, K, 20) : pf == 1 ? run<1>(dA, dB, dC, M, N, K, 20) : pf == 2 ? run<2>(dA, dB, dC, M, N, K, 20) : pf == 4 ? run<4>(dA, dB, dC, M, N, K, 20) : run<5>(dA, dB, dC, M, N, K, 20);
       hipMemcpy(hC.data(), dC, hC.size() * 2, hipMemcpyDeviceToHost);
       double worst = 0.0;
       for (int t = 0; t < 64; ++t) {  // sampled elements against a double-precision dot product
@@ -250,7 +300,7 @@ int main() {
         worst = (err > worst || err != err) ? err : worst;  // (NaN sticks)
       }
       printf("%6d x %5d x %5d  ds_write %s: %.3f ms  %.0f TF/s  (worst sampled rel. error %.1e)\n", M, N, K,
-             pf == 1 ? "at the head of the next K tile, loads a tile ahead" : pf == 0 ? "after the K tile's MFMAs, loads behind the barrier " : pf == 2 ? "NONE and no loads (timing only)                   " : "one filler behind every MFMA (sched_group_barrier)", ms, 2.0 * M * N * K / ms / 1e9, worst);
+             pf == 1 ? "at the head of the next K tile, loads a tile ahead" : pf == 0 ? "after the K tile's MFMAs, loads behind the barrier " : pf == 2 ? "NONE and no loads (timing only)                   " : pf == 4 ? "one filler behind every MFMA (sched_group_barrier)" : "NONE: LDS-DMA behind every 2nd MFMA of steps 0, 1 ", ms, 2.0 * M * N * K / ms / 1e9, worst);
     }
     hipFree(dA); hipFree(dB); hipFree(dC);
   }
