@@ -573,6 +573,68 @@ __global__ __launch_bounds__(C::NT) void gemm_glds_kernel(GemmParams p) {
   for (int s = 0; s < NS - 1; ++s)
     if (s < nt) issue(kt0 + s, s);
 
+  // PIN — four waves, 128-row wave tiles (one wave per SIMD, accumulators in AGPRs), two stages: the issue order of a K tile is
+  // pinned by sched_barrier(0) behind every MFMA pair — { 2 MFMA ; one fragment read of the next k16 step ; one DMA of the next K tile
+  // } — instead of { all DMAs ; per k16 step: all reads, all MFMAs }: a lone wave has no partner to cover its LDS-DMA issues (~60
+  // cycles each among MFMAs) or its fragment reads, so they have to sit one per MFMA shadow (tools/probes/gemm4w_pgr.hip: 1 246 ->
+  // 1 339 TF/s at 8192^3 for the pinned order; hipcc's own order of the same statements: 1 088).
+  constexpr bool PIN = NTHREADS == 256 && TM == 4 && NS == 2 && A_KMAJOR && B_KMAJOR && sizeof(T) == 2;
+  if constexpr (PIN) {
+    auto issue_one = [&](int d, char* sbase) {
+      if (d < GA) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa[d],
+                                         (__attribute__((address_space(3))) void*)(sbase + (wave + NWAVES * d) * 1024), 16, 0, 0);
+        pa[d] += step_a;
+        ka[d] += BK;
+      } else {
+        const int e = d - GA;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pb[e],
+                                         (__attribute__((address_space(3))) void*)(sbase + A_BYTES + (wave + NWAVES * e) * 1024), 16, 0, 0);
+        pb[e] += step_b;
+        kb[e] += BK;
+      }
+    };
+    constexpr int NSLOT = TM * TN / 2, NFR = TM + TN;
+    for (int it = 0; it < nt; ++it) {
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      const bool more = it + 1 < nt;
+      const bool dma_ok = more && (kt0 + it + 1) < kfull;
+      if (more && !dma_ok) issue(kt0 + it + 1, (it + 1) & 1);  // the K tail tile: synchronous, zero-filled (at most once)
+      const char* sbase = smem_raw + (it & 1) * STAGE_BYTES;
+      char* nbase = smem_raw + ((it + 1) & 1) * STAGE_BYTES;
+      const T* sa = reinterpret_cast<const T*>(sbase);
+      const T* sb = reinterpret_cast<const T*>(sbase + A_BYTES);
+      Frag<T> fa[2][TM], fb[2][TN];
+      auto read_one = [&](int f, int kk, int buf) {  // fragment f of k16 step kk: A rows first, then B rows
+        if (f < TM) frag_load_kswz(fa[buf][f], sa, wm * WROWS + f * 32 + lrow, kk * 16 + 8 * hi);
+        else frag_load_kswz(fb[buf][f - TM], sb, wn * WCOLS + (f - TM) * 32 + lrow, kk * 16 + 8 * hi);
+      };
+#pragma unroll
+      for (int f = 0; f < NFR; ++f) read_one(f, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int m = 2 * sl + u, i = m / TN, j = m % TN;
+            mma16(acc[i][j], fa[kk & 1][i], fb[kk & 1][j]);
+          }
+          if (kk < 3) {
+            if (sl < NFR) read_one(sl, kk + 1, (kk + 1) & 1);
+            if (sl == 0 && NFR > NSLOT) {  // (TN = 3: seven fragments, six slots)
+#pragma unroll
+              for (int f = NSLOT; f < NFR; ++f) read_one(f, kk + 1, (kk + 1) & 1);
+            }
+          }
+          if (kk * NSLOT + sl < G && dma_ok) issue_one(kk * NSLOT + sl, nbase);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  } else
   for (int it = 0; it < nt; ++it) {
     // tile `it` must have landed; up to NS-2 later tiles may stay in flight (steady state), fewer near the end
     const int issued = (it + NS - 1 < nt) ? it + NS - 1 : nt;
@@ -1051,6 +1113,7 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
     else if (f == "small2") rc = launch_glds<bf16_t, true, true, CfgSmall, 2>(p, d->M, d->N, nbatch, s);
     else if (f == "small3") rc = launch_glds<bf16_t, true, true, CfgSmall, 3>(p, d->M, d->N, nbatch, s);
     else if (f == "big4") rc = launch_glds<bf16_t, true, true, Cfg<256, 256, 2, 2>, 2>(p, d->M, d->N, nbatch, s);  // 4 waves x (128 x 128): see tools/bench_gemm_big4.py
+    else if (f == "big4n") rc = launch_glds<bf16_t, true, true, Cfg<256, 192, 2, 2>, 2>(p, d->M, d->N, nbatch, s);  // 128 x 96 wave tiles: N = 768 is 4 tiles
     else if (f == "big4r") rc = launch<bf16_t, true, true, false, Cfg<256, 256, 2, 2>>(p, d->M, d->N, nbatch, s);          // the same, register-staged
     else if (f == "large") rc = launch<bf16_t, true, true, false, CfgLarge>(p, d->M, d->N, nbatch, s);
     else if (f == "8p" && cst_gemm8p_supported(p, ak, bk, nbatch)) rc = cst_gemm8p_launch(p, ak, bk, nbatch, s);

@@ -23,12 +23,12 @@ def t(fn, iters=30):
     return s.elapsed_time(e) / iters
 
 
-for (m, n, k) in [(47968, 768, 3072), (47968, 3072, 768), (47968, 2304, 768), (8192, 8192, 8192), (31760, 768, 3072)]:
+for (m, n, k) in [(47968, 768, 3072), (47968, 3072, 768), (47968, 2304, 768), (8192, 8192, 8192), (31760, 768, 3072), (31760, 768, 2304), (31760, 768, 768)]:
     a = (torch.rand(m, k, device="cuda") * 2 - 1).bfloat16()
     w = (torch.rand(n, k, device="cuda") * 2 - 1).bfloat16()
     c = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
     row, ref = [], None
-    for cfg in ("8p", "big4", "big4r", "large"):
+    for cfg in ("8p", "big4", "big4n", "big4r", "large"):
         os.environ["CST_GEMM_FORCE_CFG"] = cfg
         ms = t(lambda: K.gemm(a, w, c, m, n, k, a_kmajor=1, b_kmajor=1, lda=k, ldb=k, ldc=n, split_k=1))
         if ref is None:

@@ -112,7 +112,8 @@ __global__ __launch_bounds__(NT) void gemm4w_kernel(const bf16_t* __restrict__ A
     for (int j = 0; j < 4; ++j) fb[buf][j] = *reinterpret_cast<const bf16x8*>(base + fb0 + j * 4096 + fch[kk]);
   };
 
-  if (PF == 5) {
+  if (PF == 5 || PF == 6) {
+    constexpr bool EXACT = PF == 6;
     // LDS-DMA instead of register staging: the next K tile goes HBM/L2 -> LDS by 16 buffer_load ... lds per wave (1 KiB each, the lane
     // -> (row, chunk) map carries the swizzle), issued behind every second MFMA of the first two k16 steps; nothing passes through
     // VGPRs or the ds_write path.  Stage st ^ 1 was last read a K tile ago (barrier in between); its DMAs are waited for (vmcnt(0))
@@ -135,6 +136,34 @@ __global__ __launch_bounds__(NT) void gemm4w_kernel(const bf16_t* __restrict__ A
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (EXACT) {
+      // the same work with the issue order pinned by sched_barrier(0) behind every MFMA pair: { 2 MFMA ; one fragment read of the next
+      // k16 step ; one DMA (first two steps) }
+      for (int kt = 0; kt < nkt; ++kt) {
+        const int st = kt & 1;
+        const char* rbase = smem + st * STAGE;
+        fread(st, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+          for (int pr = 0; pr < 8; ++pr) {
+            const int i = pr >> 1, j0 = (pr & 1) * 2;
+            acc[i][j0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk & 1][j0], fa[kk & 1][i], acc[i][j0], 0, 0, 0);
+            acc[i][j0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk & 1][j0 + 1], fa[kk & 1][i], acc[i][j0 + 1], 0, 0, 0);
+            if (kk < 3) {
+              const int nb = (kk + 1) & 1;
+              if (pr < 4) fa[nb][pr] = *reinterpret_cast<const bf16x8*>(rbase + fa0 + pr * 4096 + fch[kk + 1]);
+              else fb[nb][pr - 4] = *reinterpret_cast<const bf16x8*>(rbase + fb0 + (pr - 4) * 4096 + fch[kk + 1]);
+            }
+            if (kk < 2 && kt > 0) dma(kk * 8 + pr, kt + 1 < nkt ? kt + 1 : nkt - 1, st ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    } else
     for (int kt = 0; kt < nkt; ++kt) {
       const int st = kt & 1;
       const int ktn = kt + 2 < nkt ? kt + 2 : nkt - 1;
@@ -284,10 +313,10 @@ int main() {
     hipMalloc(&dA, hA.size() * 2); hipMalloc(&dB, hB.size() * 2); hipMalloc(&dC, hC.size() * 2);
     hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice);
     hipMemcpy(dB, hB.data(), hB.size() * 2, hipMemcpyHostToDevice);
-    for (int pf = 0; pf < 6; ++pf) {
+    for (int pf = 0; pf < 7; ++pf) {
       if (pf == 3) continue;
       hipMemset(dC, 0, hC.size() * 2);
-      const double ms = pf == 0 ? run<0>(dA, dB, dC, M, N, K, 20) : pf == 1 ? run<1>(dA, dB, dC, M, N, K, 20) : pf == 2 ? run<2>(dA, dB, dC, M, N, K, 20) : pf == 4 ? run<4>(dA, dB, dC, M, N, K, 20) : run<5>(dA, dB, dC, M, N, K, 20);
+      const double ms = pf == 0 ? run<0>(dA, dB, dC, M, N, K, 20) : pf == 1 ? run<1>(dA, dB, dC, M, N, K, 20) : pf == 2 ? run<2>(dA, dB, dC, M, N, K, 20) : pf == 4 ? run<4>(dA, dB, dC, M, N, K, 20) : pf == 5 ? run<5>(dA, dB, dC, M, N, K, 20) : run<6>(dA, dB, dC, M, N, K, 20);
       hipMemcpy(hC.data(), dC, hC.size() * 2, hipMemcpyDeviceToHost);
       double worst = 0.0;
       for (int t = 0; t < 64; ++t) {  // sampled elements against a double-precision dot product
@@ -300,7 +329,7 @@ int main() {
         worst = (err > worst || err != err) ? err : worst;  // (NaN sticks)
       }
       printf("%6d x %5d x %5d  ds_write %s: %.3f ms  %.0f TF/s  (worst sampled rel. error %.1e)\n", M, N, K,
-             pf == 1 ? "at the head of the next K tile, loads a tile ahead" : pf == 0 ? "after the K tile's MFMAs, loads behind the barrier " : pf == 2 ? "NONE and no loads (timing only)                   " : pf == 4 ? "one filler behind every MFMA (sched_group_barrier)" : "NONE: LDS-DMA behind every 2nd MFMA of steps 0, 1 ", ms, 2.0 * M * N * K / ms / 1e9, worst);
+             pf == 1 ? "at the head of the next K tile, loads a tile ahead" : pf == 0 ? "after the K tile's MFMAs, loads behind the barrier " : pf == 2 ? "NONE and no loads (timing only)                   " : pf == 4 ? "one filler behind every MFMA (sched_group_barrier)" : pf == 5 ? "NONE: LDS-DMA behind every 2nd MFMA of steps 0, 1 " : "NONE: LDS-DMA, order pinned per MFMA pair         ", ms, 2.0 * M * N * K / ms / 1e9, worst);
     }
     hipFree(dA); hipFree(dB); hipFree(dC);
   }
