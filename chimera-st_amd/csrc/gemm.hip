@@ -620,7 +620,7 @@ __global__ __launch_bounds__(C::NT) void gemm_glds_kernel(GemmParams p) {
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             const int m = 2 * sl + u, i = m / TN, j = m % TN;
-            mma16(acc[i][j], fa[kk & 1][i], fb[kk & 1][j]);
+            mma16(acc[i][j], fb[kk & 1][j], fa[kk & 1][i]);  // SWAPPED (D = B-frag x A-frag): lane -> output row, register quad -> 4 columns
           }
           if (kk < 3) {
             if (sl < NFR) read_one(sl, kk + 1, (kk + 1) & 1);
@@ -674,14 +674,58 @@ __global__ __launch_bounds__(C::NT) void gemm_glds_kernel(GemmParams p) {
     }
   }
 
+  float* wsp = p.splits > 1 ? p.ws + ((int64_t)z) * p.M * p.N : nullptr;
+  const bool ws_vec = (p.N % 4) == 0;
+  if constexpr (PIN) {
+    // ---- epilogue of the four-wave instantiations: every wave turns its own 128-row block into an fp32 image of 32 rows at a time in
+    //      ITS quarter of the LDS (16-byte writes from the swapped accumulator layout), reads it back row-contiguously and runs the
+    //      common element epilogue — one pass per 32-row block, no workgroup barrier between them (the generic epilogue below stages 64
+    //      rows of the whole tile per pass through one image: four passes, two barriers each, 4-byte LDS writes) ----
+    constexpr int LDW = WCOLS + 4, VPRW = WCOLS / 8, RITER = 32 * VPRW / 64;
+    static_assert(4 * 32 * LDW * 4 <= NS * STAGE_BYTES && (32 * VPRW) % 64 == 0, "the four waves' images live in the stage buffers");
+    __syncthreads();  // every wave is done reading the stages
+    float* img = reinterpret_cast<float*>(smem_raw) + wave * (32 * LDW);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {  // one 32-row block of the wave tile per pass
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+          *reinterpret_cast<f32x4*>(img + lrow * LDW + j * 32 + 8 * q + 4 * hi) = v;
+        }
+#pragma unroll 2
+      for (int tv = 0; tv < RITER; ++tv) {
+        const int v = tv * 64 + lane;
+        const int rl = v / VPRW, cl = (v % VPRW) * 8;
+        const int64_t row = m0 + wm * WROWS + i * 32 + rl, col = n0 + wn * WCOLS + cl;
+        if (row >= p.M || col >= p.N) continue;
+        float x[8];
+        {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(img + rl * LDW + cl);
+          const f32x4 b = *reinterpret_cast<const f32x4*>(img + rl * LDW + cl + 4);
+          x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
+        }
+        const bool full = col + 8 <= p.N;
+        if (wsp) {
+          if (full && ws_vec) store8(wsp + row * p.N + col, x);
+          else
+            for (int e = 0; e < 8 && col + e < p.N; ++e) wsp[row * p.N + col + e] = x[e];
+        } else if (full && p.vec_epi) {
+          epilogue_store8<T>(p, cofs, bofs, row, col, x);
+        } else {
+          for (int e = 0; e < 8 && col + e < p.N; ++e) epilogue_store<T>(p, cofs, bofs, row, col + e, x[e]);
+        }
+      }
+    }
+    return;
+  }
   // ---- epilogue (identical to gemm_kernel) ----
   constexpr int LDC = BN + 4;
   constexpr int VPR = BN / 8;
   constexpr int NPASS = BM / 64;
   constexpr int ITERS = 64 * VPR / NTHREADS;
   float* stage = reinterpret_cast<float*>(smem_raw);
-  float* wsp = p.splits > 1 ? p.ws + ((int64_t)z) * p.M * p.N : nullptr;
-  const bool ws_vec = (p.N % 4) == 0;
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
     __syncthreads();
