@@ -284,6 +284,129 @@ __global__ __launch_bounds__(NT) void gemm4w_kernel(const bf16_t* __restrict__ A
   }
 }
 
+// ---- the pinned-order LDS-DMA loop alone, for 256 x (64 TN) tiles: TN = 4 is the kernel above (PF = 6), TN = 3 makes N = 768 exactly
+//      four tile columns (wave tile 128 x 96, 14 DMAs per wave and K tile, 12 MFMAs per k16 step) ----
+template <int TN>
+__global__ __launch_bounds__(NT) void gemm4w_dma_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C,
+                                                        int M, int N, int K, int tiles_m, int tiles_n) {
+  constexpr int BNt = 64 * TN, IMGB = BNt * 128, STG = IMG + IMGB, GB = BNt / 32, G = 8 + GB, NSLOT = 2 * TN, NFR = 4 + TN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lrow = lane & 31, hi = lane >> 5;
+  const int ntiles = tiles_m * tiles_n;
+  int id = blockIdx.x;
+  {
+    const int q = ntiles / 8, r = ntiles % 8, xcd = id % 8, loc = id / 8;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * tiles_n;
+  const int grp = id / per_group, rem = id % per_group;
+  const int gm0 = grp * GROUP_M;
+  const int gsz = (tiles_m - gm0 < GROUP_M) ? (tiles_m - gm0) : GROUP_M;
+  const int tm = gm0 + rem % gsz, tn = rem / gsz;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BNt;
+
+  const int row0 = 8 * wave + (lane >> 3);
+  const unsigned voff = (unsigned)row0 * (unsigned)K * 2u + (unsigned)(((lane & 7) ^ ((row0 >> 1) & 7)) << 4);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(A + m0 * (int64_t)K), (short)0, (int)0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(B + n0 * (int64_t)K), (short)0, (int)0x7fffffff, 0x00020000);
+  const unsigned rstep32 = 32u * (unsigned)K * 2u;
+  auto dma = [&](int d, int kt, int stg) {
+    const int i = d < 8 ? d : d - 8;
+    char* dst = smem + stg * STG + (d < 8 ? 0 : IMG) + (wave + 4 * i) * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(d < 8 ? rsA : rsB, (__attribute__((address_space(3))) void*)dst, 16, (int)voff,
+                                             (int)((unsigned)i * rstep32 + (unsigned)kt * 128u), 0, 0);
+  };
+  const int swr = (lrow >> 1) & 7;
+  const unsigned fa0 = (unsigned)((wm * 128 + lrow) * 128), fb0 = (unsigned)(IMG + (wn * 32 * TN + lrow) * 128);
+  unsigned fch[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) fch[kk] = (unsigned)(((2 * kk + hi) ^ swr) << 4);
+  f32x16 acc[4][TN];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  const int nkt = K / BK;
+#pragma unroll
+  for (int d = 0; d < G; ++d) dma(d, 0, 0);
+  bf16x8 fa[2][4], fb[2][TN];
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int st = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const char* rbase = smem + st * STG;
+    auto read_one = [&](int f, int kk, int nb) {
+      if (f < 4) fa[nb][f] = *reinterpret_cast<const bf16x8*>(rbase + fa0 + f * 4096 + fch[kk]);
+      else fb[nb][f - 4] = *reinterpret_cast<const bf16x8*>(rbase + fb0 + (f - 4) * 4096 + fch[kk]);
+    };
+#pragma unroll
+    for (int f = 0; f < NFR; ++f) read_one(f, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    const bool more = kt + 1 < nkt;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+      for (int sl = 0; sl < NSLOT; ++sl) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int m = 2 * sl + u, i = m / TN, j = m % TN;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk & 1][j], fa[kk & 1][i], acc[i][j], 0, 0, 0);
+        }
+        if (kk < 3) {
+          if (sl < NFR) read_one(sl, kk + 1, (kk + 1) & 1);
+          if (sl == 0 && NFR > NSLOT) {
+#pragma unroll
+            for (int f = NSLOT; f < NFR; ++f) read_one(f, kk + 1, (kk + 1) & 1);
+          }
+        }
+        if (kk * NSLOT + sl < G && more) dma(kk * NSLOT + sl, kt + 1, st ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  __syncthreads();
+  {
+    constexpr int ERS = 64 * TN + 16;  // bf16 image row stride in bytes (32 TN columns x 2 B + 16)
+    char* img = smem + wave * (128 * ERS);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          u32x2 w = {pack2(acc[i][j][4 * q], acc[i][j][4 * q + 1]), pack2(acc[i][j][4 * q + 2], acc[i][j][4 * q + 3])};
+          *reinterpret_cast<u32x2*>(img + (i * 32 + lrow) * ERS + (j * 32 + 8 * q + 4 * hi) * 2) = w;
+        }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    bf16_t* cbase = C + (m0 + wm * 128) * (int64_t)N + n0 + wn * 32 * TN;
+    constexpr int CPR = 4 * TN;  // 16-byte chunks per row of the wave tile
+    for (int v = lane; v < 128 * CPR; v += 64) {
+      const int row = v / CPR, ch = v % CPR;
+      const u32x4 x = *reinterpret_cast<const u32x4*>(img + row * ERS + ch * 16);
+      __builtin_nontemporal_store(x, reinterpret_cast<u32x4*>(cbase + row * (int64_t)N + ch * 8));
+    }
+  }
+}
+
+template <int TN>
+static double run_dma(const bf16_t* dA, const bf16_t* dB, bf16_t* dC, int M, int N, int K, int iters) {
+  constexpr int lds = 2 * (IMG + 64 * TN * 128) > 4 * 128 * (64 * TN + 16) ? 2 * (IMG + 64 * TN * 128) : 4 * 128 * (64 * TN + 16);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4w_dma_kernel<TN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  const int tm = M / BM, tn = N / (64 * TN);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gemm4w_dma_kernel<TN>, dim3(tm * tn), dim3(NT), lds, 0, dA, dB, dC, M, N, K, tm, tn);
+  hipEventRecord(e0);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(gemm4w_dma_kernel<TN>, dim3(tm * tn), dim3(NT), lds, 0, dA, dB, dC, M, N, K, tm, tn);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  return ms / iters;
+}
+
 static float bf2f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
 static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
 
@@ -301,7 +424,7 @@ static double run(const bf16_t* dA, const bf16_t* dB, bf16_t* dC, int M, int N, 
 }
 
 int main() {
-  const int shapes[][3] = {{8192, 8192, 8192}, {47872, 768, 3072}};
+  const int shapes[][3] = {{8192, 8192, 8192}, {47872, 768, 3072}, {31744, 768, 3072}, {31744, 768, 2304}};
   for (auto& s : shapes) {
     const int M = s[0], N = s[1], K = s[2];
     std::vector<uint16_t> hA((size_t)M * K), hB((size_t)N * K), hC((size_t)M * N);
@@ -330,6 +453,23 @@ int main() {
       }
       printf("%6d x %5d x %5d  ds_write %s: %.3f ms  %.0f TF/s  (worst sampled rel. error %.1e)\n", M, N, K,
              pf == 1 ? "at the head of the next K tile, loads a tile ahead" : pf == 0 ? "after the K tile's MFMAs, loads behind the barrier " : pf == 2 ? "NONE and no loads (timing only)                   " : pf == 4 ? "one filler behind every MFMA (sched_group_barrier)" : pf == 5 ? "NONE: LDS-DMA behind every 2nd MFMA of steps 0, 1 " : "NONE: LDS-DMA, order pinned per MFMA pair         ", ms, 2.0 * M * N * K / ms / 1e9, worst);
+    }
+    for (int tn = 4; tn >= 3; --tn) {
+      if (N % (64 * tn)) continue;
+      hipMemset(dC, 0, hC.size() * 2);
+      const double ms = tn == 4 ? run_dma<4>(dA, dB, dC, M, N, K, 20) : run_dma<3>(dA, dB, dC, M, N, K, 20);
+      hipMemcpy(hC.data(), dC, hC.size() * 2, hipMemcpyDeviceToHost);
+      double worst = 0.0;
+      for (int t = 0; t < 64; ++t) {
+        x = x * 1664525u + 1013904223u; const int r = (int)((x >> 4) % (unsigned)M);
+        x = x * 1664525u + 1013904223u; const int c = (int)((x >> 4) % (unsigned)N);
+        double ref = 0.0;
+        for (int k = 0; k < K; ++k) ref += (double)bf2f(hA[(size_t)r * K + k]) * (double)bf2f(hB[(size_t)c * K + k]);
+        const double err = fabs((double)bf2f(hC[(size_t)r * N + c]) - ref) / (fabs(ref) + 1.0);
+        worst = (err > worst || err != err) ? err : worst;
+      }
+      printf("%6d x %5d x %5d  pinned LDS-DMA loop alone, 256 x %d tiles (%d tiles = %.2f rounds of 256): %.3f ms  %.0f TF/s  (worst sampled rel. error %.1e)\n",
+             M, N, K, 64 * tn, (M / 256) * (N / (64 * tn)), (M / 256) * (N / (64 * tn)) / 256.0, ms, 2.0 * M * N * K / ms / 1e9, worst);
     }
     hipFree(dA); hipFree(dB); hipFree(dC);
   }
