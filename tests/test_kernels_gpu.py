@@ -1427,3 +1427,34 @@ def test_attention_kv_packed_projection_equals_separate_k_and_v(K, dt, drop):
         outs.append((o.detach(), gq, gkv))
     for a, b, name in zip(outs[0], outs[1], ("o", "dq", "dkv")):
         assert torch.equal(a, b), name
+
+
+def test_four_wave_instantiations_of_the_dma_gemm_keep_the_bits():
+    """The experiment-hook configurations big4 / big4n (gemm_glds_kernel with four waves and 128-row wave tiles: pinned issue order,
+    per-wave epilogue, swapped accumulator layout — DESIGN 5.1, round 4) against whatever the dispatcher picks: plain bf16 stores of
+    the same products in the same K order are the same bits, ragged M / N edges and a K tail included.  (Own process: the hook's
+    environment switch is read once per process.)"""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import importlib, os, sys, torch
+sys.path.insert(0, %r)
+K = importlib.import_module("chimera-st_amd.kernels")
+for (m, n, k) in [(1000, 768, 512), (2304, 700, 1096), (513, 384, 200)]:
+    a = (torch.rand(m, k, device="cuda") * 2 - 1).bfloat16(); w = (torch.rand(n, k, device="cuda") * 2 - 1).bfloat16()
+    outs = []
+    for cfg in ("", "big4", "big4n"):
+        os.environ["CST_GEMM_FORCE_CFG"] = cfg
+        c = torch.full((m, n), float("nan"), device="cuda", dtype=torch.bfloat16)
+        K.gemm(a, w, c, m, n, k, a_kmajor=1, b_kmajor=1, lda=k, ldb=k, ldc=n, split_k=1)
+        outs.append(c)
+    ref = (a.float() @ w.float().t())
+    assert torch.isfinite(outs[0].float()).all() and (outs[0].float() - ref).abs().max() <= 2e-2 * ref.abs().max()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (m, n, k)
+print("ok")
+""" % ROOT
+    e = dict(os.environ, CST_GEMM_EXPERIMENT="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
