@@ -1127,6 +1127,10 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
   const bool mid8p = !no_mid8p && ak && bk && !seg && nbatch == 1 && p.splits == 1 && d->M >= 256 && d->N >= 256 &&
                      cst_ceil_div(d->M, 256) * cst_ceil_div(d->N, 256) >= 150;
   static const bool no_narrow = getenv("CST_GEMM_NO_NARROW") != nullptr;
+  // gemm4w.hip (four waves, pinned issue order): 7-8 % faster than the 8-wave kernel on the N = 768 long-K launches in a timing loop,
+  // where the 195 MB operand stays in the Infinity Cache — and 8-11 % SLOWER on the K = 3072 ones inside the training step, where it
+  // comes from HBM and the kernel's one-K-tile prefetch distance is too short (K = 2304: -4 %).  Opt-in until it has a deeper ring.
+  static const bool no_4w = getenv("CST_GEMM_4W") == nullptr;
   static const bool experiment = getenv("CST_GEMM_EXPERIMENT") != nullptr;
   const char* force_cfg = experiment ? getenv("CST_GEMM_FORCE_CFG") : nullptr;
   if (force_cfg && !*force_cfg) force_cfg = nullptr;
@@ -1161,6 +1165,7 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
     else if (f == "big4r") rc = launch<bf16_t, true, true, false, Cfg<256, 256, 2, 2>>(p, d->M, d->N, nbatch, s);          // the same, register-staged
     else if (f == "large") rc = launch<bf16_t, true, true, false, CfgLarge>(p, d->M, d->N, nbatch, s);
     else if (f == "8p" && cst_gemm8p_supported(p, ak, bk, nbatch)) rc = cst_gemm8p_launch(p, ak, bk, nbatch, s);
+    else if (f == "4w" && cst_gemm4w_supported(p, ak, bk, nbatch)) rc = cst_gemm4w_launch(p, s);
     else { cst_set_error("cst_gemm: unknown CST_GEMM_FORCE_CFG %s", force_cfg); return CST_ERR_BAD_ARG; }
   } else if (!no_skinny && ak && bk && !seg && nbatch == 1 && p.splits == 1 &&
              (d->M <= 256 || (!large && !mid8p && cst_ceil_div(d->M, 128) * cst_ceil_div(d->N, 128) < skinny_tiles))) {
@@ -1174,6 +1179,8 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
                                              : launch_glds<float, true, true, CfgSkinny, 2>(p, d->M, d->N, nbatch, s);
     else rc = d->dtype == CST_BF16 ? launch_glds<bf16_t, true, true, CfgSkinny, 4>(p, d->M, d->N, nbatch, s)
                                    : launch_glds<float, true, true, CfgSkinny, 4>(p, d->M, d->N, nbatch, s);
+  } else if (d->dtype == CST_BF16 && !seg && !no_4w && !d->colsum && cst_gemm4w_supported(p, ak, bk, nbatch)) {
+    rc = cst_gemm4w_launch(p, s);  // long K, N a multiple of 192 (the N = 768 family): four waves, pinned issue order (gemm4w.hip)
   } else if (d->dtype == CST_BF16 && !seg && !no_8p && !d->colsum && (ak || all_8p || force_8p) && (!d->dact || (dact_8p && !d->resid && !d->aux_out) || all_8p || force_8p) && (large || mid8p || force_8p) && cst_gemm8p_supported(p, ak, bk, nbatch))
     rc = cst_gemm8p_launch(p, ak, bk, nbatch, s);
   else if (d->dtype == CST_BF16) rc = CST_GEMM_DISPATCH(bf16_t);

@@ -112,4 +112,7 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int64_t cof
 // gemm8p.hip: 256 x 256 x 64 bf16 tile, 8 waves, 8-phase DMA pipeline.  Returns CST_OK after the launch.
 int cst_gemm8p_launch(cstg::GemmParams p, bool a_kmajor, bool b_kmajor, int64_t nbatch, hipStream_t s);
 bool cst_gemm8p_supported(const cstg::GemmParams& p, bool a_kmajor, bool b_kmajor, int64_t nbatch);
+// gemm4w.hip: four waves, 256 x 192 tiles, pinned issue order — the long-K N = 768-family launches (same bits as gemm8p's fast path)
+int cst_gemm4w_launch(cstg::GemmParams p, hipStream_t s);
+bool cst_gemm4w_supported(const cstg::GemmParams& p, bool a_kmajor, bool b_kmajor, int64_t nbatch);
 

@@ -1432,8 +1432,9 @@ def test_attention_kv_packed_projection_equals_separate_k_and_v(K, dt, drop):
 def test_four_wave_instantiations_of_the_dma_gemm_keep_the_bits():
     """The experiment-hook configurations big4 / big4n (gemm_glds_kernel with four waves and 128-row wave tiles: pinned issue order,
     per-wave epilogue, swapped accumulator layout — DESIGN 5.1, round 4) against whatever the dispatcher picks: plain bf16 stores of
-    the same products in the same K order are the same bits, ragged M / N edges and a K tail included.  (Own process: the hook's
-    environment switch is read once per process.)"""
+    the same products in the same K order are the same bits, ragged M / N edges and a K tail included.  And gemm4w.hip (the lean
+    kernel of the same shape, opt-in: CST_GEMM_4W=1) against the persistent 8-wave kernel with bias + dropout + residual, residual
+    + live-tile stamps, rows beyond M: the same bits.  (Own process: the hook's environment switch is read once per process.)"""
     import os
     import subprocess
     import sys
@@ -1453,6 +1454,21 @@ for (m, n, k) in [(1000, 768, 512), (2304, 700, 1096), (513, 384, 200)]:
     ref = (a.float() @ w.float().t())
     assert torch.isfinite(outs[0].float()).all() and (outs[0].float() - ref).abs().max() <= 2e-2 * ref.abs().max()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (m, n, k)
+# gemm4w.hip against the persistent 8-wave kernel, with the step's epilogues and live-tile stamps: the same bits
+L = importlib.import_module("chimera-st_amd.lib")
+m, n, k = 24000, 768, 1536
+a = (torch.rand(m, k, device="cuda") * 2 - 1).bfloat16(); w = (torch.rand(n, k, device="cuda") * 2 - 1).bfloat16()
+a[20000:] = 0
+stamps = torch.zeros((m + 63) // 64, dtype=torch.int32, device="cuda"); stamps[: 20000 // 64 + 1] = 7
+r = torch.randn(m, n, device="cuda").bfloat16(); b = torch.randn(n, device="cuda").bfloat16()
+for kw in (dict(), dict(resid=r, ld_resid=n), dict(resid=r, ld_resid=n, bias=b, drop_p=0.1, drop_key=4242), dict(resid=r, ld_resid=n, m_live=(stamps, 7))):
+    outs = []
+    for cfg in ("8p", "4w"):
+        os.environ["CST_GEMM_FORCE_CFG"] = cfg
+        c = torch.full((m, n), float("nan"), device="cuda", dtype=torch.bfloat16)
+        K.gemm(a, w, c, m, n, k, a_kmajor=1, b_kmajor=1, lda=k, ldb=k, ldc=n, split_k=1, **kw)
+        outs.append(c)
+    assert torch.isfinite(outs[1].float()).all() and torch.equal(outs[0], outs[1]), sorted(kw)
 print("ok")
 """ % ROOT
     e = dict(os.environ, CST_GEMM_EXPERIMENT="1")

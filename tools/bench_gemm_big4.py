@@ -39,15 +39,15 @@ for (m, n, k) in [(47968, 768, 3072), (47968, 3072, 768), (47968, 2304, 768), (8
     print("%6d x %5d x %5d: %s | hipBLASLt %.3f ms (%.0f TF/s)" % (m, n, k, " | ".join(row), hb, 2.0 * m * n * k / hb / 1e9), flush=True)
 
 print("with the step's epilogues (fc2 forward: bias + residual + dropout 0.1; dX: residual):")
-for (m, n, k, epi) in [(31760, 768, 3072, "fc2"), (31760, 768, 3072, "resid"), (31760, 768, 2304, "resid"), (47968, 768, 3072, "fc2")]:
+for (m, n, k, epi) in [(31760, 768, 3072, "plain"), (31760, 768, 3072, "fc2"), (31760, 768, 3072, "resid"), (31760, 768, 2304, "resid"), (47968, 768, 3072, "fc2"), (47968, 768, 3072, "resid")]:
     a = (torch.rand(m, k, device="cuda") * 2 - 1).bfloat16()
     w = (torch.rand(n, k, device="cuda") * 2 - 1).bfloat16()
     c = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
-    kw = dict(resid=torch.randn(m, n, device="cuda").bfloat16(), ld_resid=n)
+    kw = dict(resid=torch.randn(m, n, device="cuda").bfloat16(), ld_resid=n) if epi != "plain" else {}
     if epi == "fc2":
         kw.update(bias=torch.randn(n, device="cuda").bfloat16(), drop_p=0.1, drop_key=12345)
     row, ref = [], None
-    for cfg in ("8p", "big4n"):
+    for cfg in ("8p", "4w", "big4n"):
         os.environ["CST_GEMM_FORCE_CFG"] = cfg
         ms = t(lambda: K.gemm(a, w, c, m, n, k, a_kmajor=1, b_kmajor=1, lda=k, ldb=k, ldc=n, split_k=1, **kw))
         if ref is None:
