@@ -1127,10 +1127,9 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
   const bool mid8p = !no_mid8p && ak && bk && !seg && nbatch == 1 && p.splits == 1 && d->M >= 256 && d->N >= 256 &&
                      cst_ceil_div(d->M, 256) * cst_ceil_div(d->N, 256) >= 150;
   static const bool no_narrow = getenv("CST_GEMM_NO_NARROW") != nullptr;
-  // gemm4w.hip (four waves, pinned issue order): 7-8 % faster than the 8-wave kernel on the N = 768 long-K launches in a timing loop,
-  // where the 195 MB operand stays in the Infinity Cache — and 8-11 % SLOWER on the K = 3072 ones inside the training step, where it
-  // comes from HBM and the kernel's one-K-tile prefetch distance is too short (K = 2304: -4 %).  Opt-in until it has a deeper ring.
-  static const bool no_4w = getenv("CST_GEMM_4W") == nullptr;
+  // gemm4w.hip (four waves, pinned issue order, three A stages): the N = 768 long-K launches of the step, same bits as the 8-wave
+  // kernel, 3-8 % faster inside the update (CST_GEMM_NO_4W=1: the 8-wave kernel everywhere, for A/B runs)
+  static const bool no_4w = getenv("CST_GEMM_NO_4W") != nullptr;
   static const bool experiment = getenv("CST_GEMM_EXPERIMENT") != nullptr;
   const char* force_cfg = experiment ? getenv("CST_GEMM_FORCE_CFG") : nullptr;
   if (force_cfg && !*force_cfg) force_cfg = nullptr;

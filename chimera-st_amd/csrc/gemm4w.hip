@@ -1,6 +1,6 @@
 // gemm4w.hip — the long-K, N = 768-family bf16 GEMM of libcst_hip: 256 x 192 x 64 tile, FOUR waves (one per SIMD), wave tile 128 x 96,
-// 192 accumulator registers per lane in the AGPR half of the register file, operands HBM/L2 -> LDS by buffer_load ... lds (two
-// stages), v_mfma_f32_32x32x16_bf16 with swapped operands, and the issue order of a K tile pinned by hand:
+// 192 accumulator registers per lane in the AGPR half of the register file, operands HBM/L2 -> LDS by buffer_load ... lds,
+// v_mfma_f32_32x32x16_bf16 with swapped operands, and the issue order of a K tile pinned by hand:
 //     { 2 MFMA ; one fragment read of the next k16 step ; one DMA of the next K tile }  x 6 per k16 step
 // A lone wave per SIMD has no partner to cover its LDS-DMA issues (~60 cycles each among MFMAs) or its fragment reads, so each sits
 // in the shadow of an MFMA pair; hipcc's own order of the same statements runs 20 % slower (DESIGN 5.1, round 4;
@@ -12,8 +12,11 @@
 // pre-activation output / act'.  RESULTS ARE THE BITS OF gemm8p's fast path: the bias row seeds the accumulators, K tiles and k16
 // steps in ascending order, ONE bf16 rounding of the accumulator (the pre-activation, as the reference's bf16 F.linear output),
 // dropout on that value, residual added in fp32, one more rounding.
-// LDS: 2 stages x (A image 32 KiB + B image 24 KiB); k-major images [rows][128 B], 16-byte chunk c of row r stored at c ^ ((r >> 1) & 7)
-// through the DMA's per-lane SOURCE address; ds_read_b128 fragments apply the same permutation (conflict-free).
+// LDS (144 KiB): THREE stages of the A image (32 KiB each) and two of the B image (24 KiB): inside a training update A — the
+// activations, 195 MB at 31 760 x 3072 — comes from HBM, and with two stages a lone wave has one K tile (~0.8 us) of prefetch distance:
+// the kernel was 7-8 % faster than the 8-wave one in a timing loop (operand resident in the 256 MB Infinity Cache) and 8-11 % slower
+// inside the update; with A two K tiles ahead it is 3-8 % faster there too.  k-major images [rows][128 B], 16-byte chunk c of row r
+// stored at c ^ ((r >> 1) & 7) through the DMA's per-lane SOURCE address; ds_read_b128 fragments apply the same permutation.
 // Rows of A beyond M come back as zeros through the buffer descriptor's range check; their outputs are not stored.
 #include "gemm_common.h"
 #include <cstdlib>
@@ -25,11 +28,13 @@ using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
 
 constexpr int BM = 256, TN = 3, BN = 64 * TN, BK = 64, NT = 256;
 static_assert(BM <= cstg::GEMM_MAX_BM && cstg::GEMM_MAX_BM % BM == 0, "conv0.hip (cst_conv_row_limits) sizes live frames from GEMM_MAX_BM");
-constexpr int IMGA = BM * 128, IMGB = BN * 128, STG = IMGA + IMGB;
+constexpr int IMGA = BM * 128, IMGB = BN * 128;
+constexpr int NSA = 3, NSB = 2;            // A (the activation rows: HBM-cold inside an update) rides three stages, B (the weight) two
+constexpr int BOFF = NSA * IMGA;           // LDS: A stages | B stages
 constexpr int GA = BM / 32, GB = BN / 32, G = GA + GB;  // 1-KiB DMA pieces per wave and K tile: 8 + 6
 constexpr int NSLOT = 2 * TN, NFR = 4 + TN;             // MFMA pairs per k16 step, fragments per k16 step
 constexpr int ERS = 2 * (BN / 2) + 16;                  // epilogue image (bf16, one wave's 128 x 96 block): row stride in bytes
-constexpr int LDS_BYTES = 2 * STG > 4 * 128 * ERS ? 2 * STG : 4 * 128 * ERS;
+constexpr int LDS_BYTES = NSA * IMGA + NSB * IMGB > 4 * 128 * ERS ? NSA * IMGA + NSB * IMGB : 4 * 128 * ERS;  // 144 KiB
 
 __global__ __launch_bounds__(NT) void gemm4w_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -71,14 +76,18 @@ __global__ __launch_bounds__(NT) void gemm4w_kernel(GemmParams p) {
                                                                          (int)((unsigned)(mrem - 1) * lda2 + (unsigned)(p.K * 2)), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.B + n0 * p.ldb), (short)0,
                                                                          (int)((unsigned)(BN - 1) * ldb2 + (unsigned)(p.K * 2)), 0x00020000);
-  auto dma = [&](int d, int kt, int stg) {  // d < GA: A rows 8 (wave + 4 d) ..; else B rows 8 (wave + 4 (d - GA)) ..
-    const int i = d < GA ? d : d - GA;
-    char* dst = smem + stg * STG + (d < GA ? 0 : IMGA) + (wave + 4 * i) * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(d < GA ? rsA : rsB, (__attribute__((address_space(3))) void*)dst, 16, (int)(d < GA ? voffa : voffb),
-                                             (int)((unsigned)(32 * i) * (d < GA ? lda2 : ldb2) + (unsigned)kt * 128u), 0, 0);
+  auto dma_a = [&](int i, int kt, int stg) {  // A rows 8 (wave + 4 i) .. of K tile kt -> A stage stg
+    char* dst = smem + stg * IMGA + (wave + 4 * i) * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)dst, 16, (int)voffa,
+                                             (int)((unsigned)(32 * i) * lda2 + (unsigned)kt * 128u), 0, 0);
+  };
+  auto dma_b = [&](int i, int kt, int stg) {
+    char* dst = smem + BOFF + stg * IMGB + (wave + 4 * i) * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)dst, 16, (int)voffb,
+                                             (int)((unsigned)(32 * i) * ldb2 + (unsigned)kt * 128u), 0, 0);
   };
   const int swr = (lrow >> 1) & 7;
-  const unsigned fa0 = (unsigned)((wm * 128 + lrow) * 128), fb0 = (unsigned)(IMGA + (wn * 32 * TN + lrow) * 128);
+  const unsigned fa0 = (unsigned)((wm * 128 + lrow) * 128), fb0 = (unsigned)(BOFF + (wn * 32 * TN + lrow) * 128);
   unsigned fch[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) fch[kk] = (unsigned)(((2 * kk + hi) ^ swr) << 4);
@@ -105,24 +114,37 @@ __global__ __launch_bounds__(NT) void gemm4w_kernel(GemmParams p) {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   }
 
+  // Ring: during K tile kt the wave issues B(kt + 1) (slots 0..5) and then A(kt + 2) (slots 6..13).  At the head of tile kt the newest
+  // eight pieces in flight are A(kt + 1): vmcnt(8) retires B(kt) and A(kt) and leaves them travelling — two K tiles of flight time
+  // for the cold operand.  WAR: A stage (kt + 2) % 3 and B stage (kt + 1) % 2 were last read during tile kt - 1, behind the barrier.
   if (nkt > 0) {
 #pragma unroll
-    for (int d = 0; d < G; ++d) dma(d, 0, 0);
+    for (int i = 0; i < GA; ++i) dma_a(i, 0, 0);
+#pragma unroll
+    for (int i = 0; i < GB; ++i) dma_b(i, 0, 0);
+    if (nkt > 1) {
+#pragma unroll
+      for (int i = 0; i < GA; ++i) dma_a(i, 1, 1);
+    }
   }
   bf16x8 fa[2][4], fb[2][TN];
+  int sa = 0;  // A stage of tile kt
   for (int kt = 0; kt < nkt; ++kt) {
-    const int st = kt & 1;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's pieces of tile kt have landed; its reads of the other stage are done
+    const int sb = kt & 1;
+    if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");  // (A(kt + 1) may still be on its way)
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    const char* rbase = smem + st * STG;
+    const char* abase = smem + sa * IMGA;
+    const char* bbase = smem + sb * IMGB;
     auto read_one = [&](int f, int kk, int nb) {
-      if (f < 4) fa[nb][f] = *reinterpret_cast<const bf16x8*>(rbase + fa0 + f * 4096 + fch[kk]);
-      else fb[nb][f - 4] = *reinterpret_cast<const bf16x8*>(rbase + fb0 + (f - 4) * 4096 + fch[kk]);
+      if (f < 4) fa[nb][f] = *reinterpret_cast<const bf16x8*>(abase + fa0 + f * 4096 + fch[kk]);
+      else fb[nb][f - 4] = *reinterpret_cast<const bf16x8*>(bbase + fb0 + (f - 4) * 4096 + fch[kk]);
     };
 #pragma unroll
     for (int f = 0; f < NFR; ++f) read_one(f, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    const bool more = kt + 1 < nkt;
+    const bool more_b = kt + 1 < nkt, more_a = kt + 2 < nkt;
+    const int sa2 = sa == 0 ? 2 : sa - 1;  // (kt + 2) % 3
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
@@ -136,10 +158,15 @@ __global__ __launch_bounds__(NT) void gemm4w_kernel(GemmParams p) {
           if (sl < NFR) read_one(sl, kk + 1, (kk + 1) & 1);
           if (sl == 0) read_one(NSLOT, kk + 1, (kk + 1) & 1);  // seven fragments, six slots
         }
-        if (kk * NSLOT + sl < G && more) dma(kk * NSLOT + sl, kt + 1, st ^ 1);
+        {
+          const int d = kk * NSLOT + sl;
+          if (d < GB) { if (more_b) dma_b(d, kt + 1, sb ^ 1); }
+          else if (d < G) { if (more_a) dma_a(d - GB, kt + 2, sa2); }
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    sa = sa == 2 ? 0 : sa + 1;
   }
   static_assert(NFR == NSLOT + 1, "the slot plan above places exactly one extra fragment read");
 

@@ -1433,7 +1433,7 @@ def test_four_wave_instantiations_of_the_dma_gemm_keep_the_bits():
     """The experiment-hook configurations big4 / big4n (gemm_glds_kernel with four waves and 128-row wave tiles: pinned issue order,
     per-wave epilogue, swapped accumulator layout — DESIGN 5.1, round 4) against whatever the dispatcher picks: plain bf16 stores of
     the same products in the same K order are the same bits, ragged M / N edges and a K tail included.  And gemm4w.hip (the lean
-    kernel of the same shape, opt-in: CST_GEMM_4W=1) against the persistent 8-wave kernel with bias + dropout + residual, residual
+    kernel of the same shape: the N = 768 long-K launches of the step) against the persistent 8-wave kernel with bias + dropout + residual, residual
     + live-tile stamps, rows beyond M: the same bits.  (Own process: the hook's environment switch is read once per process.)"""
     import os
     import subprocess
