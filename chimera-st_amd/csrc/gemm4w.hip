@@ -250,10 +250,12 @@ bool cst_gemm4w_supported(const cstg::GemmParams& p, bool ak, bool bk, int64_t n
   if (p.lda * 2 * 256 + p.K * 2 >= (1ll << 31) || p.ldb * 2 * 256 >= (1ll << 31)) return false;  // 32-bit offsets inside a tile's descriptor
   // One tile per workgroup, so the launch costs whole rounds of 256 CUs; the persistent 8-wave kernel (half-height tail items, claimed
   // work) degrades more gently.  Measured with the residual epilogue at K = 1536 / 2304 / 3072 (tools/_ab sweep): this
-  // kernel wins by 5-9 % at 1.0 and 1.47-2.0 rounds, loses by 20-40 % just above a whole round and from ~3.4 rounds on.
+  // kernel wins by 5-9 % at 1.0, 1.47-2.0 and 2.7-3.0 rounds, loses by 20-40 % just above a whole round and from ~3.4 rounds on.
   const int64_t tiles = cst_ceil_div(p.M, BM) * (p.N / BN);
   const int64_t r = tiles % 256;
-  return tiles >= 256 && tiles <= 512 && (r == 0 || r >= 115);
+  // (third round: only when it is at least two thirds full — 752 tiles, the all-30 s batch: 88.5-89.4 ms per update against 89.0-91.0)
+  static const int64_t max_tiles = [] { const char* e = getenv("CST_GEMM_4W_MAXTILES"); return e ? (int64_t)atoll(e) : (int64_t)768; }();
+  return tiles >= 256 && tiles <= max_tiles && (r == 0 || r >= (tiles > 512 ? 170 : 115));
 }
 
 int cst_gemm4w_launch(cstg::GemmParams p, hipStream_t s) {
