@@ -48,7 +48,7 @@ __global__ __launch_bounds__(NT) void gemm4w_kernel(GemmParams p) {
     const int q = ntiles / 8, r = ntiles % 8, xcd = id % 8, loc = id / 8;
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
-  constexpr int GROUP_M = 8;
+  const int GROUP_M = p.group_m;
   const int per_group = GROUP_M * p.tiles_n;
   const int grp = id / per_group, rem = id % per_group;
   const int gm0 = grp * GROUP_M;
@@ -266,6 +266,8 @@ int cst_gemm4w_launch(cstg::GemmParams p, hipStream_t s) {
   }
   p.tiles_m = (int)cst_ceil_div(p.M, BM);
   p.tiles_n = (int)(p.N / BN);
+  static const int group_m = [] { const char* e = getenv("CST_GEMM_4W_GROUP_M"); const int g = e ? atoi(e) : 8; return g > 0 ? g : 8; }();
+  p.group_m = group_m;  // m tiles per group of the tile walk (an XCD's concurrent workgroups cover group_m x tiles_n tiles)
   hipLaunchKernelGGL(gemm4w_kernel, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(NT), LDS_BYTES, s, p);
   return cst_check_launch("cst_gemm (4-wave)");
 }
