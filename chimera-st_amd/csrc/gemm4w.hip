@@ -249,7 +249,7 @@ bool cst_gemm4w_supported(const cstg::GemmParams& p, bool ak, bool bk, int64_t n
   if (p.bias_mode != CST_BIAS_NONE && (p.bias_mode != CST_BIAS_COL || p.alpha != 1.0f)) return false;
   if (p.lda * 2 * 256 + p.K * 2 >= (1ll << 31) || p.ldb * 2 * 256 >= (1ll << 31)) return false;  // 32-bit offsets inside a tile's descriptor
   // One tile per workgroup, so the launch costs whole rounds of 256 CUs; the persistent 8-wave kernel (half-height tail items, claimed
-  // work) degrades more gently.  Measured with the residual epilogue at K = 1536 / 2304 / 3072 (tools/_ab sweep): this
+  // work) degrades more gently.  Measured with the residual epilogue at K = 1536 / 2304 / 3072 (tools/bench_gemm4w_sweep.py): this
   // kernel wins by 5-9 % at 1.0, 1.47-2.0 and 2.7-3.0 rounds, loses by 20-40 % just above a whole round and from ~3.4 rounds on.
   const int64_t tiles = cst_ceil_div(p.M, BM) * (p.N / BN);
   const int64_t r = tiles % 256;
