@@ -2,7 +2,8 @@
 """bench.py — train utterances/sec of the Chimera-ST hot path on MI355X (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1: launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...; started
+   plainly, `python bench.py --gpus N` launches its N rank processes itself)
 
 Workload (config.workload): BASELINE configs[1] — `s2t_transformer_w2v2` with the s2t_transformer_m dimensions
 (d 512, ffn 2048, 8 heads, 12 encoder + 6 decoder layers, tied 10 000-way vocabulary) behind the full wav2vec2-small
@@ -430,7 +431,14 @@ def main():
     args = ap.parse_args()
 
     dist_mod = importlib.import_module("chimera-st_amd.distributed")
+    if dist_mod.needs_self_launch(args.gpus):
+        # started plainly (`python bench.py --gpus N`, as the driver starts the N = 1 run): this process has not touched the GPU and
+        # becomes the launcher — N rank processes with the torchrun environment, rank 0's JSON line on our stdout
+        # (fairseq/distributed_utils.py:286-303).  Under torchrun (WORLD_SIZE set) nothing changes.
+        sys.exit(dist_mod.launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
     rank, world = dist_mod.distributed_init()
+    if os.environ.get("CST_BENCH_FAIL_RANK") == str(rank):  # (tests: a rank that dies must take the self-launched job down with it)
+        sys.exit(7)
     assert world == args.gpus or (world == 1 and args.gpus == 1), "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)

@@ -17,7 +17,7 @@ import time
 import torch
 
 from . import checkpoint_utils, criterions, registry, s2t_transformer, tasks, w2v2_transformer, w2v2_transformer_interlingua  # noqa: F401
-from .distributed import distributed_init
+from .distributed import distributed_init, launch_ranks, needs_self_launch
 from .trainer import Trainer
 
 
@@ -76,6 +76,19 @@ def train_main(argv=None):
         setattr(args, k, v)
     if args.fp16 or getattr(args, "memory_efficient_fp16", False):
         args.fp16, args.memory_efficient_fp16, args.bf16 = False, False, True
+    # Started plainly on a multi-GPU node, fairseq-train spawns one process per GPU itself (fairseq/distributed_utils.py:286-303,
+    # nprocs = min(device_count, distributed_world_size); the flag's default is the device count, options.py:310).  Same here: this
+    # process has not touched the GPU yet (device_count() does not initialise it) and becomes the launcher of the rank processes.
+    if "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        ndev = torch.cuda.device_count()
+        want = args.distributed_world_size if args.distributed_world_size is not None else max(ndev, 1)
+        nproc = want if os.environ.get("CST_DIST_BACKEND") else min(max(ndev, 1), want)  # (gloo: ranks may share a GPU — tests)
+        if needs_self_launch(nproc):
+            entry = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fairseq_train.py")
+            code = launch_ranks(nproc, [sys.executable, entry] + argv)
+            if code != 0:
+                raise SystemExit(code)
+            return None
     rank, world = distributed_init()
     device = torch.device("cuda", torch.cuda.current_device())
     torch.manual_seed(args.seed)

@@ -38,6 +38,59 @@ def distributed_init(backend=None):
     return rank, world
 
 
+def needs_self_launch(nproc):
+    """True when this process was started plainly (no torchrun-style rank environment) for a job of nproc > 1 ranks."""
+    return int(nproc) > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ
+
+
+def launch_ranks(nproc, argv, env=None):
+    """Start one process per GPU ourselves — what the reference's entry point does when it is started plainly on a multi-GPU node
+    (fairseq/distributed_utils.py:286-303: call_main -> torch.multiprocessing.spawn(distributed_main, nprocs=min(device_count,
+    distributed_world_size)), rank = start_rank + i, device_id = i).  The caller is a parent that has NOT touched the GPU (no HIP
+    call, no torch.cuda.is_available()): children are fresh interpreters started with `argv` and RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set, i.e. exactly what `python -m torch.distributed.run` would have given them, so the rank code path
+    is the same either way.  Rank 0 inherits stdout (its ONE JSON line is the job's output); the other ranks' stdout goes to stderr.
+    Returns 0 when every rank exits 0; otherwise the survivors are terminated (their exact PIDs) and the first failing code is
+    returned."""
+    import socket
+    import subprocess
+    import sys
+    import time
+    nproc = int(nproc)
+    base = dict(os.environ if env is None else env)
+    if "MASTER_PORT" not in base:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        base["MASTER_PORT"] = str(s.getsockname()[1])
+        s.close()
+    base.setdefault("MASTER_ADDR", "127.0.0.1")
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(nproc):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nproc), LOCAL_WORLD_SIZE=str(nproc))
+        procs.append(subprocess.Popen(list(argv), env=e, stdout=None if r == 0 else sys.stderr))
+    code = 0
+    alive = set(range(nproc))
+    while alive:
+        for r in sorted(alive):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            alive.discard(r)
+            if rc != 0 and code == 0:
+                code = rc if rc > 0 else 1
+                sys.stderr.write("rank %d exited with code %d: stopping the other ranks\n" % (r, rc))
+                for o in sorted(alive):
+                    procs[o].terminate()
+        time.sleep(0.05)
+    for pr in procs:
+        try:
+            pr.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+    return code
+
+
 _UNUSED_LISTENERS = []
 
 
@@ -80,9 +133,16 @@ class BucketedGradAllReduce:
             for idx in bk["members"]:
                 self.param_bucket[idx] = b
         self.enabled = True
-        # CUs the persistent GEMMs leave to the all-reduce kernels while buckets are in flight (first-8-GPU-run knob; 0 = off):
-        # --ddp-reserve-cus / CST_DDP_RESERVE_CUS.  Bucket size: --bucket-cap-mb / CST_BUCKET_CAP_MB.
-        self.reserve_cus = int(os.environ.get("CST_DDP_RESERVE_CUS", "0"))
+        # CUs the persistent GEMMs leave to the all-reduce kernels WHILE a bucket is in flight (--ddp-reserve-cus / CST_DDP_RESERVE_CUS;
+        # bucket size: --bucket-cap-mb / CST_BUCKET_CAP_MB).  Default with more than one rank: 32 = one XCD's worth, 12.5 % of the chip.
+        # The persistent GEMM grids own one workgroup per CU, so an RCCL kernel that becomes runnable under them only gets CUs at a GEMM
+        # launch boundary; its ring kernels run a few dozen workgroups (one per channel).  The reservation is taken when a bucket is
+        # launched and dropped as soon as the gradient hooks see every launched collective completed (is_completed(): an event query),
+        # so it is on for about the collectives' own duration (~0.3 ms per 64 MiB bucket at xGMI ring rates) plus the host's lead over
+        # the GPU, not for the whole backward pass: 12.5 % of the GEMM rate over a few ms per update is the bounded price.  UNMEASURED
+        # on more than one GPU (no multi-GPU hardware reached this build): the first 8-GPU session sweeps it (0 switches it off).
+        env_r = os.environ.get("CST_DDP_RESERVE_CUS")
+        self.reserve_cus = int(env_r) if env_r is not None else (32 if self.world > 1 else 0)
         # CST_DDP_COLLECTIVE = allreduce (default) | rs_ag: the gradient exchange of a bucket as reduce-scatter + all-gather
         self.collective = os.environ.get("CST_DDP_COLLECTIVE", "allreduce")
         if self.collective not in ("allreduce", "rs_ag"):
@@ -94,21 +154,23 @@ class BucketedGradAllReduce:
         self._offsets = list(offsets)
         self._hooks = []
         self._index = {id(p): idx for idx, p in enumerate(self.params)}
-        # Gradient hooks on a FEW parameters per bucket only — the ones expected to arrive last (lowest offsets: gradients arrive
-        # roughly in reverse parameter order) — each of which re-examines the buckets in launch order.  A Python hook on each of the
-        # ~300 parameters cost the backward pass of the 512-wide layers 10-15 us of host time per parameter, in the phase where the
-        # host is the bound (1-rank RCCL run: 63.0 -> 66.5 ms per update; profiles/r04_ddp1_idle_gaps.txt).  A bucket is ready when
-        # every member has a gradient or was reported unused; if the order of arrival is not the expected one the bucket simply
-        # leaves with a later trigger (or in finish()) — correct either way.
-        per_bucket = int(os.environ.get("CST_DDP_HOOKS_PER_BUCKET", "3"))
-        self._hooked = set()
-        for bk in self.buckets:
-            by_off = sorted(bk["members"], key=lambda i: self._offsets[i])
-            self._hooked.update(by_off if per_bucket <= 0 else by_off[:per_bucket])
-        for idx in sorted(self._hooked):
-            self._hooks.append(self.params[idx].register_post_accumulate_grad_hook(self._make_hook(idx)))
+        # Arrival is an explicit RECORD, never inferred from tensor state: every parameter carries a post-accumulate hook that notes
+        # "the gradient of this pass exists" and counts its bucket down (O(1): a set insert and a decrement; the bucket at the head of
+        # the launch order leaves when its count reaches zero).  Round 4 hooked three parameters per bucket and read the others'
+        # arrival off `p.grad._version`; the gradients written straight into the flat buffer (optim.grad_slot) are views that share
+        # ONE version counter with every other view of it, so in an accumulated update (update_freq > 1) the first in-place add of the
+        # last micro-batch, or a bucket's `div_`, made every slot-written weight look arrived at once and buckets left before their
+        # members' gradients existed (advisor, round 4; tests/test_host_cpu.py::test_accumulated_update_with_slot_written_gradients).
+        # Measured on one GPU (1-rank RCCL group, same box, round 4): a hook per parameter 63.8 ms per update, three per bucket 63.9.
+        for idx, p in enumerate(self.params):
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(idx)))
         _UNUSED_LISTENERS.append(self._on_unused)
         self.reset()
+
+    def _account(self, idx):
+        if idx not in self._done:
+            self._done.add(idx)
+            self._pending[self.param_bucket[idx]] -= 1
 
     def _on_unused(self, params):
         if not self.enabled or not self.active:
@@ -117,6 +179,7 @@ class BucketedGradAllReduce:
             idx = self._index.get(id(p))
             if idx is not None:
                 self._skipped.add(idx)  # (a bucket is never launched from here: only from a gradient hook, i.e. during backward)
+                self._account(idx)
 
     def reset(self):
         if getattr(self, "_reserved", False):  # a backward pass that raised before finish(): the reservation is process-global
@@ -124,33 +187,38 @@ class BucketedGradAllReduce:
         for idx in getattr(self, "_frozen", ()):
             self.params[idx]._cst_slot_frozen = False
         self._frozen = []          # parameters whose flat-buffer slot travelled without their gradient (optim.grad_slot must not hand it out)
-        self._without = []         # per launched bucket: the reported-unused members that had no gradient when it left
+        self._absent = set()       # the same, as a set: members of a launched bucket whose gradient hook had not fired when it left
+        self._late = set()         # ... and fired afterwards
         self._next = 0
         self._works = []
-        self._skipped = set()
-        self._fired = set()
-        self._base = {}
+        self._skipped = set()      # reported unused for this pass (notify_unused_parameters)
+        self._fired = set()        # gradient hook fired in this (reducing) pass
+        self._done = set()         # accounted for in its bucket's count: fired or reported unused
+        self._pending = [len(bk["members"]) for bk in self.buckets]
 
     def arm(self):
-        """Called when the reducer is (re-)enabled for the LAST backward pass of an update: gradients accumulated by earlier
-        micro-batches (no_sync) are already there, so "this parameter has arrived" means its gradient was ADDED to since now —
-        autograd accumulates in place, which bumps the tensor's version.  Nothing to remember in the common case (no gradient yet)."""
-        self._base = {i: p.grad._version for i, p in enumerate(self.params) if p.grad is not None}
+        """Called when the reducer is (re-)enabled for the LAST backward pass of an update.  Nothing to snapshot: what the accumulation
+        passes (no_sync) left in p.grad says nothing about this pass — only this pass's hooks do."""
+        return None
 
     def _arrived(self, i):
-        g = self.params[i].grad
-        return g is not None and (i not in self._base or g._version != self._base[i])
+        return i in self._fired
 
     def _bucket_ready(self, b):
-        sk = self._skipped
-        return all(i in sk or self._arrived(i) for i in self.buckets[b]["members"])
+        return self._pending[b] == 0
 
     def _make_hook(self, idx):
         def hook(param):
             if not self.enabled or not self.active:
                 return
             b = self.param_bucket[idx]
-            if idx in self._fired and b < self._next:
+            if b < self._next:
+                if idx in self._absent and idx not in self._fired:
+                    # reported unused, took part after all, and its bucket has left without it: reduced again, alone (late_reduce).
+                    # Its slot is frozen (optim.grad_slot) and _launch dropped p.grad, so this gradient is a tensor of its own.
+                    self._fired.add(idx)
+                    self._late.add(idx)
+                    return
                 # a second backward pass through the same parameter after its bucket has left: p.grad IS the flat-buffer slice the
                 # asynchronous all-reduce is writing (gather_grads re-points it), so autograd's in-place accumulation races with the
                 # collective and the slice already holds the mean.  Accumulate under no_sync() instead (update_freq micro-batches
@@ -158,7 +226,11 @@ class BucketedGradAllReduce:
                 raise RuntimeError("gradient of parameter %d arrived a second time after its bucket's all-reduce was launched: "
                                    "run every backward pass but the last one under DistributedFairseqModel.no_sync()" % idx)
             self._fired.add(idx)
-            self._launch_ready()
+            self._account(idx)
+            if self._pending[self._next] == 0:
+                self._launch_ready()
+            elif self._reserved and all(w.is_completed() for w in self._works):
+                self._set_reserved(False)  # nothing in flight any more: the GEMMs get the whole chip back until the next bucket leaves
 
         return hook
 
@@ -170,16 +242,21 @@ class BucketedGradAllReduce:
         # members that travel without a gradient (reported unused, or never used): should one of them get a gradient after all
         # (layerdrop reported it and it took part anyway) it is reduced again, alone (late_reduce) — and must not be written into
         # its slot of the flat buffer while the collective owns that memory (optim.grad_slot)
-        absent = [i for i in bk["members"] if not self._arrived(i)]
+        absent = [i for i in bk["members"] if i not in self._fired]
         for i in absent:
             self.params[i]._cst_slot_frozen = True
         self._frozen.extend(absent)
-        self._without.append(absent)
+        self._absent.update(absent)
         if self.gather is not None:
             self.gather(bk["members"])
+        for i in absent:
+            # what earlier micro-batches accumulated for such a member (update_freq > 1) travels with the bucket and is in the flat
+            # buffer now; a late gradient of THIS pass must not be added in place into the travelling slice, so it gets a tensor of
+            # its own and late_reduce adds its mean on top
+            self.params[i].grad = None
         g = self.flat_grad[bk["lo"]:bk["hi"]]
         g.div_(self.world)
-        if self.reserve_cus > 0 and not self._reserved:  # from the first bucket in flight until finish()
+        if self.reserve_cus > 0 and not self._reserved:  # while a bucket is in flight (released by the hooks / finish())
             self._set_reserved(True)
         n = g.numel()
         if self.collective == "rs_ag" and n % self.world == 0 and n > 0:
@@ -211,37 +288,37 @@ class BucketedGradAllReduce:
         """Second, rank-agreed reduction of the parameters whose bucket left without the gradient of SOME rank.  late_by_rank[r] =
         the set of parameter indices that were late on rank r (every rank holds the same table: the trainer all-gathers the 0/1
         masks; a rank that lost its forward pass to an out-of-memory error has an empty set, and an update that is going to be
-        dropped skips the call).  For a parameter in the union, a rank where it was late holds its own raw gradient (the bucket
-        carried zeros for it) and contributes gradient / world; the ranks where it was on time all hold the same partial mean
-        S = sum over the on-time ranks / world: the lowest of them contributes S, the others zeros.  The sum is the mean over all
-        ranks, exactly.  Only the late parameter's slice is touched, so the other members of its bucket are not divided again."""
+        dropped skips the call).  After the bucket's collective every rank's slot holds S = (sum over the on-time ranks' gradients
+        + what the late ranks had accumulated in earlier micro-batches) / world.  What is missing is the late ranks' gradient of
+        this pass: a rank where the parameter was late contributes gradient / world (a tensor of its own: the slot was frozen and
+        _launch dropped p.grad), every other rank zeros, and the all-reduced correction is ADDED to the slot — the mean over all
+        ranks, and only the late parameter's slice is touched, so the other members of its bucket are not divided again."""
         rank = dist.get_rank(self.pg)
         union = sorted(set().union(*late_by_rank))
         works = []
         for idx in union:
             p = self.params[idx]
-            g = self.flat_grad[self._offsets[idx]:self._offsets[idx] + p.numel()]
+            n = p.numel()
             if idx in late_by_rank[rank]:
-                if self.gather is not None:
-                    self.gather([idx])
-                g.div_(self.world)
+                t = (p.grad.detach().reshape(-1) / self.world).to(self.flat_grad.dtype)
             else:
-                on_time = [r for r in range(self.world) if idx not in late_by_rank[r]]
-                if rank != on_time[0]:
-                    g.zero_()
-            works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
-        for w in works:
+                t = torch.zeros(n, dtype=self.flat_grad.dtype, device=self.flat_grad.device)
+            works.append((idx, t, dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)))
+        for idx, t, w in works:
             w.wait()
+            view = self.flat_grad[self._offsets[idx]:self._offsets[idx] + t.numel()]
+            view.add_(t)
+            self.params[idx].grad = view.view(self.params[idx].shape)
 
     def finish(self):
         """Launch whatever has not been reduced yet (parameters without gradient stay zero) and wait for everything.  Leaves the
         parameters that need a second, rank-agreed reduction in `late_params` (see late_reduce)."""
         self.late_params = []
         if self.active and self.enabled:
-            self._launch_ready()  # (a bucket whose last gradient came from a parameter without a hook)
+            self._launch_ready()
             # overlap bookkeeping of the update that just ended: buckets launched during backward, parameters nobody accounted for
             self.last_early = self._next
-            self.last_missing = [i for i in range(len(self.params)) if not self._arrived(i) and i not in self._skipped]
+            self.last_missing = [i for i in range(len(self.params)) if i not in self._done]
             while self._next < len(self.buckets):
                 self._launch(self._next)
                 self._next += 1
@@ -251,7 +328,7 @@ class BucketedGradAllReduce:
             if self._reserved:
                 self._set_reserved(False)
             # a gradient that exists now for a member that travelled without one: reported unused, took part after its bucket had left
-            self.late_params = sorted(i for absent in self._without for i in absent if self._arrived(i))
+            self.late_params = sorted(self._late)
         self.reset()
 
 

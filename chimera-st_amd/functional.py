@@ -137,8 +137,11 @@ class _WeightTransposes:
             stale = []
             for k, v in list(self.entries.items()):
                 t = self._src(v)
-                if t is None:
+                if t is None or t.data_ptr() != k[0]:
+                    # dead, or a Parameter re-homed since it was cached (FlatParamBuffers: `p.data = view`): it is asked for under
+                    # its new address from now on; this entry would be re-transposed every update into a copy nobody reads
                     del self.entries[k]
+                    self.tables.pop(kind, None)
                 elif t.device == w.device and k[2] == w.dtype and v[3] != epoch:
                     stale.append(v)
             ids = [id(v) for v in stale]

@@ -118,7 +118,7 @@ def add_common_args(parser):
     g.add_argument("--warmup-init-lr", type=float, default=-1)
     g.add_argument("--clip-norm", type=float, default=0.0)
     g.add_argument("--ddp-backend", default="no_c10d")
-    g.add_argument("--distributed-world-size", type=int, default=1)
+    g.add_argument("--distributed-world-size", type=int, default=None, help="ranks to start when launched plainly (default: one per visible GPU, options.py:310)")
     g.add_argument("--bucket-cap-mb", type=int, default=25)
     g.add_argument("--ddp-reserve-cus", type=int, default=None, help="CUs the persistent GEMMs leave to the gradient all-reduce while "
                    "buckets are in flight under the backward pass (distributed.BucketedGradAllReduce.reserve_cus)")

@@ -44,19 +44,33 @@ class Trainer:
         for p in model.parameters():
             if seen.get(id(p), 1) > 1:
                 p._cst_shared = True  # (modules mark parameters they apply twice in one pass themselves: the memory layers' LayerNorm)
+        self._defer_cache = None  # (criterion id, decision, the parameters THIS trainer marked for it)
+
         def _defer_ok():
-            if not getattr(self._model, "single_use_parameters", False):
-                return False
-            if getattr(self.criterion, "single_pass", False):
-                return True
-            # two passes that share the decoder call (TripletSTMTContrastiveCriterion.one_decoder_pass): the parameters both passes run
-            # through are named by the criterion and marked; all the others receive one gradient per backward pass
-            twice = getattr(self.criterion, "twice_used", lambda m: None)(self._model)
-            if twice is None:
-                return False
-            for p in twice:
-                p._cst_shared = True
-            return True
+            # decided once per (criterion, environment switches the criterion's twice_used reads): the walk over named_parameters is
+            # not an every-update cost, and marks set for one criterion are taken back before another one is evaluated
+            key = (id(self.criterion),) + tuple(os.environ.get(k) for k in ("CST_NO_PACK", "CST_NO_PAIR_DECODER", "CST_NO_PAIR_ENCODER", "CST_NO_PAIR_MEMORY"))
+            if self._defer_cache is not None and self._defer_cache[0] == key:
+                return self._defer_cache[1]
+            if self._defer_cache is not None:
+                for p in self._defer_cache[2]:
+                    p._cst_shared = False
+            marked, ok = [], False
+            if getattr(self._model, "single_use_parameters", False):
+                if getattr(self.criterion, "single_pass", False):
+                    ok = True
+                else:
+                    # two passes that share the decoder call (TripletSTMTContrastiveCriterion.one_decoder_pass): the parameters both
+                    # passes run through are named by the criterion and marked; all the others receive one gradient per backward pass
+                    twice = getattr(self.criterion, "twice_used", lambda m: None)(self._model)
+                    if twice is not None:
+                        ok = True
+                        for p in twice:
+                            if not getattr(p, "_cst_shared", False):
+                                p._cst_shared = True
+                                marked.append(p)
+            self._defer_cache = (key, ok, marked)
+            return ok
 
         self._defer_ok = _defer_ok
         self.optimizer.defer_reductions = self._defer_ok()

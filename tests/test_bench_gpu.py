@@ -79,6 +79,26 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
     assert d["cpu_baseline"] is None and not d.get("extra")  # the CPU baseline and the extra legs belong to the N = 1 line
 
 
+def test_bench_launches_its_own_ranks_when_started_plainly():
+    """`python3 bench.py --gpus 2` with NO rank variables — the way the driver starts the N = 1 run: the parent (which never touches the
+    GPU) starts the two rank processes itself (distributed.launch_ranks; fairseq/distributed_utils.py:286-303), relays rank 0's line and
+    exits 0.  gloo on the shared GPU stands in for RCCL on two GPUs (CST_DIST_BACKEND)."""
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+    e["CST_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+                        "--seconds", "3"], capture_output=True, text=True, timeout=900, env=e, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and r.stdout.strip().splitlines()[-1] == lines[0]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 8 and d["value"] > 0
+    # a rank that fails takes the job down with its exit code instead of leaving the others in a collective
+    e["CST_BENCH_FAIL_RANK"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2",
+                        "--seconds", "2"], capture_output=True, text=True, timeout=900, env=e, cwd=ROOT)
+    assert r.returncode == 7 and "rank 1 exited with code 7" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
 def test_bench_decode_line_contract():
     """--mode decode (BASELINE configs[4]) on a reduced workload: the same one-line contract, an HBM-bound roofline object."""
     e = dict(os.environ)

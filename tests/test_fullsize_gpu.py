@@ -15,11 +15,11 @@ from conftest import ROOT, load_pkg
 pytestmark = pytest.mark.gpu
 
 
-def _build(batch=4):
+def _build(batch=4, dropout=0.0):
     sys.path.insert(0, ROOT)
     import bench
     load_pkg()
-    args = Namespace(batch=batch, seconds=30.0, lengths="uniform", dtype="bf16", model="s2t_w2v2", dropout=0.0, layerdrop=0.0)
+    args = Namespace(batch=batch, seconds=30.0, lengths="uniform", dtype="bf16", model="s2t_w2v2", dropout=dropout, layerdrop=0.0)
     torch.manual_seed(1)
     trainer, task, tasks, ns = bench.build(args, torch.device("cuda", 0))
     return trainer, bench.make_batch(tasks, task, args, 0, torch.device("cuda", 0))
@@ -37,6 +37,41 @@ def _loss_and_grads(trainer, sample, overlap=False):
         loss.backward()
     trainer.buffers.gather_grads()
     return float(loss), trainer.buffers.flat_grad.clone()
+
+
+def test_the_bench_batch_itself_is_bit_reproducible_and_its_loss_is_the_one_bench_prints():
+    """The batch bench.py times — `bench.make_batch` at B = 32 x <= 30 s uniform lengths (31 512 packed wav2vec2 rows, 32 sequences), the
+    training recipe's dropout 0.1 — is the one shape no other test executes.  Properties that do not need the oracle at this size:
+    loss and every gradient bit-equal run to run (counter-based dropout masks, fixed-order reductions) and with the exact key-tile /
+    dead-tile skipping switched off; the padded (CST_NO_PACK) stack gives the same loss to bf16 rounding of a different row layout;
+    and the first update's loss is bit-equal to what `bench.py --steps 1 --warmup 0` prints on its line for that update."""
+    import json
+    import subprocess
+    trainer, sample = _build(batch=32, dropout=0.1)
+    assert sample["net_input"]["src_tokens"].shape[0] == 32
+    l1, g1 = _loss_and_grads(trainer, sample, overlap=True)
+    l2, g2 = _loss_and_grads(trainer, sample, overlap=True)
+    assert torch.isfinite(g1.float()).all() and float(g1.float().norm()) > 0
+    assert l1 == l2 and torch.equal(g1, g2), "B = 32 update differs run to run: %r vs %r, %d elements" % (l1, l2, int((g1 != g2).sum()))
+    os.environ["CST_ATTN_NO_KVLEN"] = "1"
+    os.environ["CST_GEMM_NO_KLIVE"] = "1"
+    try:
+        l3, g3 = _loss_and_grads(trainer, sample, overlap=True)
+    finally:
+        del os.environ["CST_ATTN_NO_KVLEN"], os.environ["CST_GEMM_NO_KLIVE"]
+    assert l3 == l1, "switching the tile skipping off changed the loss: %r vs %r" % (l3, l1)
+    # (m_live / k_live change the split-K cuts of the weight gradients: same values to fp32 summation order, not the same bits)
+    rel = float((g3.float() - g1.float()).norm() / g1.float().norm())
+    assert rel < 2e-3, rel
+    out = trainer.train_step([sample])  # the update bench.py times: same seed (args.seed + num_updates = 1), same batch
+    assert out is not None and abs(float(out["loss"]) - l1) <= 1e-6 * abs(l1), (out["loss"], l1)
+    del trainer, sample, g1, g2, g3
+    torch.cuda.empty_cache()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline",
+                        "--no-extra"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["batch_per_gpu"] == 32 and d["config"]["loss"] == float(out["loss"]), (d["config"]["loss"], float(out["loss"]))
 
 
 def test_full_size_update_properties():

@@ -14,7 +14,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import load_golden, load_pkg
+from conftest import ROOT, load_golden, load_pkg
 from oracle import chimera_oracle as O
 
 load_pkg()
@@ -479,7 +479,7 @@ def test_grad_slot_hands_a_flat_buffer_slot_out_once_per_epoch():
 
 
 def _odd_order_worker(port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", CST_DDP_FORCE="1", CST_DDP_HOOKS_PER_BUCKET="1")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", CST_DDP_FORCE="1")
     dist.init_process_group("gloo", rank=0, world_size=1)
     torch.manual_seed(0)
     layers = [torch.nn.Linear(6, 6) for _ in range(6)]
@@ -489,7 +489,7 @@ def _odd_order_worker(port, q):
     params = [p for i in order for p in layers[i].parameters()]
     buf = optim.FlatParamBuffers(params)
     red = distributed.BucketedGradAllReduce(buf.params, buf.offsets, buf.flat_grad, None, bucket_cap_mb=0.0002, gather=buf.gather_grads)
-    assert red.active and len(red.buckets) >= 3 and len(red._hooked) == len(red.buckets)
+    assert red.active and len(red.buckets) >= 3 and len(red._hooks) == len(buf.params)
     x = torch.randn(4, 6)
     outs = []
     for step in range(2):
@@ -510,9 +510,9 @@ def _odd_order_worker(port, q):
     dist.destroy_process_group()
 
 
-def test_reducer_with_one_hook_per_bucket_and_an_unexpected_arrival_order():
-    """Hooks sit on a few parameters per bucket; when the gradients do not arrive in reverse storage order some buckets cannot leave
-    from a hook — they leave in finish().  Whatever the order: every bucket is reduced exactly once and the gradients are complete."""
+def test_reducer_with_an_unexpected_arrival_order():
+    """Buckets leave strictly in storage order; when the gradients do not arrive in reverse storage order a bucket waits for its
+    last member's hook (or for finish()).  Whatever the order: every bucket is reduced exactly once and the gradients are complete."""
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -522,3 +522,123 @@ def test_reducer_with_one_hook_per_bucket_and_an_unexpected_arrival_order():
     p.join(60)
     assert p.exitcode == 0
     assert 0 <= early1 <= nb and early1 == early2 and same and err < 1e-6
+
+
+# ---- accumulated updates (update_freq > 1) with weight gradients written straight into the flat buffer (optim.grad_slot) --------------
+class _SlotLinear(torch.autograd.Function):
+    """What functional._linear_backward does on the GPU: the weight gradient goes into the parameter's slot of the flat gradient
+    buffer when optim.grad_slot hands it out (first micro-batch), otherwise it is an ordinary tensor autograd adds in place."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        g = dy.t() @ x
+        out = optim.grad_slot(w)
+        if out is not None:
+            out.copy_(g)
+            g = out
+        return dy @ w, g
+
+
+class _SlotNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(12, 12) * 0.3) for _ in range(6)])  # bias-free layers
+
+    def forward(self, x):
+        for w in self.w:
+            x = torch.tanh(_SlotLinear.apply(x, w))
+        return x
+
+
+def _accum_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = _SlotNet()
+    buf = optim.FlatParamBuffers(net.parameters())
+    model = distributed.DistributedFairseqModel(Namespace(bucket_cap_mb=0.0006), net, buf)  # one 144-element weight per bucket
+    red = model.reducer
+    assert len(red.buckets) == 6
+    g = torch.Generator().manual_seed(100 + rank)
+    xs = [torch.randn(5, 12, generator=g) for _ in range(2)]
+    launched_at = []  # (bucket, had every member's hook fired in the reducing pass?)
+    orig = red._launch
+
+    def spy(b):
+        launched_at.append((b, all(i in red._fired for i in red.buckets[b]["members"])))
+        orig(b)
+
+    red._launch = spy
+    buf.zero_grad()
+    with model.no_sync():
+        net(xs[0]).pow(2).sum().backward()
+    assert all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(buf.params, buf.grad_views))  # slot-written
+    net(xs[1]).pow(2).sum().backward()  # the reducing pass: in-place adds into the slots, which share ONE version counter
+    early = red._next
+    model.all_reduce()
+    q.put((rank, buf.flat_grad.clone().numpy(), [x.numpy() for x in xs], launched_at, early, list(red.late_params)))
+    dist.destroy_process_group()
+
+
+def test_accumulated_update_with_slot_written_gradients():
+    """Advisor, round 4 (high): with update_freq > 1 the slot-written gradients are views of one flat tensor and share its version
+    counter; a reducer that reads arrival off `p.grad._version` sees every weight arrive with the first in-place add of the last
+    micro-batch and lets buckets go before their members' gradients exist.  Arrival is a per-parameter hook record now: every bucket
+    leaves only after all of its members fired in the reducing pass, nothing is flagged late, and the result is the mean over the
+    ranks of the sum over both micro-batches."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_accum_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    torch.manual_seed(0)
+    net = _SlotNet()
+    want = [torch.zeros_like(p) for p in net.parameters()]
+    for r in range(world):
+        for x in res[r][2]:
+            gs = torch.autograd.grad(net(torch.from_numpy(x)).pow(2).sum(), list(net.parameters()))
+            want = [w + g / world for w, g in zip(want, gs)]
+    np.testing.assert_allclose(res[0][1], torch.cat([w.reshape(-1) for w in want]).numpy(), rtol=1e-5, atol=1e-6)
+    for r in res:
+        assert len(r[3]) == 6 and all(ok for _, ok in r[3]), r[3]   # no bucket left before its member's gradient of the last pass
+        assert r[4] == 6 and r[5] == []                              # all of them under backward; nobody "late"
+
+
+def test_launch_ranks_starts_one_process_per_rank_and_propagates_failure(tmp_path, capfd):
+    """distributed.launch_ranks (what `python bench.py --gpus N` / `fairseq_train.py` do when started without a launcher;
+    fairseq/distributed_utils.py:286-303): N children with the torchrun environment that can form a process group; rank 0 owns stdout;
+    a failing rank stops the job with its exit code."""
+    import subprocess
+    import sys
+    prog = tmp_path / "rank.py"
+    prog.write_text(
+        "import os, sys, torch, torch.distributed as dist\n"
+        "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+        "assert os.environ['LOCAL_RANK'] == str(r) and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+        "if len(sys.argv) > 1 and sys.argv[1] == str(r): sys.exit(5)\n"
+        "dist.init_process_group('gloo', rank=r, world_size=w)\n"
+        "t = torch.tensor([float(r + 1)]); dist.all_reduce(t)\n"
+        "print('rank %d of %d sum %d' % (r, w, int(t.item())), flush=True)\n"
+        "dist.destroy_process_group()\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    assert distributed.needs_self_launch(3) and not distributed.needs_self_launch(1)
+    r = subprocess.run([sys.executable, "-c", "import sys, importlib; sys.path.insert(0, %r); d = importlib.import_module('chimera-st_amd.distributed'); "
+                        "sys.exit(d.launch_ranks(3, [sys.executable, %r]))" % (ROOT, str(prog))], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert [l for l in r.stdout.splitlines() if l.startswith("rank")] == ["rank 0 of 3 sum 6"]  # rank 0 alone writes to stdout
+    assert "rank 1 of 3 sum 6" in r.stderr and "rank 2 of 3 sum 6" in r.stderr
+    r = subprocess.run([sys.executable, "-c", "import sys, importlib; sys.path.insert(0, %r); d = importlib.import_module('chimera-st_amd.distributed'); "
+                        "sys.exit(d.launch_ranks(3, [sys.executable, %r, '2']))" % (ROOT, str(prog))], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 5 and "rank 2 exited with code 5" in r.stderr
