@@ -79,6 +79,67 @@ def test_two_ranks_equal_one_rank_on_both_batches():
     np.testing.assert_allclose(res[0][3], ref, rtol=1e-4, atol=1e-5)
 
 
+def _samples4(task):
+    tasks = import_module("chimera-st_amd.tasks")
+    return _samples(task) + [tasks.synthetic_sample(task.target_dictionary, 2, [3680, 2400], [6, 4], [5, 7], seed=13),
+                             tasks.synthetic_sample(task.target_dictionary, 2, [4000, 3200], [3, 8], [6, 2], seed=14)]
+
+
+def _worker_accum(rank, world, port, q):
+    """update_freq = 2 on two ranks (chimera/scripts/train-en2any-ST.sh: --update-freq $(expr 8 / $num_gpus)): the first micro-batch
+    runs under no_sync() and leaves its weight gradients IN the flat buffer (optim.grad_slot), the second one is the reducing pass."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    model, task, crit = _build()
+    Trainer = import_module("chimera-st_amd.trainer").Trainer
+    tr = Trainer(_targs(), task, model, crit, device="cuda")
+    red = tr.model.reducer
+    early = []
+    orig = red._launch
+
+    def spy(b):
+        early.append(all(i in red._fired or i in red._skipped for i in red.buckets[b]["members"]))
+        orig(b)
+
+    red._launch = spy
+    s4 = _samples4(task)
+    out = tr.train_step([s4[2 * rank], s4[2 * rank + 1]])
+    slot_written = sum(1 for p, v in zip(tr.buffers.params, tr.buffers.grad_views) if p.grad is not None and p.grad.data_ptr() == v.data_ptr())
+    q.put((rank, out["loss"], out["gnorm"], tr.buffers.flat_param.detach().cpu().numpy(), early, tr.last_late_count, slot_written))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_with_two_micro_batches_each_equal_one_rank_on_all_four():
+    """Advisor, round 4 (high): an accumulated update under data parallelism.  No bucket may leave before every member's gradient of
+    the LAST micro-batch exists (arrival is a hook record, not a tensor version: the slot-written gradients share one version counter),
+    nothing is flagged late, and the update equals the single-process update over the four micro-batches."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_accum, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(res[0][3], res[1][3])
+    for r in res:
+        assert len(r[4]) >= 3 and all(r[4]), r[4]
+        assert r[5] == 0 and r[6] > 10, (r[5], r[6])  # no late gradients; the weight gradients did go through the flat-buffer slots
+    model, task, crit = _build()
+    Trainer = import_module("chimera-st_amd.trainer").Trainer
+    tr = Trainer(_targs(), task, model, crit, device="cuda")
+    out = tr.train_step(_samples4(task))
+    assert out["loss"] == pytest.approx(res[0][1], rel=1e-5)
+    assert out["gnorm"] == pytest.approx(res[0][2], rel=1e-4)
+    np.testing.assert_allclose(res[0][3], tr.buffers.flat_param.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
 def _worker_uneven(rank, world, port, q):
     """Rank 1's shard of the epoch has run out: it gets the empty batch ShardedIterator pads with (iterators.py:470-500) and must
     still take part in every collective with a zeroed contribution (trainer.py:469-477, 552-556)."""
