@@ -162,8 +162,33 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
       const int q = ntiles >> 3, r = ntiles & 7, xcd = id & 7, loc = id >> 3;
       id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
+    if (kp->mrot > 0) {
+      // row-limited batches with too few tile groups for the deal below: batch z starts its walk z * mrot positions further on, so
+      // the XCD that holds the dead tail of one batch holds the live head of the next (batches are sorted by length: the offsets
+      // z mod 8 give every XCD one batch of each length class)
+      int zr = z * kp->mrot;
+      zr -= fdiv(zr, kp->magic_ntiles) * ntiles;
+      id += zr;
+      if (id >= ntiles) id -= ntiles;
+    }
     const int GROUP_M = kp->group_m, per_group = kp->per_group, gshift = kp->group_shift;
-    const int grp = fdiv(id, kp->magic_per_group), rem = id - grp * per_group;
+    int grp = fdiv(id, kp->magic_per_group);
+    const int rem = id - grp * per_group;
+    if (kp->gperm_full > 0 && grp < kp->gperm_full) {
+      // Per-batch row limits (m_len): the tiles behind a batch's limit are the TAIL of its m range, and the chunk map above hands
+      // XCD x the x-th eighth of every batch's m range — with utterance lengths between a third of the longest and the longest,
+      // XCD 0 .. 2 never meet a dead tile and XCD 7 meets almost nothing else; the claim counters are per XCD, so the launch took
+      // as long as if nothing had been skipped (conv layer 1 forward inside the update: 2.44 ms, all rows live standalone: 2.57).
+      // Instead XCD x gets groups x, x + 8, x + 16, ...: `grp` counts the groups column by column through an 8-column arrangement
+      // of the real group numbers (columns 0 .. r - 1 hold q + 1 groups, the others q), so that the contiguous run of an XCD is
+      // (about) one column.  A group stays on one XCD: the L2 sees the same 4 x tiles_n patches as before.  Same tiles, same
+      // arithmetic per tile: same bits.
+      const int q = kp->gperm_q, r = kp->gperm_r, big = (q + 1) * r;
+      int col, row;
+      if (grp < big) { col = fdiv(grp, kp->magic_gq1); row = grp - col * (q + 1); }
+      else { const int t = grp - big, c = fdiv(t, kp->magic_gq); col = r + c; row = t - c * q; }
+      grp = row * 8 + col;
+    }
     const int gm0 = grp * GROUP_M;
     const int gsz = (p.tiles_m - gm0 < GROUP_M) ? (p.tiles_m - gm0) : GROUP_M;
     int tm, tn;
@@ -800,6 +825,16 @@ int launch8p(GemmParams p, int64_t nbatch, hipStream_t s) {
     p.group_shift = -1;
     for (int sft = 0; sft < 16; ++sft)
       if ((1 << sft) == p.group_m) p.group_shift = sft;
+    // round-robin deal of the m-tile groups over the XCDs (setup()): launches with per-batch row limits whose batches have at
+    // least two full groups per XCD; CST_GEMM8P_NO_GPERM=1 keeps the contiguous runs (A/B runs)
+    static const bool no_gperm = getenv("CST_GEMM8P_NO_GPERM") != nullptr;
+    const int gfull = p.tiles_m / p.group_m;
+    p.gperm_full = (!no_gperm && p.m_len && gfull >= 16) ? gfull : 0;
+    p.mrot = (!no_gperm && p.m_len && p.gperm_full == 0 && ntl >= 2) ? (int)(ntl / 8 > 0 ? ntl / 8 : 1) : 0;
+    p.gperm_q = gfull / 8;
+    p.gperm_r = gfull % 8;
+    p.magic_gq = p.gperm_q > 0 ? ((1ull << 40) / (unsigned long long)p.gperm_q) + 1ull : 0ull;
+    p.magic_gq1 = ((1ull << 40) / (unsigned long long)(p.gperm_q + 1)) + 1ull;
   }
   static const int ncu = [] {
     int dev = 0, n = 256;

@@ -39,6 +39,12 @@ struct GemmParams {
   // constants are multiplications by these (q = (n * magic) >> 40, exact for n * d < 2^40)
   unsigned long long magic_ntiles, magic_per_group;
   int per_group, group_shift;  // group_m * tiles_n; log2(group_m) or -1 if group_m is not a power of two
+  // gemm8p, launches with per-batch row limits (m_len: the conv stack): the m-tile GROUPS of a batch are dealt to the XCDs round-robin
+  // instead of in contiguous runs (see the kernel's setup()): gperm_full = number of full groups taking part (0 = off),
+  // gperm_q / gperm_r = gperm_full / 8 and % 8, with the division magics for gperm_q and gperm_q + 1
+  int gperm_full, gperm_q, gperm_r;
+  int mrot;  // ... and batches with fewer groups than that: batch z walks its tiles rotated by z * mrot positions (0 = off)
+  unsigned long long magic_gq, magic_gq1;
   int split_order;  // gemm_kernel, split-K unbatched: XCD-contiguous (split, tile) item order (see the kernel)
   int* sched;       // gemm8p: 16 zeroed ints of scheduling state (8 per-XCD item counters, 1 exit counter), nullptr = static walk
   const uint32_t* m_live; uint32_t m_epoch;  // rows of A in blocks of 64: an output tile with no live block skips its K loop

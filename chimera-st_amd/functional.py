@@ -966,8 +966,14 @@ class _PosConvFn(torch.autograd.Function):
     a plain k-major operand with lda = C/G < K (overlapping rows) — no segmented addressing in the inner loop."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, groups):
-        """x [B,T,C]; weight [C, C/g, k] -> x + GELU(conv(x) + bias)   (one fused GEMM launch)."""
+    def forward(ctx, x, weight, bias, groups, lens=None, grad_rows=None):
+        """x [B,T,C]; weight [C, C/g, k] -> x + GELU(conv(x) + bias)   (one fused GEMM launch).
+        lens (int32 [B], device): frames of x from lens[b] on are ZERO (wav2vec2.py:820-821 zeroes the padding in front of this
+        convolution).  The window of output frame t >= lens[b] + k // 2 then holds nothing but zeros, so its row of the implicit
+        GEMM's A operand is zero: cst_gemm_desc.m_len = lens + k // 2 lets the tiles behind it skip their K loop, and their epilogue
+        on zero accumulators — GELU(bias) + x — IS the value of those frames: every output frame keeps its bits.
+        grad_rows (int32 [B], device): the gradient of the output is exactly zero from frame grad_rows[b] on (the rows a packing plan
+        keeps: pack_rows' backward writes zeros behind them); the windows of dx frames >= grad_rows[b] + k - 1 - k // 2 are zero."""
         B, T, C = x.shape
         k = weight.shape[2]
         cg = C // groups
@@ -983,11 +989,13 @@ class _PosConvFn(torch.autograd.Function):
         y = torch.empty(B, T, C, dtype=x.dtype, device=x.device)
         z = torch.empty_like(y)
         xc = x if x.is_contiguous() else x.contiguous()
+        ml = None if lens is None else torch.clamp(lens.to(torch.int32) + padl, max=T).contiguous()
         K.gemm(xg, wg, y, T, cg, k * cg, a_kmajor=1, b_kmajor=1, lda=cg, ldb=k * cg, ldc=C, batch0=B, batch1=groups,
                sa=(Tp * cg, B * Tp * cg), sb=(0, cg * k * cg), sc=(T * C, cg), bias=bias, sbias=(0, cg), act=L.ACT_GELU,
-               aux_out=z, ld_aux_out=C, resid=xc, ld_resid=C, split_k=1)
+               aux_out=z, ld_aux_out=C, resid=xc, ld_resid=C, split_k=1, m_len=ml)
         ctx.save_for_backward(xg, weight, z)
         ctx.cfg = (B, T, C, k, groups, cg, padl, Tp)
+        ctx.grad_rows = grad_rows
         return y
 
     @staticmethod
@@ -1009,8 +1017,10 @@ class _PosConvFn(torch.autograd.Function):
             # dx[m] = dy[m] + sum_j dz[m + padl - j] w_j  = dy[m] + sum_j' dzp[m + j'] wflip[j'],  dzp[(k-1-padl) + t] = dz[t]
             wflip = weight.view(groups, cg, cg, k).flip(3).permute(0, 2, 3, 1).contiguous()  # [g][ci][j'][co]
             dx = torch.empty(B, T, C, dtype=dy.dtype, device=dy.device)
+            gr = ctx.grad_rows
+            ml = None if gr is None else torch.clamp(gr.to(torch.int32) + lp, max=T).contiguous()  # (dead tiles: dx = 0 + dy = dy, exactly)
             K.gemm(dzg, wflip, dx, T, cg, k * cg, a_kmajor=1, b_kmajor=1, lda=cg, ldb=k * cg, ldc=C, batch0=B, batch1=groups,
-                   sa=(Tp * cg, B * Tp * cg), sb=(0, cg * k * cg), sc=(T * C, cg), resid=dy, ld_resid=C, split_k=1)
+                   sa=(Tp * cg, B * Tp * cg), sb=(0, cg * k * cg), sc=(T * C, cg), resid=dy, ld_resid=C, split_k=1, m_len=ml)
         if ctx.needs_input_grad[1]:
             # dw[g][co][(j,ci)] = sum_{b,t} dz[b, t, g, co] xg[g, b, t + j, ci]: ONE reduction over the frames of the whole batch per
             # group.  Row kappa = b Tp + t of A is dzg's row kappa + lp (zero for t >= T: the windows that would run from one
@@ -1030,7 +1040,7 @@ class _PosConvFn(torch.autograd.Function):
                 db = db.to(weight.dtype)
         if ctx.needs_input_grad[2] and db is None:
             db = K.colsum(dz.view(B * T, C), weight.dtype)
-        return dx, dw, db, None
+        return dx, dw, db, None, None, None
 
 
 class _WeightNormFn(torch.autograd.Function):
@@ -1055,8 +1065,8 @@ def weight_norm_last_dim(v, g):
     return _WeightNormFn.apply(v, g)
 
 
-def pos_conv_gelu_residual(x, weight, bias, groups):
-    return _PosConvFn.apply(x, weight, bias, groups)
+def pos_conv_gelu_residual(x, weight, bias, groups, lens=None, grad_rows=None):
+    return _PosConvFn.apply(x, weight, bias, groups, lens, grad_rows)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -1474,3 +1474,64 @@ print("ok")
     e = dict(os.environ, CST_GEMM_EXPERIMENT="1")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_gemm8p_row_limited_batches_deal_their_tile_groups_round_robin(K):
+    """Batched launches with per-batch row limits (cst_gemm_desc.m_len: the conv stack) hand the m-tile groups of a batch to the XCDs
+    round-robin instead of in contiguous runs (gemm8p.hip setup(): the tiles behind a limit are the tail of the batch's rows, and the
+    contiguous runs gave all of them to the last XCDs).  The map must stay a bijection of the tiles: every output row below its
+    batch's limit holds the product (implicit-GEMM operand: overlapping rows, as in the conv stack), every row behind it is either
+    untouched by a live tile's store or zero, nothing is left unwritten among the live tiles — for row counts with and without a
+    partial last group and group counts that are / are not multiples of 8."""
+    k, L = K
+    dt = torch.bfloat16
+    # 19 full groups + a partial one; exactly 19 groups; 5 groups + a partial one (too few for the deal: batch z walks its tiles
+    # rotated by z * ntiles / 8 positions instead)
+    for Lout, nb in ((16384 + 256 * 4 * 3 + 130, 3), (256 * 4 * 19, 2), (256 * 4 * 5 + 100, 6)):
+        Cin, Cout, taps, stride = 64, 512, 3, 2
+        Lin = (Lout - 1) * stride + taps
+        x = rnd(nb, Lin, Cin, dt=dt, seed=5)
+        w = rnd(Cout, taps * Cin, dt=dt, seed=6, scale=(taps * Cin) ** -0.5)
+        lim = torch.tensor([Lout, Lout // 3 + 77, 5, Lout - 300, Lout // 2, 1000][:nb], dtype=torch.int32, device="cuda")
+        y = torch.full((nb, Lout, Cout), float("nan"), dtype=dt, device="cuda")
+        k.gemm(x, w, y, Lout, Cout, taps * Cin, a_kmajor=1, b_kmajor=1, lda=stride * Cin, ldb=taps * Cin, ldc=Cout, batch0=nb,
+               sa=(Lin * Cin, 0), sb=(0, 0), sc=(Lout * Cout, 0), split_k=1, m_len=lim)
+        A = torch.as_strided(x, (nb, Lout, taps * Cin), (Lin * Cin, stride * Cin, 1)).float()
+        ref = A @ w.float().t()
+        for b in range(nb):
+            n_live = int(lim[b])
+            check(y[b, :n_live], ref[b, :n_live], dt, "rows below the limit, batch %d" % b)
+            tail = y[b, (n_live + 255) // 256 * 256:]          # whole tiles behind the limit: zeros (the skipped K loop's epilogue)
+            assert bool((tail == 0).all()), "rows of dead tiles: %d non-zero / NaN" % int((tail != 0).sum())
+        assert torch.isfinite(y.float()).all()
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_pos_conv_frame_limits_keep_every_bit(K, dt):
+    """functional.pos_conv_gelu_residual with `lens` / `grad_rows` (round 5): the input is zero from lens[b] on (wav2vec2.py:820-821), so
+    the output tiles whose windows lie in the padding skip their products and their epilogue on zero accumulators, x + GELU(bias), IS
+    the value of those frames; the gradient of the output is zero from grad_rows[b] on (what pack_rows' backward leaves), which bounds
+    the dX GEMM the same way.  Output, dx, dw and db have the bits of the unlimited call — utterances shorter than the convolution's
+    reach, a full-length one and a zero-length one included."""
+    CF = __import__("importlib").import_module("chimera-st_amd.functional")
+    k, L = K
+    B_, T, C, G, Kp = 5, 1100, 768, 16, 128
+    lens = torch.tensor([1100, 700, 333, 40, 0], dtype=torch.int32, device="cuda")
+    keep = torch.clamp(lens + 7, max=T)                      # rows a packing plan with margin 6 keeps
+    t = torch.arange(T, device="cuda")[None, :, None]
+    x0 = rnd(B_, T, C, dt=dt, seed=64, scale=0.5) * (t < lens[:, None, None]).to(dt)
+    w0 = rnd(C, C // G, Kp, dt=dt, seed=65, scale=0.02)
+    b0 = rnd(C, dt=dt, seed=66, scale=0.1)
+    dy = rnd(B_, T, C, dt=dt, seed=67) * (t < keep[:, None, None]).to(dt)
+    outs = []
+    for limited in (False, True):
+        x, w, bias = (v.clone().requires_grad_(True) for v in (x0, w0, b0))
+        k.STATS.clear()
+        y = CF.pos_conv_gelu_residual(x, w, bias, G, lens if limited else None, keep if limited else None)
+        y.backward(dy)
+        outs.append((y.detach(), x.grad, w.grad, bias.grad))
+        if limited:
+            assert k.STATS.get("gemm_m_len", 0) == 2, dict(k.STATS)   # the forward GEMM and the dX GEMM took their limits
+    for a, b, what in zip(outs[0], outs[1], ("y", "dx", "dw", "db")):
+        assert torch.isfinite(b.float()).all(), what
+        assert torch.equal(a, b), "%s differs on %d elements" % (what, int((a != b).sum()))
