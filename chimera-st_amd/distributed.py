@@ -144,9 +144,11 @@ class BucketedGradAllReduce:
         env_r = os.environ.get("CST_DDP_RESERVE_CUS")
         self.reserve_cus = int(env_r) if env_r is not None else (32 if self.world > 1 else 0)
         # CST_DDP_COLLECTIVE = allreduce (default) | rs_ag: the gradient exchange of a bucket as reduce-scatter + all-gather
+        # ("rs": reduce-scatter ONLY — rank r ends up with the mean of ITS 1 / world span of every bucket; chosen by the trainer for the
+        #  sharded optimizer, which updates those spans and all-gathers the PARAMETERS instead: shard_state() / all_gather_shards())
         self.collective = os.environ.get("CST_DDP_COLLECTIVE", "allreduce")
-        if self.collective not in ("allreduce", "rs_ag"):
-            raise ValueError("CST_DDP_COLLECTIVE must be allreduce or rs_ag, not %r" % self.collective)
+        if self.collective not in ("allreduce", "rs_ag", "rs"):
+            raise ValueError("CST_DDP_COLLECTIVE must be allreduce, rs_ag or rs, not %r" % self.collective)
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self._reserved = False
         self.last_early, self.last_missing = 0, []
@@ -259,7 +261,10 @@ class BucketedGradAllReduce:
         if self.reserve_cus > 0 and not self._reserved:  # while a bucket is in flight (released by the hooks / finish())
             self._set_reserved(True)
         n = g.numel()
-        if self.collective == "rs_ag" and n % self.world == 0 and n > 0:
+        if self.collective == "rs":
+            shard = g[self.rank * (n // self.world):(self.rank + 1) * (n // self.world)]  # (shard_state() checked n % world == 0)
+            self._works.append(dist.reduce_scatter_tensor(shard, g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        elif self.collective == "rs_ag" and n % self.world == 0 and n > 0:
             # reduce-scatter + all-gather of the bucket, in place (rank r owns shard r between the two): the same sums as the
             # all-reduce in two collectives RCCL can route over all seven xGMI links at once; the first 8-GPU session A/Bs it
             # (tools/ddp_overlap_trace.py).  Both are queued on the communicator's stream in this order, so only the second is awaited.
@@ -270,6 +275,34 @@ class BucketedGradAllReduce:
             self._works.append(dist.all_gather_into_tensor(g, shard, group=self.pg, async_op=True))
         else:
             self._works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def shard_state(self):
+        """Switch to reduce-scatter-only buckets and return the [lo, hi) spans of the flat buffers this rank owns (one per bucket, in
+        bucket order): the sharded optimizer's work list (optim.FusedAdam.shard).  Every bucket must split into `world` equal,
+        16-byte-aligned spans: FlatParamBuffers(align = 8 * world) makes every bucket boundary a multiple of that."""
+        for bk in self.buckets:
+            n = bk["hi"] - bk["lo"]
+            if n % (8 * self.world) != 0 or bk["lo"] % 8 != 0:
+                raise ValueError("bucket [%d, %d) does not split into %d aligned spans: build FlatParamBuffers with align = 8 * world"
+                                 % (bk["lo"], bk["hi"], self.world))
+        self.collective = "rs"
+        return [self._span(bk, self.rank) for bk in self.buckets]
+
+    def _span(self, bk, r):
+        n = (bk["hi"] - bk["lo"]) // self.world
+        return bk["lo"] + r * n, bk["lo"] + (r + 1) * n
+
+    def all_gather_shards(self, flat):
+        """Every rank's spans of `flat` (a tensor laid out like the flat buffers: parameters after a sharded update, optimizer state
+        for a checkpoint) -> the whole tensor on every rank, bucket by bucket, in place."""
+        if not (dist.is_initialized() and self.active):
+            return
+        works = []
+        for bk in self.buckets:
+            lo, hi = self._span(bk, self.rank)
+            works.append(dist.all_gather_into_tensor(flat[bk["lo"]:bk["hi"]], flat[lo:hi], group=self.pg, async_op=True))
+        for w in works:
+            w.wait()
 
     def _set_reserved(self, on):
         if not torch.cuda.is_available():  # CPU-only hosts (the gloo tests): there is no persistent GEMM to shrink

@@ -25,8 +25,10 @@ PARAM_EPOCH = [0]
 class FlatParamBuffers:
     """Re-home a model's parameters (and their .grad) as views of two flat tensors."""
 
-    def __init__(self, params, adjacent=None):
-        """`adjacent`: groups of parameters to be laid out back to back, in the given order (the q | k | v projection weights and
+    def __init__(self, params, adjacent=None, align=ALIGN):
+        """`align` (elements, a multiple of ALIGN): every parameter's slot starts at a multiple of it — the sharded optimizer asks for
+        ALIGN x world so that the 1 / world shards of every bucket keep the kernels' 16-byte alignment.
+        `adjacent`: groups of parameters to be laid out back to back, in the given order (the q | k | v projection weights and
         biases of a self-attention module: the packed [3C, C] projection is then a VIEW of the flat buffer instead of a torch.cat
         per layer and update).  Only the storage layout changes; `self.params` keeps model.parameters() order, which is the index
         space of the reference's optimizer state (optim/fairseq_optimizer.py)."""
@@ -46,12 +48,14 @@ class FlatParamBuffers:
                 order.extend(lead[i])
             elif i not in follow:
                 order.append(i)
+        assert align >= ALIGN and align % ALIGN == 0
+        self.align = int(align)
         self.offsets, total = [0] * len(self.params), 0
         for i in order:
             p = self.params[i]
             assert p.dtype == self.dtype and p.device == self.device, "all trainable parameters must share dtype/device"
             self.offsets[i] = total
-            total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+            total += (p.numel() + self.align - 1) // self.align * self.align
         self.total = total
         self.flat_param = torch.zeros(total, dtype=self.dtype, device=self.device)
         self.flat_grad = torch.zeros(total, dtype=self.dtype, device=self.device)
@@ -176,6 +180,60 @@ class FusedAdam:
         self.lr = inverse_sqrt_lr(0, lr, warmup_updates, warmup_init_lr)
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._scale = torch.ones(1, dtype=torch.float32, device=dev)
+        self.segments = None   # sharded optimizer state (shard()): the [lo, hi) spans of the flat buffers this rank owns
+        self._gather = None    # ... and the collective that assembles a flat tensor from every rank's spans
+
+    # ---- ZeRO-1 ("optimizer state sharding": --zero-sharding os, fairseq/trainer.py:241-252 + optim/shard.py, where the reference
+    #      hands its optimizer to fairscale's OSS).  Behind a reduce-scatter of every gradient bucket (distributed.py, collective
+    #      "rs") rank r holds the reduced gradient of ITS 1 / world span of each bucket only; it keeps fp32 master weights and both
+    #      Adam moments for those spans alone (1 / world of the optimizer memory and of the update's 28 bytes per parameter), runs
+    #      cst_sumsq + cst_adam_step on them, and the bf16 parameters are all-gathered bucket by bucket afterwards — the same bytes
+    #      on the wire as the gradient all-gather they replace.  The update itself is element-wise: with the same gradient scale
+    #      every parameter gets the bits of the unsharded route. ----
+    def shard(self, segments, gather):
+        segs = [(int(lo), int(hi)) for lo, hi in segments if hi > lo]
+        assert all(lo % ALIGN == 0 and hi % ALIGN == 0 for lo, hi in segs), "shard spans must keep the 16-byte alignment of the kernels"
+        full = (self.master, self.exp_avg, self.exp_avg_sq) if self.segments is None else self._full_state()
+        self.segments, self._gather = segs, gather
+        self._seg_loc, at = [], 0
+        for lo, hi in segs:
+            self._seg_loc.append(at)
+            at += hi - lo
+        self.master, self.exp_avg, self.exp_avg_sq = (self._take(t) for t in full)
+
+    def _take(self, flat):
+        """This rank's spans of a flat [total] tensor, back to back."""
+        dev = self.buf.device
+        if not self.segments:
+            return torch.zeros(0, dtype=flat.dtype, device=dev)
+        return torch.cat([flat[lo:hi] for lo, hi in self.segments]).contiguous()
+
+    def _full_state(self):
+        """(master, exp_avg, exp_avg_sq) as flat [total] fp32 tensors on EVERY rank (a collective when the state is sharded: all
+        ranks must call it — checkpoints, re-sharding)."""
+        if self.segments is None:
+            return self.master, self.exp_avg, self.exp_avg_sq
+        out = []
+        for local in (self.master, self.exp_avg, self.exp_avg_sq):
+            flat = torch.zeros(self.buf.total, dtype=torch.float32, device=self.buf.device)
+            for (lo, hi), a in zip(self.segments, self._seg_loc):
+                flat[lo:hi].copy_(local[a:a + hi - lo])
+            self._gather(flat)
+            out.append(flat)
+        return tuple(out)
+
+    def _spans(self):
+        """(lo, hi, offset into the local state) of the spans this rank updates: the whole buffer when nothing is sharded."""
+        if self.segments is None:
+            return [(0, self.buf.total, 0)]
+        return [(lo, hi, a) for (lo, hi), a in zip(self.segments, self._seg_loc)]
+
+    # the two kernels behind the update (the world-2 CPU tests of the sharding logic replace them with torch arithmetic)
+    def _sumsq_span(self, grad, out):
+        K.sumsq(grad, out)  # out[0] += sum(grad^2): fixed-order two-stage sum, spans added in span order
+
+    def _adam_span(self, master, m, v, grad, param):
+        K.adam_step(master, m, v, grad, param, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.num_updates, self._scale)
 
     @classmethod
     def from_args(cls, args, params, buffers=None):
@@ -200,7 +258,8 @@ class FusedAdam:
         """sum(grad^2) over the flat gradient buffer as a 1-element fp32 device tensor (fixed-order two-stage sum: replicas that hold
         the same all-reduced gradients get the same bits)."""
         self._sumsq.zero_()
-        K.sumsq(self.buf.flat_grad, self._sumsq)
+        for lo, hi, _ in self._spans():  # (sharded state: the sum over THIS rank's spans; the trainer adds the ranks' sums)
+            self._sumsq_span(self.buf.flat_grad[lo:hi], self._sumsq)
         return self._sumsq
 
     def grad_norm(self, multiply=1.0):
@@ -226,19 +285,24 @@ class FusedAdam:
                 self._scale.fill_(multiply)
         self.num_updates += 1
         PARAM_EPOCH[0] += 1
-        K.adam_step(self.master, self.exp_avg, self.exp_avg_sq, self.buf.flat_grad, self.buf.flat_param, self.lr,
-                    self.betas[0], self.betas[1], self.eps, self.weight_decay, self.num_updates, self._scale)
+        for lo, hi, a in self._spans():
+            n = hi - lo
+            self._adam_span(self.master[a:a + n], self.exp_avg[a:a + n], self.exp_avg_sq[a:a + n], self.buf.flat_grad[lo:hi], self.buf.flat_param[lo:hi])
+        if self.segments is not None:
+            self._gather(self.buf.flat_param)  # every rank's freshly updated spans -> the full parameter buffer on every rank
         self.lr = inverse_sqrt_lr(self.num_updates, self.base_lr, self.warmup_updates, self.warmup_init_lr)
         return gnorm
 
     # ---- the reference's on-disk optimizer state (torch.optim state dict of optim/adam.py, or FP16Optimizer's single flat fp32
     #      parameter, optim/fp16_optimizer.py:33-60, :71-76) <-> the flat master / moment buffers ----
     def fairseq_state_dict(self):
+        """(Sharded state: a collective — every rank calls it, every rank gets the full dict.)"""
+        _, exp_avg, exp_avg_sq = self._full_state()
         state = {}
         for i, (p, o) in enumerate(zip(self.buf.params, self.buf.offsets)):
             n = p.numel()
-            state[i] = {"step": self.num_updates, "exp_avg": self.exp_avg[o:o + n].view(p.shape).cpu().clone(),
-                        "exp_avg_sq": self.exp_avg_sq[o:o + n].view(p.shape).cpu().clone()}
+            state[i] = {"step": self.num_updates, "exp_avg": exp_avg[o:o + n].view(p.shape).cpu().clone(),
+                        "exp_avg_sq": exp_avg_sq[o:o + n].view(p.shape).cpu().clone()}
         group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
                  "params": list(range(len(self.buf.params)))}
         return {"state": state, "param_groups": [group]}
@@ -250,12 +314,14 @@ class FusedAdam:
         entries = [st[k] for k in sorted(st)]
         params, offs = self.buf.params, self.buf.offsets
         total = sum(p.numel() for p in params)
-        self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+        sharded = self.segments is not None
+        ea = torch.zeros(self.buf.total, dtype=torch.float32, device=self.buf.device) if sharded else self.exp_avg.zero_()
+        es = torch.zeros(self.buf.total, dtype=torch.float32, device=self.buf.device) if sharded else self.exp_avg_sq.zero_()
         if len(st) == 1 and len(params) > 1 and entries[0]["exp_avg"].numel() == total:  # FP16Optimizer: one flat fp32 parameter
             m, v, at = entries[0]["exp_avg"].reshape(-1).float(), entries[0]["exp_avg_sq"].reshape(-1).float(), 0
             for p, o in zip(params, offs):
-                self.exp_avg[o:o + p.numel()].copy_(m[at:at + p.numel()])
-                self.exp_avg_sq[o:o + p.numel()].copy_(v[at:at + p.numel()])
+                ea[o:o + p.numel()].copy_(m[at:at + p.numel()])
+                es[o:o + p.numel()].copy_(v[at:at + p.numel()])
                 at += p.numel()
         else:
             for i, e in st.items():
@@ -263,19 +329,26 @@ class FusedAdam:
                     raise ValueError("optimizer state entry %d does not match the model's parameter list (the index space of a "
                                      "fairseq optimizer state is model.parameters() order)" % i)
                 n, o = params[i].numel(), offs[i]
-                self.exp_avg[o:o + n].copy_(e["exp_avg"].reshape(-1).float())
-                self.exp_avg_sq[o:o + n].copy_(e["exp_avg_sq"].reshape(-1).float())
+                ea[o:o + n].copy_(e["exp_avg"].reshape(-1).float())
+                es[o:o + n].copy_(e["exp_avg_sq"].reshape(-1).float())
         step = int(entries[0]["step"]) if entries else 0
         self.num_updates = int(num_updates) if num_updates is not None else step
-        self.master.copy_(self.buf.flat_param.float())
+        if sharded:
+            self.exp_avg, self.exp_avg_sq, self.master = self._take(ea), self._take(es), self._take(self.buf.flat_param.float())
+        else:
+            self.master.copy_(self.buf.flat_param.float())
         self.lr = inverse_sqrt_lr(self.num_updates, self.base_lr, self.warmup_updates, self.warmup_init_lr)
 
     def state_dict(self):
-        return {"master": self.master, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
-                "num_updates": self.num_updates, "lr": self.lr}
+        """Flat fp32 master / moments of the whole buffer (sharded state: a collective, as fairseq_state_dict)."""
+        master, exp_avg, exp_avg_sq = self._full_state()
+        return {"master": master, "exp_avg": exp_avg, "exp_avg_sq": exp_avg_sq, "num_updates": self.num_updates, "lr": self.lr}
 
     def load_state_dict(self, sd):
-        self.master.copy_(sd["master"]); self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        if self.segments is not None:
+            self.master, self.exp_avg, self.exp_avg_sq = (self._take(sd[k].to(self.buf.device)) for k in ("master", "exp_avg", "exp_avg_sq"))
+        else:
+            self.master.copy_(sd["master"]); self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.num_updates, self.lr = sd["num_updates"], sd["lr"]
-        self.buf.flat_param.copy_(self.master)
+        self.buf.flat_param.copy_(sd["master"])
         PARAM_EPOCH[0] += 1  # the parameters changed under their views

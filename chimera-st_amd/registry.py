@@ -120,6 +120,8 @@ def add_common_args(parser):
     g.add_argument("--ddp-backend", default="no_c10d")
     g.add_argument("--distributed-world-size", type=int, default=None, help="ranks to start when launched plainly (default: one per visible GPU, options.py:310)")
     g.add_argument("--bucket-cap-mb", type=int, default=25)
+    g.add_argument("--zero-sharding", default="none", choices=["none", "os"], help="os: optimizer state sharded over the data-parallel "
+                   "ranks (fairseq/trainer.py:241-252; here: reduce-scattered gradient buckets, per-shard Adam, all-gathered parameters)")
     g.add_argument("--ddp-reserve-cus", type=int, default=None, help="CUs the persistent GEMMs leave to the gradient all-reduce while "
                    "buckets are in flight under the backward pass (distributed.BucketedGradAllReduce.reserve_cus)")
     g.add_argument("--nonfinite-tolerance", type=int, default=20, help="consecutive updates with NaN / Inf gradients that are skipped "

@@ -13,7 +13,20 @@ import torch.distributed as dist
 
 from .distributed import DistributedFairseqModel, all_reduce_stats
 from . import rng
-from .optim import FlatParamBuffers, FusedAdam, qkv_groups
+from .optim import ALIGN, FlatParamBuffers, FusedAdam, qkv_groups
+
+
+class _StateView:
+    """The optimizer as checkpoint_utils.save_state sees it, with a state dict that was assembled beforehand (sharded state)."""
+
+    def __init__(self, opt, full):
+        self._opt, self._full = opt, full
+
+    def fairseq_state_dict(self):
+        return self._full
+
+    def __getattr__(self, name):
+        return getattr(self._opt, name)
 
 
 class Trainer:
@@ -26,14 +39,19 @@ class Trainer:
                                       "bf16 needs no loss scaling (DESIGN.md)")
         model = model.to(device=self.device, dtype=dtype)  # trainer.py:70-78
         self.criterion = criterion.to(self.device)
-        self.buffers = FlatParamBuffers(model.parameters(), adjacent=qkv_groups(model))
-        self.optimizer = FusedAdam.from_args(args, None, buffers=self.buffers)
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         # CST_DDP_FORCE=1 keeps the collective path on for a 1-rank group (a 1-GPU box can only form that RCCL communicator)
         self.ddp = self.world > 1 or (dist.is_initialized() and os.environ.get("CST_DDP_FORCE") == "1")
+        # --zero-sharding os (fairseq/trainer.py:241-252, optim/shard.py: the reference wraps its optimizer in fairscale's OSS):
+        # optimizer state sharded over the data-parallel ranks behind reduce-scattered gradient buckets (optim.FusedAdam.shard)
+        self.zero = self.ddp and (getattr(args, "zero_sharding", "none") == "os" or os.environ.get("CST_ZERO1") == "1")
+        self.buffers = FlatParamBuffers(model.parameters(), adjacent=qkv_groups(model), align=ALIGN * self.world if self.zero else ALIGN)
+        self.optimizer = FusedAdam.from_args(args, None, buffers=self.buffers)
         self.model = DistributedFairseqModel(args, model, self.buffers) if self.ddp else model
         self._model = model
+        if self.zero:
+            self.optimizer.shard(self.model.reducer.shard_state(), self.model.reducer.all_gather_shards)
         # Deferred reductions (kernels.DEFER): allowed when every parameter receives exactly one gradient per backward pass — the
         # criterion runs ONE pass over the model (label_smoothed_cross_entropy; the triplet criterion runs two) and the model
         # declares that a pass uses each parameter once.  Parameters reachable under two names (tied embeddings) are marked and
@@ -227,7 +245,12 @@ class Trainer:
             slots = norm_slots()
             dist.all_reduce(slots)
             sumsq = slots.tolist()
-        self._check_grad_norms(sumsq)  # raises when the replicas disagree (a mix of finite and non-finite norms included)
+        if self.zero:
+            # sharded optimizer: a rank's slot is the sum over ITS spans of the reduced gradient — the slots are the parts of one sum,
+            # not copies of one number, so there is nothing for _check_grad_norms to compare; every rank adds them in slot order
+            sumsq = [math.fsum(sumsq)] * self.world if all(math.isfinite(v) for v in sumsq) else [float("nan")] * self.world
+        else:
+            self._check_grad_norms(sumsq)  # raises when the replicas disagree (a mix of finite and non-finite norms included)
         if not all(math.isfinite(v) for v in sumsq):
             # NaN / Inf in the reduced gradient (every rank holds the same vector, so every rank is here): drop the update, as the
             # reference does on an fp16 overflow (trainer.py:629-646, optim/fp16_optimizer.py:182); master weights and both Adam
@@ -269,11 +292,18 @@ class Trainer:
     # ---- checkpoints in the reference's format (fairseq/trainer.py:270-395; checkpoint_utils.py) -------------------------
     def save_checkpoint(self, filename, extra_state=None):
         from . import checkpoint_utils
+        if self.zero:  # the moments live in every rank's shards: assembling them is a collective, so every rank builds the state
+            full = self.optimizer.fairseq_state_dict()
+            if self.rank != 0:
+                return None
+            opt = _StateView(self.optimizer, full)
+        else:
+            opt = self.optimizer
         if self.rank != 0:
             return None
         extra = {"train_iterator": {"epoch": 1, "iterations_in_epoch": 0}, "val_loss": None}
         extra.update(extra_state or {})
-        return checkpoint_utils.save_state(filename, self.args, self._model.state_dict(), self.criterion, self.optimizer,
+        return checkpoint_utils.save_state(filename, self.args, self._model.state_dict(), self.criterion, opt,
                                            self.num_updates, extra_state=extra)
 
     def load_checkpoint(self, filename, reset_optimizer=False):

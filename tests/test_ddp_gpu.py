@@ -140,6 +140,55 @@ def test_two_ranks_with_two_micro_batches_each_equal_one_rank_on_all_four():
     np.testing.assert_allclose(res[0][3], tr.buffers.flat_param.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
 
 
+def _worker_zero(rank, world, port, q):
+    """--zero-sharding os on two ranks against the all-reduce route in the same processes: real kernels (cst_sumsq / cst_adam_step
+    on this rank's spans, bf16-or-fp32 parameters all-gathered), two updates each."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    Trainer = import_module("chimera-st_amd.trainer").Trainer
+    res = {}
+    for zero in (True, False):
+        model, task, crit = _build()
+        a = _targs()
+        a.clip_norm, a.zero_sharding = 0.0, "os" if zero else "none"   # (no clipping: the gradient scale is the same number on both routes)
+        tr = Trainer(a, task, model, crit, device="cuda")
+        s4 = _samples4(task)
+        outs = [tr.train_step([s4[rank]]), tr.train_step([s4[2 + rank]])]
+        res[zero] = (tr, [o["gnorm"] for o in outs], [o["loss"] for o in outs])
+    tz, tu = res[True][0], res[False][0]
+    same = all(torch.equal(p, q_) for p, q_ in zip(tz.buffers.params, tu.buffers.params))
+    q.put((rank, tz.zero and tz.model.reducer.collective == "rs", same, res[True][1], res[False][1], res[True][2], res[False][2],
+           tz.optimizer.exp_avg.numel(), tz.buffers.total, torch.cat([p.detach().reshape(-1) for p in tz.buffers.params]).cpu().numpy()))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_zero_sharded_equal_the_all_reduce_route():
+    """ZeRO-1 (fairseq/trainer.py:241-252): per-rank Adam on 1 / world of the state behind reduce-scattered buckets, parameters
+    all-gathered — every parameter bit-equal to the all-reduce route after two updates, replicas identical, gradient norms equal to
+    rounding (the sum of the ranks' partial sums)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_zero, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in res:
+        assert r[1] and r[2], "sharded parameters differ from the all-reduce route"
+        assert r[7] * 2 == r[8]
+        for a, b in zip(r[3], r[4]):
+            assert a == pytest.approx(b, rel=1e-5)
+        assert r[5] == r[6]
+    np.testing.assert_array_equal(res[0][9], res[1][9])
+
+
 def _worker_uneven(rank, world, port, q):
     """Rank 1's shard of the epoch has run out: it gets the empty batch ShardedIterator pads with (iterators.py:470-500) and must
     still take part in every collective with a zeroed contribution (trainer.py:469-477, 552-556)."""

@@ -642,3 +642,98 @@ def test_launch_ranks_starts_one_process_per_rank_and_propagates_failure(tmp_pat
     r = subprocess.run([sys.executable, "-c", "import sys, importlib; sys.path.insert(0, %r); d = importlib.import_module('chimera-st_amd.distributed'); "
                         "sys.exit(d.launch_ranks(3, [sys.executable, %r, '2']))" % (ROOT, str(prog))], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 5 and "rank 2 exited with code 5" in r.stderr
+
+
+# ---- ZeRO-1: optimizer state sharded behind reduce-scattered gradient buckets (--zero-sharding os) ---------------------------------
+def _torch_adam_trainer(zero):
+    """A CPU Trainer whose two optimizer KERNELS are torch arithmetic (real Adam with both moments, so that a mis-sliced shard of the
+    state shows); everything around them — buckets, reduce-scatter, spans, the all-gather of the parameters — is the product code."""
+    Trainer = import_module("chimera-st_amd.trainer").Trainer
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 40), torch.nn.ReLU(), torch.nn.Linear(40, 24), torch.nn.ReLU(), torch.nn.Linear(24, 4))
+    net.upgrade_state_dict = lambda sd: None  # (the fairseq model surface Trainer.load_checkpoint calls)
+    args = Namespace(bf16=False, lr=[1e-2], adam_betas="(0.9, 0.98)", adam_eps=1e-8, weight_decay=0.0, clip_norm=0.0, seed=1,
+                     bucket_cap_mb=0.0008, zero_sharding="os" if zero else "none")
+    tr = Trainer(args, tasks.FairseqTask(args), net, _ToyCriterion(), device="cpu")
+    opt = tr.optimizer
+
+    def sumsq_span(grad, out):
+        out.add_(grad.double().pow(2).sum().float())
+
+    def adam_span(master, m, v, grad, param):
+        b1, b2, t = opt.betas[0], opt.betas[1], opt.num_updates
+        g = grad.float() * opt._scale
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = (v.sqrt() / math.sqrt(1 - b2 ** t)).add_(opt.eps)
+        master.addcdiv_(m, denom, value=-opt.lr / (1 - b1 ** t))
+        param.copy_(master)
+
+    opt._sumsq_span, opt._adam_span = sumsq_span, adam_span
+    return tr
+
+
+def _zero_worker(rank, world, port, q, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = {"rank": rank}
+    runs = {}
+    for zero in (True, False):
+        tr = _torch_adam_trainer(zero)
+        g = torch.Generator().manual_seed(100 + rank)
+        gn = []
+        for _ in range(3):
+            o = tr.train_step([{"x": torch.randn(5, 6, generator=g)}])
+            gn.append(o["gnorm"])
+        runs[zero] = (tr, gn)
+    tz, tu = runs[True][0], runs[False][0]
+    out["zero_on"] = tz.zero and not tu.zero and tz.model.reducer.collective == "rs"
+    out["spans"] = list(tz.optimizer.segments)
+    out["state_numel"] = (tz.optimizer.exp_avg.numel(), tz.buffers.total, tu.optimizer.exp_avg.numel(), tu.buffers.total)
+    # the sharded buffers are laid out with align = 8 * world: compare parameter by parameter
+    out["params_equal"] = all(torch.equal(a, b) for a, b in zip(tz.buffers.params, tu.buffers.params))
+    out["gnorm"] = (runs[True][1], runs[False][1])
+    sz, su = tz.optimizer.fairseq_state_dict(), tu.optimizer.fairseq_state_dict()   # (a collective for the sharded one: both ranks call it)
+    out["state_equal"] = all(torch.equal(sz["state"][i][k], su["state"][i][k]) for i in su["state"] for k in ("exp_avg", "exp_avg_sq"))
+    # checkpoint round trip through the reference's format: rank 0 writes, every rank loads into a fresh sharded trainer and continues
+    path = os.path.join(tmp, "ckpt.pt")
+    tz.save_checkpoint(path)
+    dist.barrier()
+    t2 = _torch_adam_trainer(True)
+    t2.load_checkpoint(path)
+    g2 = torch.Generator().manual_seed(500 + rank)
+    batch = {"x": torch.randn(5, 6, generator=g2)}
+    t2.train_step([batch]); tz.train_step([batch]); tu.train_step([batch])
+    out["resume_equal"] = all(torch.equal(a, b) for a, b in zip(t2.buffers.params, tz.buffers.params))
+    out["still_equal"] = all(torch.equal(a, b) for a, b in zip(tz.buffers.params, tu.buffers.params))
+    out["param"] = torch.cat([p.detach().reshape(-1) for p in tz.buffers.params]).numpy()
+    q.put(out)
+    dist.destroy_process_group()
+
+
+def test_zero_sharded_optimizer_equals_the_unsharded_update_gloo_world2(tmp_path):
+    """--zero-sharding os (fairseq/trainer.py:241-252): reduce-scattered buckets, Adam on this rank's spans with 1 / world of the
+    state, parameters all-gathered — against the all-reduce route on the same batches: every parameter and both moments bit-equal
+    after three updates (the update is element-wise; clip-norm 0 here, so the scale is the same number), the gradient norm equal to
+    rounding (a sum of the ranks' partial sums), replicas identical, and a checkpoint written from the shards resumes to the same
+    next update."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_zero_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t["rank"])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in res:
+        assert r["zero_on"] and r["params_equal"] and r["state_equal"] and r["resume_equal"] and r["still_equal"], {k: v for k, v in r.items() if k != "param"}
+        nz, tz, nu, tu = r["state_numel"]
+        assert nz * 2 == tz and nu == tu and tz >= tu, r["state_numel"]        # half of the optimizer state per rank
+        for a, b in zip(*r["gnorm"]):
+            assert a == pytest.approx(b, rel=1e-6)
+    spans = res[0]["spans"] + res[1]["spans"]
+    assert sum(hi - lo for lo, hi in spans) == res[0]["state_numel"][1]        # the two ranks' spans tile the flat buffer
+    assert len(set(spans)) == len(spans) and all(lo % 8 == 0 and hi % 8 == 0 for lo, hi in spans)
+    np.testing.assert_array_equal(res[0]["param"], res[1]["param"])
