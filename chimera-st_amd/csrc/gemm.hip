@@ -258,7 +258,7 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmParams p) {
   //      evenly: batches are sorted by length, so equal K ranges would leave the first split (the longest utterances) with
   //      nearly all of its tiles and the launch no faster.  (The fp32 summation order across splits therefore differs from the
   //      unstamped launch; with one split the result is bit-identical to it.) ----
-  constexpr int KLIST_MAX = 512;
+  constexpr int KLIST_MAX = 1000;  // (4 000 B of static LDS: the launch attribute leaves 4 096; the positional convolution's weight gradient walks 812 K tiles)
   __shared__ int klist[KLIST_MAX];
   __shared__ int klist_n;
   const bool kskip = !SEG && BK == 64 && p.k_live != nullptr && per <= KLIST_MAX;

@@ -1033,8 +1033,20 @@ class _PosConvFn(torch.autograd.Function):
                 # the bias gradient = column sums of this GEMM's A operand (every dz row is inside its K range, the rest are zeros):
                 # [groups][cg] = channel order (cst_gemm_desc.colsum)
                 db = torch.empty(C, dtype=dy.dtype, device=dy.device)
+            live = None
+            if ctx.grad_rows is not None and not _os.environ.get("CST_GEMM_NO_KLIVE"):
+                # dz is zero from frame grad_rows[b] of utterance b on: the 64-row K blocks of A that lie in those stretches (a third
+                # of them at the bench's lengths) are skipped (cst_gemm_desc.k_live: a block is live iff its stamp equals the epoch, 1).
+                # Row kappa = b Tp + t; a block may run from one utterance's tail into the head of the next.
+                n = ctx.grad_rows.to(torch.int64)
+                ks = torch.arange((Kr + 63) // 64, device=dy.device, dtype=torch.int64) * 64
+                b0 = torch.div(ks, Tp, rounding_mode="floor")
+                t0 = ks - b0 * Tp
+                nxt = torch.clamp(b0 + 1, max=B - 1)
+                stamps = ((t0 < n[b0]) | ((t0 + 64 > Tp) & (b0 + 1 < B) & (n[nxt] > 0))).to(torch.int32)
+                live = (stamps, 1)
             K.gemm(dzg, xg, dwg, cg, k * cg, Kr, a_kmajor=0, b_kmajor=0, lda=cg, ldb=cg, ldc=k * cg, batch0=1, batch1=groups,
-                   sa=(0, B * Tp * cg), sb=(0, B * Tp * cg), sc=(0, cg * k * cg), a_off=lp * cg, split_k=_POSCONV_DW_SPLIT, colsum=db)
+                   sa=(0, B * Tp * cg), sb=(0, B * Tp * cg), sc=(0, cg * k * cg), a_off=lp * cg, split_k=_POSCONV_DW_SPLIT, colsum=db, k_live=live)
             dw = dwg.view(groups, cg, k, cg).permute(0, 1, 3, 2).reshape(C, cg, k).to(weight.dtype)
             if db is not None:
                 db = db.to(weight.dtype)

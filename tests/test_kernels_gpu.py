@@ -1532,6 +1532,7 @@ def test_pos_conv_frame_limits_keep_every_bit(K, dt):
         outs.append((y.detach(), x.grad, w.grad, bias.grad))
         if limited:
             assert k.STATS.get("gemm_m_len", 0) == 2, dict(k.STATS)   # the forward GEMM and the dX GEMM took their limits
+            assert k.STATS.get("gemm_k_live", 0) == 1, dict(k.STATS)  # ... and the weight-gradient GEMM its live K blocks
     for a, b, what in zip(outs[0], outs[1], ("y", "dx", "dw", "db")):
         assert torch.isfinite(b.float()).all(), what
         assert torch.equal(a, b), "%s differs on %d elements" % (what, int((a != b).sum()))
