@@ -233,7 +233,7 @@ def measure_train(args, device, rank, lib, traffic=True):
         roof["algorithmic_bytes"] = r["bytes"] / max(r["launches"], 1)
         # HBM-side traffic of the same launches from the committed PMC pass of this command (counters need their own rocprofv3
         # run and cannot be read inside the timed process); only quoted for the workload it was collected on
-        pmc = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_gemm_class.json", "r03_pmc_gemm_class.json", "r02_pmc_gemm_class.json", "r01f_pmc_gemm_class.json")) if os.path.exists(f)), None)
+        pmc = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_gemm_class.json", "r04_pmc_gemm_class.json", "r03_pmc_gemm_class.json", "r02_pmc_gemm_class.json", "r01f_pmc_gemm_class.json")) if os.path.exists(f)), None)
         if traffic and name == "gemm" and pmc and args.model == "s2t_w2v2" and args.batch == 32 and args.seconds == 30.0 and args.dtype == "bf16":
             rec = json.load(open(pmc))
             if abs(rec["gemm_class_launches_per_update"] - r["launches"]) <= 16:

@@ -21,7 +21,15 @@ python tools/idle_gaps.py $TDB 3 10 4 40 > $O/${TAG}_idle_gaps.txt 2>&1
 python tools/pmc_step_summary.py --trace-db $TDB $O/pmc_mfma $O/pmc_hbm > $O/${TAG}_pmc_step_summary.txt 2>&1
 python tools/pmc_gemm_class.py $O/pmc_hbm 2 $BUILD > $O/${TAG}_pmc_gemm_class.json 2> $O/pmc_gemm_class.err
 grep -h '^{' $O/trace.log > $O/${TAG}_bench_under_trace.json
-rm -rf $O/trace $O/pmc_mfma $O/pmc_hbm $O/dec_trace $O/pmc_one_ea $O/pmc_one_hm
+# the same launch with the A-stationary walk (8 m-tile rows per XCD group, all N columns swept: CST_GEMM8P_GROUP_M=8)
+export CST_GEMM8P_GROUP_M=8
+cd /tmp
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum -d $O/pmc_g8_ea -o pmc -- python3 $R/tools/gemm_one.py kk 47968 3072 768 3 fc1 > $O/pmc_g8_ea.log 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $O/pmc_g8_hm -o pmc -- python3 $R/tools/gemm_one.py kk 47968 3072 768 3 fc1 > $O/pmc_g8_hm.log 2>&1
+unset CST_GEMM8P_GROUP_M
+cd $R
+python tools/pmc_gemm_one.py $O/pmc_g8_ea $O/pmc_g8_hm 47968 3072 768 "$BUILD group_m=8" > $O/${TAG}_pmc_gemm_groupm8.json 2> $O/pmc_gemm_g8.err
+rm -rf $O/trace $O/pmc_mfma $O/pmc_hbm $O/dec_trace $O/pmc_one_ea $O/pmc_one_hm $O/pmc_g8_ea $O/pmc_g8_hm
 # the bench lines below quote the counter files of THIS build
 cp $O/${TAG}_pmc_gemm_class.json $O/${TAG}_pmc_gemm.json $R/profiles/
 python bench.py > $O/${TAG}_bench_s2t.json 2> $O/bench_s2t.err
@@ -31,4 +39,7 @@ python bench.py --mode decode > $O/${TAG}_bench_decode.json 2> $O/bench_decode.e
 python bench.py --lengths max --no-cpu-baseline --no-extra > $O/${TAG}_bench_maxlen.json 2> $O/bench_maxlen.err
 python tools/probes/hipblaslt_names.py 2>/dev/null | grep ratio > $O/${TAG}_hipblaslt_vs_this_library.txt
 python tools/gemm_shapes_in_step.py > $O/${TAG}_gemm_shapes_in_step.txt 2>/dev/null
+python tools/vendor_in_step.py > $O/${TAG}_vendor_in_step.txt 2>/dev/null
+tools/probes/mfma_rate.bin 4000 > $O/${TAG}_mfma_shape_probe_raw.txt 2>&1
+python tools/bench_conv_layout.py > $O/${TAG}_conv_layout.txt 2>/dev/null
 ls -la $O; du -sh $O
