@@ -707,6 +707,7 @@ class PackedRows:
     def __init__(self, offsets, kv_len, rows, longest, B, T, host_lens=None):
         self.offsets, self.kv_len, self.rows, self.longest, self.B, self.T = offsets, kv_len, rows, longest, B, T
         self.host_lens = host_lens  # real frames per sequence as host integers (read with the plan's one host transfer)
+        self.kept_host = None       # rows each sequence keeps (offsets[b + 1] - offsets[b]) as host integers, where the planner knows them
 
 
 def plan_packed_rows(padding_mask, margin):
@@ -719,7 +720,9 @@ def plan_packed_rows(padding_mask, margin):
     off = torch.zeros(B + 1, dtype=torch.int32, device=padding_mask.device)
     off[1:] = torch.cumsum(n, 0)
     host = torch.cat((off[-1:], n.max().view(1), lens)).tolist()  # the step's packing plan: total rows, longest sequence, lengths
-    return PackedRows(off.contiguous(), lens.contiguous(), int(host[0]), int(host[1]), B, T, [int(v) for v in host[2:]])
+    plan = PackedRows(off.contiguous(), lens.contiguous(), int(host[0]), int(host[1]), B, T, [int(v) for v in host[2:]])
+    plan.kept_host = [min(T, v + margin + 1) for v in plan.host_lens]
+    return plan
 
 
 def plan_from_lengths(lens_dev, host_lens, T):
@@ -966,7 +969,7 @@ class _PosConvFn(torch.autograd.Function):
     a plain k-major operand with lda = C/G < K (overlapping rows) — no segmented addressing in the inner loop."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, groups, lens=None, grad_rows=None):
+    def forward(ctx, x, weight, bias, groups, lens=None, grad_rows=None, grad_rows_host=None):
         """x [B,T,C]; weight [C, C/g, k] -> x + GELU(conv(x) + bias)   (one fused GEMM launch).
         lens (int32 [B], device): frames of x from lens[b] on are ZERO (wav2vec2.py:820-821 zeroes the padding in front of this
         convolution).  The window of output frame t >= lens[b] + k // 2 then holds nothing but zeros, so its row of the implicit
@@ -995,7 +998,7 @@ class _PosConvFn(torch.autograd.Function):
                aux_out=z, ld_aux_out=C, resid=xc, ld_resid=C, split_k=1, m_len=ml)
         ctx.save_for_backward(xg, weight, z)
         ctx.cfg = (B, T, C, k, groups, cg, padl, Tp)
-        ctx.grad_rows = grad_rows
+        ctx.grad_rows, ctx.grad_rows_host = grad_rows, grad_rows_host
         return y
 
     @staticmethod
@@ -1038,12 +1041,26 @@ class _PosConvFn(torch.autograd.Function):
                 # dz is zero from frame grad_rows[b] of utterance b on: the 64-row K blocks of A that lie in those stretches (a third
                 # of them at the bench's lengths) are skipped (cst_gemm_desc.k_live: a block is live iff its stamp equals the epoch, 1).
                 # Row kappa = b Tp + t; a block may run from one utterance's tail into the head of the next.
-                n = ctx.grad_rows.to(torch.int64)
-                ks = torch.arange((Kr + 63) // 64, device=dy.device, dtype=torch.int64) * 64
-                b0 = torch.div(ks, Tp, rounding_mode="floor")
-                t0 = ks - b0 * Tp
-                nxt = torch.clamp(b0 + 1, max=B - 1)
-                stamps = ((t0 < n[b0]) | ((t0 + 64 > Tp) & (b0 + 1 < B) & (n[nxt] > 0))).to(torch.int32)
+                if ctx.grad_rows_host is not None:
+                    # the plan's row counts are host integers already (its one host read): the stamps are a few hundred numbers of
+                    # numpy arithmetic and ONE asynchronous copy from a pinned buffer instead of a dozen small launches
+                    import numpy as np
+                    n = np.asarray(ctx.grad_rows_host, dtype=np.int64)
+                    ks = np.arange((Kr + 63) // 64, dtype=np.int64) * 64
+                    b0 = ks // Tp
+                    t0 = ks - b0 * Tp
+                    nxt = np.minimum(b0 + 1, B - 1)
+                    st = ((t0 < n[b0]) | ((t0 + 64 > Tp) & (b0 + 1 < B) & (n[nxt] > 0))).astype(np.int32)
+                    # (a fresh pinned block per call: torch's host allocator does not hand it out again before the copy has run, which
+                    #  a buffer kept here could not promise across the micro-batches of an accumulated update)
+                    stamps = torch.from_numpy(st).pin_memory().to(dy.device, non_blocking=True)
+                else:
+                    n = ctx.grad_rows.to(torch.int64)
+                    ks = torch.arange((Kr + 63) // 64, device=dy.device, dtype=torch.int64) * 64
+                    b0 = torch.div(ks, Tp, rounding_mode="floor")
+                    t0 = ks - b0 * Tp
+                    nxt = torch.clamp(b0 + 1, max=B - 1)
+                    stamps = ((t0 < n[b0]) | ((t0 + 64 > Tp) & (b0 + 1 < B) & (n[nxt] > 0))).to(torch.int32)
                 live = (stamps, 1)
             K.gemm(dzg, xg, dwg, cg, k * cg, Kr, a_kmajor=0, b_kmajor=0, lda=cg, ldb=cg, ldc=k * cg, batch0=1, batch1=groups,
                    sa=(0, B * Tp * cg), sb=(0, B * Tp * cg), sc=(0, cg * k * cg), a_off=lp * cg, split_k=_POSCONV_DW_SPLIT, colsum=db, k_live=live)
@@ -1052,7 +1069,7 @@ class _PosConvFn(torch.autograd.Function):
                 db = db.to(weight.dtype)
         if ctx.needs_input_grad[2] and db is None:
             db = K.colsum(dz.view(B * T, C), weight.dtype)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 class _WeightNormFn(torch.autograd.Function):
@@ -1077,8 +1094,8 @@ def weight_norm_last_dim(v, g):
     return _WeightNormFn.apply(v, g)
 
 
-def pos_conv_gelu_residual(x, weight, bias, groups, lens=None, grad_rows=None):
-    return _PosConvFn.apply(x, weight, bias, groups, lens, grad_rows)
+def pos_conv_gelu_residual(x, weight, bias, groups, lens=None, grad_rows=None, grad_rows_host=None):
+    return _PosConvFn.apply(x, weight, bias, groups, lens, grad_rows, grad_rows_host)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -219,12 +219,14 @@ class TransformerEncoder(nn.Module):
         # frame limits of the positional convolution (functional._PosConvFn): the input is zero from each utterance's end on (the
         # lines above), so the output tiles whose windows lie in the padding skip their products — exact on every frame — and with a
         # packing plan the gradient of the output is zero behind the rows the plan keeps, which bounds the dX GEMM the same way
-        lens = grad_rows = None
+        lens = grad_rows = grad_rows_host = None
         if padding_mask is not None and not os.environ.get("CST_NO_POSCONV_LIMITS") and not os.environ.get("CST_NO_MLEN"):  # (CST_NO_MLEN: every frame of every conv)
             lens = plan.kv_len if plan is not None else (~padding_mask).sum(dim=1).to(torch.int32)
             if plan is not None:
                 grad_rows = plan.offsets[1:] - plan.offsets[:-1]
-        x = CF.pos_conv_gelu_residual(x, self.pos_conv_weight(), pc.bias, self.conv_pos_groups, lens, grad_rows)  # x += GELU(SamePad(conv(x)))
+                if plan.host_lens is not None and plan.kept_host is not None:
+                    grad_rows_host = plan.kept_host
+        x = CF.pos_conv_gelu_residual(x, self.pos_conv_weight(), pc.bias, self.conv_pos_groups, lens, grad_rows, grad_rows_host)  # x += GELU(SamePad(conv(x)))
         if plan is not None:
             x = CF.pack_rows(x, plan)  # [1, rows, C]
         x = self.layer_norm(x)

@@ -1524,15 +1524,17 @@ def test_pos_conv_frame_limits_keep_every_bit(K, dt):
     b0 = rnd(C, dt=dt, seed=66, scale=0.1)
     dy = rnd(B_, T, C, dt=dt, seed=67) * (t < keep[:, None, None]).to(dt)
     outs = []
-    for limited in (False, True):
+    for limited in (False, True, "host"):   # "host": the K-block stamps from the plan's host integers (one pinned copy) instead of device ops
         x, w, bias = (v.clone().requires_grad_(True) for v in (x0, w0, b0))
         k.STATS.clear()
-        y = CF.pos_conv_gelu_residual(x, w, bias, G, lens if limited else None, keep if limited else None)
+        y = CF.pos_conv_gelu_residual(x, w, bias, G, lens if limited else None, keep if limited else None,
+                                      keep.tolist() if limited == "host" else None)
         y.backward(dy)
         outs.append((y.detach(), x.grad, w.grad, bias.grad))
         if limited:
             assert k.STATS.get("gemm_m_len", 0) == 2, dict(k.STATS)   # the forward GEMM and the dX GEMM took their limits
             assert k.STATS.get("gemm_k_live", 0) == 1, dict(k.STATS)  # ... and the weight-gradient GEMM its live K blocks
-    for a, b, what in zip(outs[0], outs[1], ("y", "dx", "dw", "db")):
-        assert torch.isfinite(b.float()).all(), what
-        assert torch.equal(a, b), "%s differs on %d elements" % (what, int((a != b).sum()))
+    for other in outs[1:]:
+        for a, b, what in zip(outs[0], other, ("y", "dx", "dw", "db")):
+            assert torch.isfinite(b.float()).all(), what
+            assert torch.equal(a, b), "%s differs on %d elements" % (what, int((a != b).sum()))
