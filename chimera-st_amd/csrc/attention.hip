@@ -761,7 +761,9 @@ extern "C" int cst_attn_fwd(const cst_attn_desc* d, cst_stream stream) {
 
 extern "C" int64_t cst_attn_bwd_workspace(const cst_attn_desc* d) {
   if (!d) return 0;
-  return (int64_t)d->B * d->H * 2 * cst_ceil_div(d->Tq, 64) * 64 * (int64_t)sizeof(float);
+  // per (batch, head) and query row padded to whole 64-query tiles: -lse2 and -delta / scale (fp32) + the row's 32-byte dropout
+  // signature (written by the DMA-staged dQ kernel for the dK / dV kernel behind it: attention_fast.inc)
+  return (int64_t)d->B * d->H * cst_ceil_div(d->Tq, 64) * 64 * (int64_t)(2 * sizeof(float) + 32);
 }
 
 extern "C" int cst_attn_bwd(const cst_attn_desc* d, cst_stream stream) {
