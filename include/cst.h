@@ -237,8 +237,9 @@ typedef struct {
    * kernels (csrc/attention_fast.inc), which read tile masks from scalar registers; without it a masked problem runs the generic
    * kernels.  Must describe exactly key_padding_mask. */
   const uint64_t* kpm_bits;
-  /* optional workspace of cst_attn_bwd, cst_attn_bwd_workspace() bytes (NULL = generic backward kernels): the pre-pass writes
-   * -lse * log2(e) and -delta / dropout-scale per query, padded to whole 64-query tiles, for the DMA-staged dK/dV kernel. */
+  /* optional workspace of cst_attn_bwd, cst_attn_bwd_workspace() bytes (NULL = generic backward kernels): the dQ kernel writes
+   * -lse * log2(e) and -delta / dropout-scale per query, padded to whole 64-query tiles, and (round 5) every query row's 32-byte
+   * dropout signature behind them, for the DMA-staged dK/dV kernel. */
   void* bwd_ws;
 } cst_attn_desc;
 
