@@ -65,29 +65,41 @@ def launch_ranks(nproc, argv, env=None):
         s.close()
     base.setdefault("MASTER_ADDR", "127.0.0.1")
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import signal
     procs = []
-    for r in range(nproc):
-        e = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nproc), LOCAL_WORLD_SIZE=str(nproc))
-        procs.append(subprocess.Popen(list(argv), env=e, stdout=None if r == 0 else sys.stderr))
+
+    def _stop(signum, frame):  # the launcher itself is told to stop (a driver's timeout): the ranks must not outlive it
+        raise SystemExit(128 + signum)
+
+    old_term = signal.signal(signal.SIGTERM, _stop)
     code = 0
-    alive = set(range(nproc))
-    while alive:
-        for r in sorted(alive):
-            rc = procs[r].poll()
-            if rc is None:
-                continue
-            alive.discard(r)
-            if rc != 0 and code == 0:
-                code = rc if rc > 0 else 1
-                sys.stderr.write("rank %d exited with code %d: stopping the other ranks\n" % (r, rc))
-                for o in sorted(alive):
-                    procs[o].terminate()
-        time.sleep(0.05)
-    for pr in procs:
-        try:
-            pr.wait(timeout=30)
-        except subprocess.TimeoutExpired:
-            pr.kill()
+    try:
+        for r in range(nproc):
+            e = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nproc), LOCAL_WORLD_SIZE=str(nproc))
+            procs.append(subprocess.Popen(list(argv), env=e, stdout=None if r == 0 else sys.stderr))
+        alive = set(range(nproc))
+        while alive:
+            for r in sorted(alive):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                alive.discard(r)
+                if rc != 0 and code == 0:
+                    code = rc if rc > 0 else 1
+                    sys.stderr.write("rank %d exited with code %d: stopping the other ranks\n" % (r, rc))
+                    for o in sorted(alive):
+                        procs[o].terminate()
+            time.sleep(0.05)
+    finally:
+        signal.signal(signal.SIGTERM, old_term)
+        for pr in procs:  # (normal exit: all have ended; an exception or a signal in the launcher: end the ranks we started, by PID)
+            if pr.poll() is None:
+                pr.terminate()
+        for pr in procs:
+            try:
+                pr.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                pr.kill()
     return code
 
 
