@@ -55,6 +55,11 @@ def test_arch_quirk_q4_and_script_flags():
     assert args.encoder_normalize_before and args.decoder_normalize_before
     assert args.dropout == 0.1 and args.attention_dropout == 0.1 and args.activation_dropout == 0.1
     assert args.loss_ratio == [1.0, 1.0, 1.0] and args.ddp_backend == "no_c10d"
+    # flags the scripts do not pass keep the reference's defaults: world size = visible GPUs (None until the launcher counts them,
+    # options.py:310), no optimizer-state sharding (dataclass/configs.py:327); `--zero-sharding os` / `--distributed-world-size N` parse
+    assert args.zero_sharding == "none" and args.distributed_world_size is None
+    a2 = reg.parse_args_and_arch(argv + ["--zero-sharding", "os", "--distributed-world-size", "8"])
+    assert a2.zero_sharding == "os" and a2.distributed_world_size == 8
     ns = Namespace()
     reg.ARCH_CONFIG_REGISTRY["s2t_transformer_m"](ns)
     assert (ns.encoder_embed_dim, ns.encoder_attention_heads, ns.dropout, ns.encoder_layers) == (512, 8, 0.15, 12)
