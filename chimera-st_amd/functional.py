@@ -831,12 +831,13 @@ class _Conv1dCLFn(torch.autograd.Function):
     so the zero rows the dX windows need at utterance boundaries exist without copying."""
 
     @staticmethod
-    def forward(ctx, x, w_cl, bias, k, stride, pad, act, prev_z, grad_is_dz, nz_out=None, nz_in=None):
+    def forward(ctx, x, w_cl, bias, k, stride, pad, act, prev_z, grad_is_dz, nz_out=None, nz_in=None, unread_ok=False):
         if _os.environ.get("CST_NO_MLEN"):  # A/B switch of the tests: compute the frames past each utterance's end as well
             nz_in = None
             fwd_len = None
         else:
-            fwd_len = nz_out if bias is None else None
+            # (with a bias the rows of a skipped tile hold act(bias), not 0: only where the caller states that nobody reads them)
+            fwd_len = nz_out if (bias is None or unread_ok) else None
         ctx.nz_out = nz_out  # int32 [B]: the incoming gradient's rows t >= nz_out[b] are exactly zero (frames past the utterance's end)
         ctx.nz_in = nz_in    # int32 [stride, B]: live rows of each residue class of dx (cst_conv_row_limits); dx is zero behind them
         B, Lin, Cin = x.shape
@@ -938,10 +939,10 @@ class _Conv1dCLFn(torch.autograd.Function):
             # (not deferred: autograd re-lays this gradient out — permute / reshape back to [Cout, Cin, k] — as soon as it is returned)
         if has_bias and ctx.needs_input_grad[2]:
             db = K.colsum(dz_rows.reshape(B * Lout, Cout) if dzp is None else dzp[:, 1:1 + Lout].reshape(B * Lout, Cout), w_cl.dtype)
-        return dx, dw, db, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
-def conv1d_cl(x, weight, bias, stride, pad=0, act=None, prev_z=None, grad_is_dz=False, nz_out=None, nz_in=None):
+def conv1d_cl(x, weight, bias, stride, pad=0, act=None, prev_z=None, grad_is_dz=False, nz_out=None, nz_in=None, unread_ok=False):
     """Channels-last conv1d.  x [B,Lin,Cin]; weight [Cout,Cin,k] (torch layout).  Returns (y, z) where z is
     the pre-activation (None without activation).  If `prev_z` (pre-GELU tensor that produced x = GELU(prev_z))
     is given, the returned input-gradient is already multiplied by GELU'(prev_z), i.e. it is d/d prev_z; the
@@ -951,7 +952,7 @@ def conv1d_cl(x, weight, bias, stride, pad=0, act=None, prev_z=None, grad_is_dz=
     w_cl = weight.permute(0, 2, 1).reshape(Cout, k * Cin)
     if not w_cl.is_contiguous():
         w_cl = w_cl.contiguous()
-    return _Conv1dCLFn.apply(x, w_cl, bias, k, stride, pad, _ACT[act], prev_z, bool(grad_is_dz), nz_out, nz_in)
+    return _Conv1dCLFn.apply(x, w_cl, bias, k, stride, pad, _ACT[act], prev_z, bool(grad_is_dz), nz_out, nz_in, bool(unread_ok))
 
 
 # ------------------------------------------------------------------------------------------------

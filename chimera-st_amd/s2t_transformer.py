@@ -4,6 +4,8 @@ fairseq/models/transformer.py:530-903."""
 import math
 from typing import Dict, List, Optional
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -47,12 +49,25 @@ class Conv1dSubsampler(nn.Module):
             out = ((out.float() - 1) / 2 + 1).floor().long()
         return out
 
-    def forward(self, src_tokens, src_lengths):
+    def forward(self, src_tokens, src_lengths, padding_unread=False):
+        """padding_unread: the caller drops every output frame behind an utterance's subsampled length (the s2t encoder's padding-free
+        layer stack) — their gradient is exactly zero and nobody reads their values, so each conv computes only the frames the live
+        outputs of the layer behind it read (cst_gemm_desc.m_len) and its weight-gradient GEMM stops there (k_len)."""
         x = src_tokens  # B x T x C
-        for conv in self.conv_layers:
-            z, _ = CF.conv1d_cl(x, conv.weight, conv.bias, 2, pad=conv.kernel_size // 2)
+        lens = [src_lengths]
+        for _ in range(self.n_layers):
+            lens.append(((lens[-1].float() - 1) / 2 + 1).floor().long())
+        limits = [None] * self.n_layers
+        if padding_unread and not os.environ.get("CST_NO_MLEN"):
+            need = lens[-1]  # frames of the last layer's output that are read
+            for i in reversed(range(self.n_layers)):
+                limits[i] = need.to(torch.int32).contiguous()
+                k = self.conv_layers[i].kernel_size
+                need = (need - 1) * 2 + (k - k // 2)  # the input frames those read: up to 2 (need - 1) + k - 1 - pad
+        for i, conv in enumerate(self.conv_layers):
+            z, _ = CF.conv1d_cl(x, conv.weight, conv.bias, 2, pad=conv.kernel_size // 2, nz_out=limits[i], unread_ok=limits[i] is not None)
             x = CF.glu(z)
-        return to_time_major_view(x), self.get_out_seq_lens_tensor(src_lengths)  # T x B x C view of batch-major storage
+        return to_time_major_view(x), lens[-1]  # T x B x C view of batch-major storage
 
 
 class TransformerDecoder(FairseqIncrementalDecoder):

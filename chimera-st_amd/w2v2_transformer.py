@@ -127,7 +127,12 @@ class S2T_W2V2_TransformerEncoder(FairseqEncoder):
     def forward(self, src_tokens, src_lengths, **extra_args):
         self.wav2vec_model.last_plan = None
         w2v_feature, _, input_lengths = self._get_w2v_feature(src_tokens, src_lengths)
-        x, input_lengths = self.subsample(w2v_feature, input_lengths)
+        # (the stack below runs on the real frames only whenever the wav2vec2 plan's host lengths are there: the subsampler then need not
+        #  compute — nor reduce its weight gradients over — the frames behind each utterance's end)
+        w2v_plan = getattr(self.wav2vec_model, "last_plan", None)
+        will_pack = (w2v_plan is not None and w2v_plan.host_lens is not None and not os.environ.get("CST_NO_PACK")
+                     and not os.environ.get("CST_NO_PACK_S2T"))
+        x, input_lengths = self.subsample(w2v_feature, input_lengths, padding_unread=will_pack)
         encoder_padding_mask = lengths_to_padding_mask(input_lengths, max_len=x.size(0))
         # embed_scale * x + sinusoidal positions (audio DOES get positions here, :356-358) + dropout: one kernel
         x = to_time_major_view(CF.embed_positions(pad_mask=encoder_padding_mask, x=to_batch_major(x),
