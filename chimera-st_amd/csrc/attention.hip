@@ -759,6 +759,12 @@ extern "C" int cst_attn_fwd(const cst_attn_desc* d, cst_stream stream) {
   return cst_check_launch("cst_attn_fwd");
 }
 
+// (internal, cst_common.h) the matrix-core kernel behind cst_dec_cross_attn for bf16 / head dim 64 / beam <= 32 (attention_fast.inc)
+int cst_fa_dec_cross(const void* q, const void* kx, const void* vx, const uint8_t* kpm, void* out, const int32_t* step, int64_t max_len,
+                     int64_t bsz, int64_t beam, int64_t H, int64_t S, float scale, hipStream_t s) {
+  return fa_dec_cross_launch(q, kx, vx, kpm, out, step, max_len, bsz, beam, H, S, scale, s);
+}
+
 extern "C" int64_t cst_attn_bwd_workspace(const cst_attn_desc* d) {
   if (!d) return 0;
   // per (batch, head) and query row padded to whole 64-query tiles: -lse2 and -delta / scale (fp32) + the row's 32-byte dropout

@@ -76,11 +76,11 @@ __global__ __launch_bounds__(512) void beam_row_topk_kernel(BeamP p, float* cand
   const int nvec = (V + VEC - 1) / VEC;
   const T* lg = reinterpret_cast<const T*>(p.logits) + (int64_t)h * p.ld_logits;
   const float NEG = -INFINITY;
-  __shared__ float red_m[NW], red_s[NW], wv[NW];
-  __shared__ int wi[NW];
+  __shared__ float red_m[NW], red_s[NW];
   __shared__ float sh_lse;
-  __shared__ float o_val[KMAX_ALL];
-  __shared__ int o_tok[KMAX_ALL];
+  __shared__ float w_val[NW * KMAX_ALL];
+  __shared__ int w_tok[NW * KMAX_ALL];
+  static_assert(KMAX_ALL <= 64 && NW <= 64, "the merge keeps one output candidate / one list head per lane of wave 0");
 
   float x[NV][VEC];
   float mx = NEG;
@@ -156,14 +156,41 @@ __global__ __launch_bounds__(512) void beam_row_topk_kernel(BeamP p, float* cand
       const int vi = tid + i * NTH;
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
+        // (bitwise, not short-circuit: the && / || form compiled to ~5 exec-mask branches per element — 121 in the kernel, 3 us per scan)
         const float val = x[i][e];
         const int v = vi * VEC + e;
-        const bool open = val < tv || (val == tv && v > ti);
-        if (open && val == val && cand_better(val, v, bv, bi)) { bv = val; bi = v; }
+        const bool open = (val < tv) | ((val == tv) & (v > ti));          // NaN (not a candidate) compares false both ways
+        const bool take = open & ((val > bv) | ((val == bv) & (v < bi)));
+        bv = take ? val : bv;
+        bi = take ? v : bi;
       }
     }
   };
-  rescan();
+  // Selection in two levels, ONE barrier (round 5; the block-wide arg-max per candidate it replaces cost two barriers and an LDS
+  // round trip for each of the 2*beam candidates: 37 us per step): every wave first extracts ITS top-K in order — K rounds of a
+  // wave-wide arg-max by shuffles, the winning lane rescans its registers — then wave 0 merges the NW sorted lists, lane w holding
+  // the head of wave w's list.  The order is total (value, then token), so the result is the block-wide selection's.
+  // the thread's best AND second best in one pass: a lane that wins a round usually has its next head at hand, and the wave enters
+  // the (divergent, 24-element) rescan only when one of its lanes wins a third time
+  float nv = NEG;
+  int ni = INT_MAX;
+  bv = NEG; bi = INT_MAX;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int vi = tid + i * NTH;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float val = x[i][e];
+      const int v = vi * VEC + e;
+      const bool b1 = (val > bv) | ((val == bv) & (v < bi));    // NaN (not a candidate): false
+      const bool b2 = (val > nv) | ((val == nv) & (v < ni));
+      nv = b1 ? bv : (b2 ? val : nv);
+      ni = b1 ? bi : (b2 ? v : ni);
+      bv = b1 ? val : bv;
+      bi = b1 ? v : bi;
+    }
+  }
+  bool have_next = true;
   for (int k = 0; k < K; ++k) {
     float cv = bv;
     int ci = bi;
@@ -171,24 +198,50 @@ __global__ __launch_bounds__(512) void beam_row_topk_kernel(BeamP p, float* cand
     for (int o = 32; o > 0; o >>= 1) {
       const float v2 = __shfl_xor(cv, o, 64);
       const int i2 = __shfl_xor(ci, o, 64);
-      if (cand_better(v2, i2, cv, ci)) { cv = v2; ci = i2; }
+      const bool b = (v2 > cv) | ((v2 == cv) & (i2 < ci));
+      cv = b ? v2 : cv;
+      ci = b ? i2 : ci;
     }
-    if (lane == 0) { wv[wave] = cv; wi[wave] = ci; }
-    __syncthreads();
-    cv = wv[0]; ci = wi[0];
-#pragma unroll
-    for (int w = 1; w < NW; ++w)
-      if (cand_better(wv[w], wi[w], cv, ci)) { cv = wv[w]; ci = wi[w]; }
-    if (bi == ci && ci != INT_MAX) {  // this thread owns the winner: take it, find its next best
+    const bool won = bi == ci && ci != INT_MAX;  // this lane owns the wave's winner: take it, bring up its next best
+    if (won) {
       tv = bv; ti = bi;
-      rescan();
+      bv = nv; bi = ni;
     }
-    if (tid == 0) { o_val[k] = cv; o_tok[k] = ci == INT_MAX ? p.pad : ci; }  // (a global store here would be waited for at every barrier)
-    __syncthreads();
+    if (__builtin_expect(__any(won && !have_next), 0)) {
+      if (won && !have_next) rescan();
+    }
+    if (won) have_next = false;
+    if (lane == 0) { w_val[wave * KMAX_ALL + k] = cv; w_tok[wave * KMAX_ALL + k] = ci; }
   }
-  if (tid < K) {
-    cand_val[(int64_t)h * K + tid] = o_val[tid];
-    cand_tok[(int64_t)h * K + tid] = o_tok[tid];
+  __syncthreads();
+  if (wave == 0) {
+    int pos = 0;  // lanes 0 .. NW-1: the next unread entry of wave `lane`'s list
+    float hv = lane < NW ? w_val[lane * KMAX_ALL] : NEG;
+    int hi_ = lane < NW ? w_tok[lane * KMAX_ALL] : INT_MAX;
+    float ov = NEG;
+    int ot = INT_MAX;
+    for (int k = 0; k < K; ++k) {
+      float cv = hv;
+      int ci = hi_;
+#pragma unroll
+      for (int o = NW / 2; o > 0; o >>= 1) {
+        const float v2 = __shfl_xor(cv, o, 64);
+        const int i2 = __shfl_xor(ci, o, 64);
+        if (cand_better(v2, i2, cv, ci)) { cv = v2; ci = i2; }
+      }
+      cv = __shfl(cv, 0, 64);
+      ci = __shfl(ci, 0, 64);
+      if (lane < NW && hi_ == ci && ci != INT_MAX) {  // this list's head was taken: advance
+        ++pos;
+        hv = pos < K ? w_val[lane * KMAX_ALL + pos] : NEG;
+        hi_ = pos < K ? w_tok[lane * KMAX_ALL + pos] : INT_MAX;
+      }
+      if (lane == k) { ov = cv; ot = ci == INT_MAX ? p.pad : ci; }
+    }
+    if (lane < K) {
+      cand_val[(int64_t)h * K + lane] = ov;
+      cand_tok[(int64_t)h * K + lane] = ot;
+    }
   }
 }
 
@@ -378,19 +431,20 @@ __global__ __launch_bounds__(256) void beam_merge_kernel(BeamP p, const float* c
     }
     // ---- (e) rows of the next step ----
     if (s < p.max_len) {
-      for (int i = 0; i < beam; ++i) {
-        const int k = act[i];
-        const int64_t src = sent * beam + c_beam[k], dst = (int64_t)sent * beam + i;
-        for (int j = tid; j <= s; j += blockDim.x) {
-          tok_new[dst * LT + j] = tok_old[src * LT + j];
-          anc_new[dst * L1 + j] = anc_old[src * L1 + j];
-          if (j < s) sc_new[dst * L1 + j] = sc_old[src * L1 + j];
-        }
-        if (tid == 0) {
-          tok_new[dst * LT + s + 1] = c_tok[k];
-          sc_new[dst * L1 + s] = c_score[k];
-          anc_new[dst * L1 + s + 1] = (int32_t)dst;
-        }
+      // (one flat loop over (row, position): a loop over the rows around a loop over the positions is `beam` dependent memory round trips)
+      for (int idx = tid; idx < beam * (s + 1); idx += blockDim.x) {
+        const int i = idx / (s + 1), j = idx - i * (s + 1);
+        const int64_t src = sent * beam + c_beam[act[i]], dst = (int64_t)sent * beam + i;
+        tok_new[dst * LT + j] = tok_old[src * LT + j];
+        anc_new[dst * L1 + j] = anc_old[src * L1 + j];
+        if (j < s) sc_new[dst * L1 + j] = sc_old[src * L1 + j];
+      }
+      if (tid < beam) {
+        const int k = act[tid];
+        const int64_t dst = (int64_t)sent * beam + tid;
+        tok_new[dst * LT + s + 1] = c_tok[k];
+        sc_new[dst * L1 + s] = c_score[k];
+        anc_new[dst * L1 + s + 1] = (int32_t)dst;
       }
     }
   }
@@ -985,12 +1039,21 @@ int cst_dec_cross_attn(const void* q, const void* kx, const void* vx, const uint
   CST_REQUIRE(dtype == CST_F32 || dtype == CST_BF16, "cst_dec_cross_attn: bad dtype %d", dtype);
   CST_REQUIRE(D == 32 || D == 64, "cst_dec_cross_attn: head dim %lld not in {32,64}", (long long)D);
   CST_REQUIRE(bsz > 0 && beam > 0 && H > 0 && S > 0, "cst_dec_cross_attn: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  // bf16 / head dim 64 / at most 32 hypotheses per sentence: the matrix-core kernel whose four waves split the keys (attention_fast.inc);
+  // CST_DEC_CROSS_VALU=1 keeps the VALU kernel below (A/B runs)
+  static const bool valu_only = getenv("CST_DEC_CROSS_VALU") != nullptr;
+  if (!valu_only && dtype == CST_BF16 && D == 64 && beam <= 32 && S * 128 < (1ll << 31) && ((uintptr_t)q % 16 == 0) && ((uintptr_t)kx % 16 == 0) &&
+      ((uintptr_t)vx % 16 == 0) && ((uintptr_t)out % 16 == 0)) {
+    CstProfScope prof(CST_K_ATTN_FWD, s, 4.0 * bsz * beam * H * D * S, 2.0 * bsz * S * H * D * cst_dtype_size(dtype));
+    const int rc = cst_fa_dec_cross(q, kx, vx, key_padding_mask, out, step, max_len, bsz, beam, H, S, scale, s);
+    return rc != CST_OK ? rc : cst_check_launch("cst_dec_cross_attn");
+  }
   const int BQ = beam == 1 ? 1 : (beam <= 5 ? 5 : 8);
   // waves per workgroup = slices the key range is cut into (each wave streams its own keys; more waves = more loads in flight)
   static const int env_nw = getenv("CST_DEC_CROSS_NW") ? atoi(getenv("CST_DEC_CROSS_NW")) : 0;
   const int NWv = env_nw == 8 ? 8 : 4;  // 8 measured no faster end to end (and the flash kernel remains the engine's default: 0.198 vs 0.230 s per batch)
   const size_t lds = ((size_t)2 * NWv * BQ + (size_t)NWv * BQ * D + (size_t)BQ * D) * sizeof(float);
-  hipStream_t s = (hipStream_t)stream;
   CstProfScope prof(CST_K_ATTN_FWD, s, 4.0 * bsz * beam * H * D * S, 2.0 * bsz * S * H * D * cst_dtype_size(dtype));
 #define CST_DCA_W(T, DD, QQ, WW)                                                                                                \
   do {                                                                                                                          \

@@ -29,7 +29,7 @@ from .optim import PARAM_EPOCH
 
 class BeamDecodeEngine:
     def __init__(self, decoder, tgt_dict, beam_size, max_len, min_len=1, normalize_scores=True, len_penalty=1.0,
-                 unk_penalty=0.0, temperature=1.0, use_graph=True, poll=8, cross_kernel="flash", lanes=None):
+                 unk_penalty=0.0, temperature=1.0, use_graph=True, poll=8, cross_kernel=None, lanes=None):
         self.dec = decoder
         self.pad, self.unk, self.eos = tgt_dict.pad(), tgt_dict.unk(), tgt_dict.eos()
         self.vocab = len(tgt_dict)
@@ -42,7 +42,11 @@ class BeamDecodeEngine:
         # streams: no faster, 0.811 vs 0.812 ms per step); "shared" = cst_dec_cross_attn (VALU kernel, one pass with online
         # softmax, K/V rows shared by the beam: ~59 us — the 5 queries' dot products per key cost more than the MFMA tile the
         # flash kernel spends on them; kept selectable, covered by the same tests)
-        assert cross_kernel in ("flash", "flash_hm", "shared")
+        # "auto" (round 5): "shared" where cst_dec_cross_attn runs its matrix-core kernel (bf16, head dim 64, beam <= 32: the four waves
+        # of a (sentence, head) workgroup split the keys, 21.5 us per layer against 26.4 for "flash" on s2t_transformer_l), else "flash"
+        if cross_kernel is None:
+            cross_kernel = os.environ.get("CST_DEC_CROSS_KERNEL", "auto")
+        assert cross_kernel in ("auto", "flash", "flash_hm", "shared")
         self.cross_kernel = cross_kernel
         # lanes: the batch may be cut into groups of sentences, each with its own state, step graph and HIP stream, replayed side by
         # side (sentences never interact in beam search: same hypotheses, tests/test_decode_engine_gpu.py).  Measured on MI355X
@@ -196,9 +200,14 @@ class BeamDecodeEngine:
         K.gemm(x, w, out, M, N, Kd, a_kmajor=1, b_kmajor=1, lda=Kd, ldb=Kd, ldc=out.stride(0), bias=b, act=act,
                resid=resid, ld_resid=0 if resid is None else resid.stride(0), split_k=split, ws=ws if split > 1 else None)
 
-    def _cross_fits(self, S, D):
+    def _cross_mode(self, dtype, D):
+        if self.cross_kernel != "auto":
+            return self.cross_kernel
+        return "shared" if (dtype == torch.bfloat16 and D == 64 and self.beam <= 32) else "flash"
+
+    def _cross_fits(self, dtype, D):
         """True: the encoder K/V of this engine are stored head-major [bsz, H, S, D]."""
-        return self.cross_kernel in ("shared", "flash_hm")
+        return self._cross_mode(dtype, D) in ("shared", "flash_hm")
 
     def _ln(self, x, ln, out, st):
         lib = L.load()
@@ -237,14 +246,15 @@ class BeamDecodeEngine:
                 self._linear(st["h"], ca.q_proj.weight, ca.q_proj.bias, st["q"])
             # cross attention: one workgroup per (sentence, head); the sentence's K/V rows serve all of its beam rows
             S = st["kx"][li].shape[1]
-            if self.cross_kernel == "flash_hm":  # the flash kernel over head-major K/V: (b, h, t) strides = (H*S*D, S*D, D)
+            ck = self._cross_mode(st["x"].dtype, D)
+            if ck == "flash_hm":  # the flash kernel over head-major K/V: (b, h, t) strides = (H*S*D, S*D, D)
                 q3, o3 = st["q"].view(bsz, self.beam, C), st["attn"].view(bsz, self.beam, C)
                 d = K.attn_desc(q3, st["kx"][li], st["vx"][li], o3, st["lse"], H, D, st["kpm"], False, float(ca.scaling))
                 d.k_sb = d.v_sb = H * S * D
                 d.k_sh = d.v_sh = S * D
                 d.k_st = d.v_st = D
                 K.attn_fwd_desc(d)
-            elif self.cross_kernel == "shared":
+            elif ck == "shared":
                 L.check(lib.cst_dec_cross_attn(L.ptr(st["q"]), L.ptr(st["kx"][li]), L.ptr(st["vx"][li]), L.ptr(st["kpm"]), L.ptr(st["attn"]),
                                                L.ptr(st["step"]), self.max_len, bsz, self.beam, H, D, S, float(ca.scaling), dt,
                                                L.stream_ptr()), "cst_dec_cross_attn")
@@ -339,7 +349,7 @@ class BeamDecodeEngine:
         flat = encb.reshape(bsz * S, Ce)
         for li, layer in enumerate(self.dec.layers):  # static cross-attention K/V, once per sentence (not per beam)
             ca = layer.encoder_attn
-            if self._cross_fits(S, ca.head_dim):  # head-major [bsz, H, S, D] for cst_dec_cross_attn (one transposing copy per call)
+            if self._cross_fits(st["x"].dtype, ca.head_dim):  # head-major [bsz, H, S, D] for cst_dec_cross_attn (one transposing copy per call)
                 for name, proj in (("kx", ca.k_proj), ("vx", ca.v_proj)):
                     self._linear(flat, proj.weight, proj.bias, st["proj"])
                     st[name][li].view(bsz, ca.num_heads, S, ca.head_dim).copy_(

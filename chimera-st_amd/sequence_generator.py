@@ -35,7 +35,7 @@ class BeamSearch:
 class SequenceGenerator:
     def __init__(self, models, tgt_dict, beam_size=1, max_len_a=0, max_len_b=200, min_len=1, normalize_scores=True,
                  len_penalty=1.0, unk_penalty=0.0, temperature=1.0, match_source_len=False, no_repeat_ngram_size=0,
-                 search_strategy=None, eos=None, fused=True, use_graph=True, cross_kernel="flash"):
+                 search_strategy=None, eos=None, fused=True, use_graph=True, cross_kernel=None):
         self.model = models[0] if isinstance(models, (list, tuple)) else models
         self.tgt_dict = tgt_dict
         self.pad, self.unk = tgt_dict.pad(), tgt_dict.unk()
