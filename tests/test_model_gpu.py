@@ -307,8 +307,8 @@ def test_cnn_gradient_is_zero_past_the_bound_the_weight_gradients_use():
     seen = []
     orig = CF.conv1d_cl
 
-    def spy(x, weight, bias, stride, pad=0, act=None, prev_z=None, grad_is_dz=False, nz_out=None, nz_in=None):
-        y, z = orig(x, weight, bias, stride, pad=pad, act=act, prev_z=prev_z, grad_is_dz=grad_is_dz, nz_out=nz_out, nz_in=nz_in)
+    def spy(x, weight, bias, stride, pad=0, act=None, prev_z=None, grad_is_dz=False, nz_out=None, nz_in=None, **kw):
+        y, z = orig(x, weight, bias, stride, pad=pad, act=act, prev_z=prev_z, grad_is_dz=grad_is_dz, nz_out=nz_out, nz_in=nz_in, **kw)
         if nz_out is not None:
             y.register_hook(lambda gr, nz=nz_out: seen.append((gr.detach().clone(), nz.clone())))
         return y, z
