@@ -1000,7 +1000,6 @@ static int gemm_one(const cst_gemm_desc* d, cst_stream stream, int64_t drop_row0
   p.sched = nullptr;  // set by the persistent kernel's launcher
   p.gperm_full = 0;  // (likewise)
   p.mrot = 0;
-  p.stagger = 0;
   {
     static const bool no_klive = getenv("CST_GEMM_NO_KLIVE") != nullptr;  // A/B switch: visit the all-zero K blocks too
     p.k_live = no_klive ? nullptr : d->k_live;

@@ -392,10 +392,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
     }
     par ^= 1;
   };
-  if (kp->stagger > 0) {
-    const int late = ((blockIdx.x >> 3) & 3) * kp->stagger;
-    for (int i = 0; i < late; ++i) __builtin_amdgcn_s_sleep(127);
-  }
   setup(v);
   {
     const int S = 4 * nt;
@@ -863,8 +859,6 @@ int launch8p(GemmParams p, int64_t nbatch, hipStream_t s) {
     }
   }
   p.nitems = (int)nitems;
-  static const int stagger = [] { const char* e = getenv("CST_GEMM8P_STAGGER"); return e ? atoi(e) : 0; }();
-  p.stagger = nitems > 2 * avail ? stagger : 0;
   dim3 grid((unsigned)(nitems < avail ? nitems : avail), 1, 1);
   static const bool static_walk = getenv("CST_GEMM8P_STATIC") != nullptr;
   // (not under stream capture: a captured launch would pin one slot of the ring for every replay of the graph)

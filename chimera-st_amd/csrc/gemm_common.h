@@ -45,7 +45,6 @@ struct GemmParams {
   int gperm_full, gperm_q, gperm_r;
   int mrot;  // ... and batches with fewer groups than that: batch z walks its tiles rotated by z * mrot positions (0 = off)
   unsigned long long magic_gq, magic_gq1;
-  int stagger;  // gemm8p (experiment): workgroup j of an XCD starts (j & 3) * stagger sleeps late
   int split_order;  // gemm_kernel, split-K unbatched: XCD-contiguous (split, tile) item order (see the kernel)
   int* sched;       // gemm8p: 16 zeroed ints of scheduling state (8 per-XCD item counters, 1 exit counter), nullptr = static walk
   const uint32_t* m_live; uint32_t m_epoch;  // rows of A in blocks of 64: an output tile with no live block skips its K loop
