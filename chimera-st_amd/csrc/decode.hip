@@ -540,14 +540,35 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const T* qkv, T* kc,
   float m = -INFINITY, l = 0.0f, acc[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) acc[e] = 0.0f;
+  // bf16 (the timed configuration): scores in log2 units (one v_exp_f32 per probability), the 8-lane dot-product sums by DPP instead
+  // of ds_bpermute.  fp32 (the parity configuration) keeps expf and the shuffle order its token ids were pinned with.
+  constexpr bool FAST = sizeof(T) == 2 && LPK == 8;
+  if (FAST) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) q[e] *= 1.4426950408889634f;
+  }
+  // The ancestry entries of a batch are a memory round trip IN FRONT of its K / V loads (their addresses): the next batch's are
+  // requested while this one is worked on, so only the first batch pays for both.
+  int an[UNR];
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) {
+    const int j = u * KPI + slot;
+    an[u] = j < s ? anc[j] : 0;
+  }
   for (int j0 = 0; j0 <= s; j0 += KPI * UNR) {
     u32x4 tk[UNR], tv[UNR];
     float part[UNR];
+    int an_next[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int jn = j0 + KPI * UNR + u * KPI + slot;
+      an_next[u] = jn < s ? anc[jn] : 0;
+    }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int j = j0 + u * KPI + slot;
       if (j <= s) {  // position s comes from the projection buffer, not from the cache (written above by other lanes)
-        const int64_t off = j == s ? 0 : (((int64_t)anc[j] * H + head) * L1 + j) * D + c0;
+        const int64_t off = j == s ? 0 : (((int64_t)an[u] * H + head) * L1 + j) * D + c0;
         tk[u] = *reinterpret_cast<const u32x4*>(j == s ? kn : kc + off);
         tv[u] = *reinterpret_cast<const u32x4*>(j == s ? vn : vc + off);
       }
@@ -563,14 +584,20 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const T* qkv, T* kc,
 #pragma unroll
         for (int e = 0; e < VEC; ++e) d = fmaf(q[e], kf[e], d);
       }
+      if constexpr (FAST) {
+        d += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+        d += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+        d += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x141, 0xF, 0xF, true));  // row_half_mirror: the other quad of the 8
+      } else {
 #pragma unroll
-      for (int o = LPK >> 1; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+        for (int o = LPK >> 1; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+      }
       part[u] = j <= s ? d : -INFINITY;
       bm = fmaxf(bm, part[u]);
     }
     bm = wave_max(bm);
     const float mn = fmaxf(m, bm);
-    const float corr = m == -INFINITY ? 0.0f : expf(m - mn);
+    const float corr = m == -INFINITY ? 0.0f : (FAST ? __builtin_amdgcn_exp2f(m - mn) : expf(m - mn));
     l *= corr;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) acc[e] *= corr;
@@ -578,7 +605,7 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const T* qkv, T* kc,
     for (int u = 0; u < UNR; ++u) {
       const int j = j0 + u * KPI + slot;
       if (j <= s) {
-        const float pe = expf(part[u] - mn);
+        const float pe = FAST ? __builtin_amdgcn_exp2f(part[u] - mn) : expf(part[u] - mn);
         l += pe;
         float vf[VEC];
         cvt_vec<T>(tv[u], vf);
@@ -586,6 +613,8 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const T* qkv, T* kc,
         for (int e = 0; e < VEC; ++e) acc[e] = fmaf(pe, vf[e], acc[e]);
       }
     }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) an[u] = an_next[u];
     m = mn;
   }
 #pragma unroll
