@@ -237,9 +237,12 @@ def test_dec_linear_matches_fp32_reference(KL, M, N, K, act, has_bias, has_resid
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("H,D,beam,S", [(8, 64, 5, 375), (2, 32, 1, 64), (4, 64, 10, 130), (16, 64, 3, 33)])
+@pytest.mark.parametrize("H,D,beam,S", [(8, 64, 5, 375), (2, 32, 1, 64), (4, 64, 10, 130), (16, 64, 3, 33), (4, 64, 32, 97), (2, 64, 1, 1),
+                                        (16, 64, 5, 750), (2, 64, 33, 70)])
 def test_dec_cross_attn(KL, dtype, H, D, beam, S):
-    """Shared per-sentence K/V, beam queries each, ragged key padding — against plain fp32 softmax attention."""
+    """Shared per-sentence K/V, beam queries each, ragged key padding — against plain fp32 softmax attention.  bf16 / head dim 64 /
+    beam <= 32 runs the matrix-core kernel whose four waves split the keys (fewer tiles than waves, a ragged last tile, 32 query rows and
+    the bench's own shape are in the list); beam 33, head dim 32 and fp32 run the VALU kernel."""
     k, L = KL
     lib = L.load()
     bsz, C = 3, H * D
