@@ -524,7 +524,10 @@ int cst_dec_self_attn(const void* qkv, void* kcache, void* vcache, const int32_t
                       int64_t rows, int64_t H, int64_t D, int64_t max_len, float scale, int dtype, cst_stream stream);
 /* Cross attention of one decode step (modules/multihead_attention.py:189-293 with static_kv): q, out [bsz*beam, H*D];
  * kx, vx HEAD-MAJOR [bsz, H, S, D] — the encoder keys / values of a SENTENCE, shared by its beam hypotheses (not replicated);
- * key_padding_mask uint8 [bsz, S] or NULL.  No-op when *step > max_len.  One pass, online softmax; any S. */
+ * key_padding_mask uint8 [bsz, S] or NULL.  No-op when *step > max_len.  One pass, online softmax; any S.
+ * bf16 / D = 64 / beam <= 32 (operands 16-byte aligned): the matrix-core kernel of csrc/attention_fast.inc — the beam rows are one
+ * 32-row MFMA block, the four waves of a (sentence, head) workgroup split the keys (32-key tiles, own LDS-DMA rings, no barrier in the
+ * loop) and add their (max, sum, output) states in wave order; every other case: a VALU kernel with the same structure. */
 int cst_dec_cross_attn(const void* q, const void* kx, const void* vx, const uint8_t* key_padding_mask, void* out,
                        const int32_t* step, int64_t max_len, int64_t bsz, int64_t beam, int64_t H, int64_t D, int64_t S, float scale,
                        int dtype, cst_stream stream);
