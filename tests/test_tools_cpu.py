@@ -52,3 +52,35 @@ def test_overlap_analysis_on_a_synthetic_trace(tmp_path):
             assert abs(u["hidden_ms"] - 7.0) < 1e-6 and abs(u["exposed_ms"] - 4.0) < 1e-6
             assert abs(u["tail_after_backward_ms"] - 4.0) < 1e-6
             assert abs(u["collectives"][0]["start_ms"] - 12.0) < 1e-6
+
+
+def test_kernel_stats_counts_the_updates_behind_the_first_optimizer_launch(tmp_path):
+    """tools/kernel_stats.py on a synthetic rocpd database: the launches of the model build and of the first update are left out,
+    the rest is divided by the updates actually inside the window; without an optimizer marker the totals are divided as given."""
+    import sqlite3
+    import subprocess
+    import sys
+    db = str(tmp_path / "r.db")
+    c = sqlite3.connect(db)
+    c.execute("create table kernels (name text, start integer, end integer)")
+    c.execute("create table top_kernels (name text, total_calls integer, total_duration real)")
+    t = 0
+    rows = []
+    for _ in range(1000):  # the model build: parameter uploads
+        rows.append(("__amd_rocclr_copyBuffer", t, t + 5000)); t += 6000
+    for u in range(4):     # four updates: 3 GEMMs of 100 us, one copy, the optimizer
+        for _ in range(3):
+            rows.append(("gemm8p_kernel", t, t + 100000)); t += 101000
+        rows.append(("__amd_rocclr_copyBuffer", t, t + 5000)); t += 6000
+        rows.append(("adam_kernel", t, t + 800000)); t += 801000
+    c.executemany("insert into kernels values (?,?,?)", rows)
+    c.commit()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_stats.py"), db, "4"], capture_output=True, text=True, check=True).stdout
+    assert "15 kernels launched over 3 updates = 5 launches per update" in out
+    line = [l for l in out.splitlines() if "copyBuffer" in l][0].split()
+    assert float(line[0]) == 1.0 and abs(float(line[2]) - 5.0) < 1e-6   # one copy of 5 us per update, not 251
+    c.execute("delete from kernels where name = 'adam_kernel'")
+    c.execute("insert into top_kernels values ('gemm8p_kernel', 12, 1200.0)")
+    c.commit()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_stats.py"), db, "4"], capture_output=True, text=True, check=True).stdout
+    assert "12 kernels launched over 4 updates = 3 launches per update" in out
