@@ -759,10 +759,17 @@ extern "C" int cst_attn_fwd(const cst_attn_desc* d, cst_stream stream) {
   return cst_check_launch("cst_attn_fwd");
 }
 
-// (internal, cst_common.h) the matrix-core kernel behind cst_dec_cross_attn for bf16 / head dim 64 / beam <= 32 (attention_fast.inc)
+// (internal, cst_common.h) the matrix-core kernel behind cst_dec_cross_attn / cst_dec_ln_q_cross_attn for bf16 / head dim 64 / beam <= 32
+// (attention_fast.inc).  Wg != NULL: q is the residual stream x [bsz * beam, K] (row stride ldx) and the LayerNorm-folded query
+// projection (Wg [H * 64, K], sg, sb, eps: cst_dec_ln_linear's operands) runs inside the kernel.
 int cst_fa_dec_cross(const void* q, const void* kx, const void* vx, const uint8_t* kpm, void* out, const int32_t* step, int64_t max_len,
-                     int64_t bsz, int64_t beam, int64_t H, int64_t S, float scale, hipStream_t s) {
-  return fa_dec_cross_launch(q, kx, vx, kpm, out, step, max_len, bsz, beam, H, S, scale, s);
+                     int64_t bsz, int64_t beam, int64_t H, int64_t S, float scale, const void* Wg, const float* sg, const float* sb, float eps,
+                     int64_t K, int64_t ldx, hipStream_t s) {
+  if (Wg) {
+    FdProj pj = {(const bf16_t*)Wg, sg, sb, eps, (int)K, (long long)ldx};
+    return fa_dec_cross_launch(q, kx, vx, kpm, out, step, max_len, bsz, beam, H, S, scale, &pj, s);
+  }
+  return fa_dec_cross_launch(q, kx, vx, kpm, out, step, max_len, bsz, beam, H, S, scale, nullptr, s);
 }
 
 extern "C" int64_t cst_attn_bwd_workspace(const cst_attn_desc* d) {

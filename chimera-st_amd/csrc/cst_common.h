@@ -19,9 +19,11 @@ struct CstProfScope {
   void tag(const char* fmt, ...);  // free-form description of this launch (shape, kernel family) for cst_prof_dump; no-op when off
 };
 int cst_check_launch(const char* what);
-// attention.hip: the matrix-core kernel of cst_dec_cross_attn (bf16, head dim 64, beam <= 32; K / V head-major [bsz][H][S][64])
+// attention.hip: the matrix-core kernel of cst_dec_cross_attn / cst_dec_ln_q_cross_attn (bf16, head dim 64, beam <= 32; K / V head-major
+// [bsz][H][S][64]); Wg != NULL: q is the residual stream and the LayerNorm-folded query projection runs inside the kernel
 int cst_fa_dec_cross(const void* q, const void* kx, const void* vx, const uint8_t* kpm, void* out, const int32_t* step, int64_t max_len,
-                     int64_t bsz, int64_t beam, int64_t H, int64_t S, float scale, hipStream_t s);
+                     int64_t bsz, int64_t beam, int64_t H, int64_t S, float scale, const void* Wg, const float* sg, const float* sb, float eps,
+                     int64_t K, int64_t ldx, hipStream_t s);
 bool cst_prof_is_on();  // the hipEvent profiling table of bench.py's roofline step is recording
 
 #define CST_REQUIRE(cond, ...)                         \

@@ -1075,7 +1075,7 @@ int cst_dec_cross_attn(const void* q, const void* kx, const void* vx, const uint
   if (!valu_only && dtype == CST_BF16 && D == 64 && beam <= 32 && S * 128 < (1ll << 31) && ((uintptr_t)q % 16 == 0) && ((uintptr_t)kx % 16 == 0) &&
       ((uintptr_t)vx % 16 == 0) && ((uintptr_t)out % 16 == 0)) {
     CstProfScope prof(CST_K_ATTN_FWD, s, 4.0 * bsz * beam * H * D * S, 2.0 * bsz * S * H * D * cst_dtype_size(dtype));
-    const int rc = cst_fa_dec_cross(q, kx, vx, key_padding_mask, out, step, max_len, bsz, beam, H, S, scale, s);
+    const int rc = cst_fa_dec_cross(q, kx, vx, key_padding_mask, out, step, max_len, bsz, beam, H, S, scale, nullptr, nullptr, nullptr, 0.0f, 0, 0, s);
     return rc != CST_OK ? rc : cst_check_launch("cst_dec_cross_attn");
   }
   const int BQ = beam == 1 ? 1 : (beam <= 5 ? 5 : 8);
@@ -1099,6 +1099,22 @@ int cst_dec_cross_attn(const void* q, const void* kx, const void* vx, const uint
 #undef CST_DCA
 #undef CST_DCA_W
   return cst_check_launch("cst_dec_cross_attn");
+}
+
+int cst_dec_ln_q_cross_attn(const void* x, int64_t ldx, const void* Wg, const float* sg, const float* sb, float eps, const void* kx, const void* vx,
+                            const uint8_t* key_padding_mask, void* out, const int32_t* step, int64_t max_len, int64_t bsz, int64_t beam, int64_t H,
+                            int64_t D, int64_t S, float scale, int dtype, cst_stream stream) {
+  CST_REQUIRE(x && Wg && sg && sb && kx && vx && out && step, "cst_dec_ln_q_cross_attn: null operand");
+  CST_REQUIRE(dtype == CST_BF16 && D == 64 && beam > 0 && beam <= 32, "cst_dec_ln_q_cross_attn: bf16, head dim 64, beam <= 32 (the unfused pair covers the rest)");
+  CST_REQUIRE(bsz > 0 && H > 0 && S > 0 && S * 128 < (1ll << 31), "cst_dec_ln_q_cross_attn: bad shape");
+  const int64_t K = H * D;  // the query projection is square: embed_dim -> H * D
+  CST_REQUIRE(K % 256 == 0 && ldx % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)Wg % 16) == 0 && ((uintptr_t)sg % 16) == 0 && ((uintptr_t)sb % 16) == 0 &&
+                  ((uintptr_t)kx % 16) == 0 && ((uintptr_t)vx % 16) == 0 && ((uintptr_t)out % 16) == 0,
+              "cst_dec_ln_q_cross_attn: embed dim %% 256 == 0 and 16-byte aligned operands required");
+  hipStream_t s = (hipStream_t)stream;
+  CstProfScope prof(CST_K_ATTN_FWD, s, 4.0 * bsz * beam * H * D * S + 2.0 * bsz * beam * K * K, 2.0 * bsz * S * H * D * 2 + 2.0 * K * K);
+  const int rc = cst_fa_dec_cross(x, kx, vx, key_padding_mask, out, step, max_len, bsz, beam, H, S, scale, Wg, sg, sb, eps, K, ldx, s);
+  return rc != CST_OK ? rc : cst_check_launch("cst_dec_ln_q_cross_attn");
 }
 
 }  // extern "C"

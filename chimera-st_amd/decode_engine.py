@@ -96,6 +96,7 @@ class BeamDecodeEngine:
             if fuse:  # LayerNorm folded into the projection that follows it (include/cst.h: cst_dec_ln_linear)
                 d["ln_qkv"] = self._fold_ln(l.self_attn_layer_norm, d["wqkv"], d["bqkv"])
                 d["ln_q"] = self._fold_ln(l.encoder_attn_layer_norm, l.encoder_attn.q_proj.weight, l.encoder_attn.q_proj.bias)
+                d["ln_q_frag"] = self.fragment_major(d["ln_q"][0], l.encoder_attn.num_heads)  # cst_dec_ln_q_cross_attn's weight layout
                 d["ln_fc1"] = self._fold_ln(l.final_layer_norm, l.fc1.weight, l.fc1.bias)
             layers.append(d)
         pos = self.dec.embed_positions
@@ -113,6 +114,9 @@ class BeamDecodeEngine:
         LayerNorm + vocabulary projection + the two beam-search kernels; + the split-K reduce of fc2 where it is split (bf16, <= 256
         hypothesis rows, ffn >= 4096)."""
         per_layer = 8 if self._fuse_ln(dtype) else 11
+        D = self.dec.layers[0].self_attn.head_dim
+        if self._fuse_ln(dtype) and self._fuse_q_cross(dtype, D, self.dec.embed_dim, self._cross_mode(dtype, D)):
+            per_layer -= 1  # the query projection runs inside the cross-attention launch
         F = self.dec.layers[0].fc1.out_features
         if rows is not None and rows <= 256 and F >= 4096 and dtype == torch.bfloat16 and not os.environ.get("CST_DEC_NO_SPLITK"):
             per_layer += 1
@@ -132,6 +136,14 @@ class BeamDecodeEngine:
         if b is not None:
             sb = (sb + b.detach().float()).contiguous()
         return wg, sg, sb, float(ln.eps)
+
+    @staticmethod
+    def fragment_major(wg, H):
+        """[H*64, K] -> the fragment-major packing of include/cst.h (cst_dec_ln_q_cross_attn): [H][2][K/16][2][32][8]."""
+        N, K = wg.shape
+        if N != H * 64 or K % 16:
+            return None
+        return wg.view(H, 2, 32, K // 16, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous()
 
     def _ln_linear(self, x, folded, out, act=L.ACT_NONE):
         wg, sg, sb, eps = folded
@@ -205,6 +217,11 @@ class BeamDecodeEngine:
             return self.cross_kernel
         return "shared" if (dtype == torch.bfloat16 and D == 64 and self.beam <= 32) else "flash"
 
+    def _fuse_q_cross(self, dtype, D, C, ck):
+        """The LayerNorm-folded query projection inside the cross-attention launch (cst_dec_ln_q_cross_attn): one node less per layer."""
+        return (ck == "shared" and dtype == torch.bfloat16 and D == 64 and self.beam <= 32 and C % 256 == 0
+                and not os.environ.get("CST_DEC_NO_QCROSS"))
+
     def _cross_fits(self, dtype, D):
         """True: the encoder K/V of this engine are stored head-major [bsz, H, S, D]."""
         return self._cross_mode(dtype, D) in ("shared", "flash_hm")
@@ -239,15 +256,23 @@ class BeamDecodeEngine:
                                           L.stream_ptr()), "cst_dec_self_attn")
             self._linear(st["attn"], sa.out_proj.weight, sa.out_proj.bias, x2, resid=x)
             x, x2 = x2, x
-            if fused:
+            S = st["kx"][li].shape[1]
+            ck = self._cross_mode(st["x"].dtype, D)
+            qfused = fused and p.get("ln_q_frag") is not None and self._fuse_q_cross(st["x"].dtype, D, C, ck)
+            if qfused:
+                pass  # the query projection runs inside the cross-attention launch below
+            elif fused:
                 self._ln_linear(x, p["ln_q"], st["q"])
             else:
                 self._ln(x, layer.encoder_attn_layer_norm, st["h"], st)
                 self._linear(st["h"], ca.q_proj.weight, ca.q_proj.bias, st["q"])
             # cross attention: one workgroup per (sentence, head); the sentence's K/V rows serve all of its beam rows
-            S = st["kx"][li].shape[1]
-            ck = self._cross_mode(st["x"].dtype, D)
-            if ck == "flash_hm":  # the flash kernel over head-major K/V: (b, h, t) strides = (H*S*D, S*D, D)
+            if qfused:
+                _, sg, sb, eps = p["ln_q"]
+                L.check(lib.cst_dec_ln_q_cross_attn(L.ptr(x), x.stride(0), L.ptr(p["ln_q_frag"]), L.ptr(sg), L.ptr(sb), eps, L.ptr(st["kx"][li]),
+                                                    L.ptr(st["vx"][li]), L.ptr(st["kpm"]), L.ptr(st["attn"]), L.ptr(st["step"]), self.max_len,
+                                                    bsz, self.beam, H, D, S, float(ca.scaling), dt, L.stream_ptr()), "cst_dec_ln_q_cross_attn")
+            elif ck == "flash_hm":  # the flash kernel over head-major K/V: (b, h, t) strides = (H*S*D, S*D, D)
                 q3, o3 = st["q"].view(bsz, self.beam, C), st["attn"].view(bsz, self.beam, C)
                 d = K.attn_desc(q3, st["kx"][li], st["vx"][li], o3, st["lse"], H, D, st["kpm"], False, float(ca.scaling))
                 d.k_sb = d.v_sb = H * S * D

@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcst_hip.so")
-ABI_VERSION = 5  # include/cst.h: CST_ABI_VERSION
+ABI_VERSION = 6  # include/cst.h: CST_ABI_VERSION
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
@@ -160,6 +160,7 @@ SYMBOLS = [
     ("cst_wav_info", c_int, [ctypes.c_char_p, c_p, c_p, c_p, c_p]),
     ("cst_wav_read_f32", c_i64, [ctypes.c_char_p, c_i64, c_i64, c_p, c_i64]),
     ("cst_dec_cross_attn", c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f, c_int, c_p]),
+    ("cst_dec_ln_q_cross_attn", c_int, [c_p, c_i64, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f, c_int, c_p]),
 ]
 
 _lib = None

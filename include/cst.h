@@ -29,9 +29,10 @@ extern "C" {
 #endif
 
 /* Bumps on any change of a signature or a descriptor layout (3: cst_gemm_desc.m_len, cst_attn_desc.seq_offsets, workspaces of the
- * fixed-order reductions; 4: cst_attn_desc.kpm_bits / bwd_ws, the separable attention-dropout mask; 5: cst_gemm_desc.colsum).
+ * fixed-order reductions; 4: cst_attn_desc.kpm_bits / bwd_ws, the separable attention-dropout mask; 5: cst_gemm_desc.colsum;
+ * 6: cst_dec_ln_q_cross_attn).
  * cst_version() returns the value the library was built with; chimera-st_amd/lib.py refuses a mismatch. */
-#define CST_ABI_VERSION 5
+#define CST_ABI_VERSION 6
 
 typedef enum { CST_F32 = 0, CST_BF16 = 1 } cst_dtype;
 
@@ -531,6 +532,17 @@ int cst_dec_self_attn(const void* qkv, void* kcache, void* vcache, const int32_t
 int cst_dec_cross_attn(const void* q, const void* kx, const void* vx, const uint8_t* key_padding_mask, void* out,
                        const int32_t* step, int64_t max_len, int64_t bsz, int64_t beam, int64_t H, int64_t D, int64_t S, float scale,
                        int dtype, cst_stream stream);
+/* The query projection of that attention and the attention itself as ONE launch (modules/transformer_layer.py:369-372 with
+ * normalize_before + multihead_attention.py:189-207): x [bsz*beam, H*D] (row stride ldx) is the decoder's residual stream in front of
+ * encoder_attn_layer_norm; Wg / sg / sb / eps are cst_dec_ln_linear's folded operands of q_proj (fp32 [H*D] vectors; Wg = bf16(W gamma),
+ * [H*D, K = H*D]) with Wg stored FRAGMENT-MAJOR — element (n, k) at  ((((n / 64) * 2 + n % 64 / 32) * (K / 16) + k / 16) * 64 +
+ * 32 * (k / 8 % 2) + n % 32) * 8 + k % 8  — so that a wave's load of one MFMA operand is one contiguous KiB (the weights are constants
+ * while decoding: packed once; Python: Wg.view(H, 2, 32, K/16, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous()).  The
+ * workgroup of (sentence, head) forms its own 64 query columns for the sentence's beam rows while its first K / V tiles stream in, rounds
+ * them to bf16 as the stored q of the two-launch path is, and attends as cst_dec_cross_attn does.  bf16, D = 64, beam <= 32, (H*D) % 256 == 0. */
+int cst_dec_ln_q_cross_attn(const void* x, int64_t ldx, const void* Wg, const float* sg, const float* sb, float eps, const void* kx, const void* vx,
+                            const uint8_t* key_padding_mask, void* out, const int32_t* step, int64_t max_len, int64_t bsz, int64_t beam, int64_t H,
+                            int64_t D, int64_t S, float scale, int dtype, cst_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Host-side (CPU) natives of the input pipeline — no device work, no stream.

@@ -274,6 +274,66 @@ def test_dec_cross_attn(KL, dtype, H, D, beam, S):
             assert float((out.float() - ref).abs().max()) < tol * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("H,beam,S", [(16, 5, 750), (8, 1, 40), (8, 32, 97), (16, 3, 33)])
+def test_dec_ln_q_cross_attn(KL, H, beam, S):
+    """LayerNorm + query projection + cross attention of one decode step as ONE launch (cst_dec_ln_q_cross_attn) against plain fp32
+    torch — LayerNorm, Linear, softmax attention over the sentence's keys with ragged key padding — and against the two-launch path
+    it replaces (cst_dec_ln_linear, then cst_dec_cross_attn), whose stored bf16 q it reproduces up to the summation order over K."""
+    k, L = KL
+    lib = L.load()
+    eng = import_module("chimera-st_amd.decode_engine").BeamDecodeEngine
+    dt, D, bsz = torch.bfloat16, 64, 3
+    C = H * D
+    g = torch.Generator().manual_seed(H * 100 + S)
+    x = (torch.randn(bsz * beam, C, generator=g) * 1.5 + 0.3).to(dt).cuda()
+    ln = torch.nn.LayerNorm(C).cuda()
+    lin = torch.nn.Linear(C, C).cuda()
+    with torch.no_grad():
+        ln.weight.copy_(1.0 + 0.2 * torch.randn(C, generator=g))
+        ln.bias.copy_(0.1 * torch.randn(C, generator=g))
+        lin.weight.copy_(torch.randn(C, C, generator=g) / C ** 0.5)
+        lin.bias.copy_(0.1 * torch.randn(C, generator=g))
+    ln, lin = ln.to(dt), lin.to(dt)
+    wg, sg, sb, eps = eng._fold_ln(ln, lin.weight, lin.bias)
+    wfrag = eng.fragment_major(wg, H)  # the fused launch's weight layout (include/cst.h)
+    kx = torch.randn(bsz, S, C, generator=g).to(dt).cuda()
+    vx = torch.randn(bsz, S, C, generator=g).to(dt).cuda()
+    kxh = kx.view(bsz, S, H, D).transpose(1, 2).contiguous()
+    vxh = vx.view(bsz, S, H, D).transpose(1, 2).contiguous()
+    lens = torch.tensor([S, max(1, S // 2), max(1, S // 3 + 1)])
+    kpm = (torch.arange(S)[None, :] >= lens[:, None]).to(torch.uint8).cuda()
+    scale = D ** -0.5
+    step = torch.tensor([3], dtype=torch.int32, device="cuda")
+    for mask in (kpm, None):
+        out = torch.zeros(bsz * beam, C, dtype=dt, device="cuda")
+        L.check(lib.cst_dec_ln_q_cross_attn(L.ptr(x), C, L.ptr(wfrag), L.ptr(sg), L.ptr(sb), eps, L.ptr(kxh), L.ptr(vxh), L.ptr(mask), L.ptr(out),
+                                            L.ptr(step), 20, bsz, beam, H, D, S, scale, L.dtype_code(dt), L.stream_ptr()), "cst_dec_ln_q_cross_attn")
+        # the two-launch path
+        q2 = torch.empty(bsz * beam, C, dtype=dt, device="cuda")
+        out2 = torch.zeros_like(out)
+        L.check(lib.cst_dec_ln_linear(L.ptr(x), L.ptr(wg), L.ptr(sg), L.ptr(sb), eps, None, L.ptr(q2), bsz * beam, C, C, C, 0, C, L.ACT_NONE, None, 0,
+                                      L.dtype_code(dt), L.stream_ptr()), "cst_dec_ln_linear")
+        L.check(lib.cst_dec_cross_attn(L.ptr(q2), L.ptr(kxh), L.ptr(vxh), L.ptr(mask), L.ptr(out2), L.ptr(step), 20, bsz, beam, H, D, S, scale,
+                                       L.dtype_code(dt), L.stream_ptr()), "cst_dec_cross_attn")
+        # fp32 torch on the same bf16 parameters
+        qf = torch.nn.functional.linear(torch.nn.functional.layer_norm(x.float(), (C,), ln.weight.float(), ln.bias.float(), ln.eps),
+                                        lin.weight.float(), lin.bias.float()).view(bsz, beam, H, D)
+        sc = torch.einsum("bqhd,bjhd->bhqj", qf, kx.float().view(bsz, S, H, D)) * scale
+        if mask is not None:
+            sc = sc.masked_fill(mask.bool()[:, None, None, :], float("-inf"))
+        ref = torch.einsum("bhqj,bjhd->bqhd", torch.softmax(sc, -1), vx.float().view(bsz, S, H, D)).reshape(bsz * beam, C)
+        top = max(1.0, float(ref.abs().max()))
+        assert float((out.float() - ref).abs().max()) < 3e-2 * top
+        assert float((out2.float() - ref).abs().max()) < 3e-2 * top
+        assert float((out.float() - out2.float()).abs().max()) < 2e-2 * top   # same roundings of q; only the K summation order differs
+    # past max_len: a no-op
+    out.zero_()
+    late = torch.tensor([99], dtype=torch.int32, device="cuda")
+    L.check(lib.cst_dec_ln_q_cross_attn(L.ptr(x), C, L.ptr(wfrag), L.ptr(sg), L.ptr(sb), eps, L.ptr(kxh), L.ptr(vxh), None, L.ptr(out), L.ptr(late), 20,
+                                        bsz, beam, H, D, S, scale, L.dtype_code(dt), L.stream_ptr()), "cst_dec_ln_q_cross_attn")
+    assert float(out.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("beam", [1, 5])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_engine_matches_reference_generator(beam, use_graph):
