@@ -82,6 +82,59 @@ def make_batch(tasks, task, args, rank, device):
     return tasks.synthetic_sample(task.target_dictionary, args.batch, audio, tgt, src, seed=1 + rank, device=device)
 
 
+def algorithmic_tflop(sample, ns, chimera, conv_spec):
+    """ALGORITHMIC FLOPs of one update on `sample`, by SURVEY section 8(d)'s formulas (FLOP = 2 MAC, training = 3 x forward), from the
+    batch's own lengths: padding, skipped tiles and tile rounding earn nothing.  Split by the launch class that executes them:
+    `gemm` (conv layers 1-6, every Linear, pos-conv, subsampler, vocabulary projection), `attention` (QK^T + PV), `conv0`.
+    Chimera's memory layers are priced at the MINIMAL variant of 8(d) (M query rows), its text pass included."""
+    C, F, H = ns.encoder_embed_dim, ns.encoder_ffn_embed_dim, 768
+    V = 10000
+    N = ns.encoder_layers
+    ND = ns.decoder_layers
+    M = int(getattr(ns, "interlingua_length", 0) or 0)
+    NM = int(getattr(ns, "interlingua_layers", 0) or 0) if chimera else 0
+    lin = lambda rows, d, f: rows * (4 * d * d + 2 * d * f)
+    gemm = attn = conv0 = 0
+
+    def tail(T2, U):  # everything behind the (audio or text) front end: encoder layers, memory, decoder, vocabulary
+        g = lin(T2, C, F) * N
+        a = N * 2 * T2 * T2 * C
+        K = T2
+        if NM:
+            g += NM * (M * (2 * C * C + 2 * C * F) + (T2 + M) * 2 * C * C)
+            a += NM * 2 * M * (T2 + M) * C
+            K = M
+        g += ND * (U * (6 * C * C + 2 * C * F) + K * 2 * C * C) + U * C * V
+        a += ND * (2 * U * U * C + 2 * U * K * C)
+        return g, a
+
+    S_all = sample["net_input"]["src_lengths"].tolist()
+    U_all = sample["target_lengths"].tolist()
+    for S, U in zip(S_all, U_all):
+        L, cin = S, 1
+        for i, (c, k, st) in enumerate(conv_spec):
+            L = (L - k) // st + 1
+            if i == 0:
+                conv0 += cin * c * k * L
+            else:
+                gemm += cin * c * k * L
+            cin = c
+        T1 = L
+        gemm += T1 * cin * H + T1 * H * (H // 16) * 128 + 12 * lin(T1, H, 4 * H)
+        attn += 12 * 2 * T1 * T1 * H
+        Ts = (T1 - 1) // 2 + 1
+        T2 = (Ts - 1) // 2 + 1
+        gemm += H * 1024 * 5 * Ts + C * 1024 * 5 * T2
+        g, a = tail(T2, U)
+        gemm, attn = gemm + g, attn + a
+    if chimera and "src_text_lengths" in sample:
+        for Ls, U in zip(sample["src_text_lengths"].tolist(), U_all):
+            g, a = tail(Ls, U)
+            gemm, attn = gemm + g, attn + a
+    k = 6.0 / 1e12
+    return {"gemm": gemm * k, "attention": attn * k, "conv0": conv0 * k, "total": (gemm + attn + conv0) * k}
+
+
 def dominant_gemm_launch(args, device):
     """The single most expensive GEMM launch of the step — wav2vec2 fc1 forward, [B*T1, 768] x [3072, 768]^T with the
     bias + GELU + pre-activation epilogue (12 launches per update) — timed alone with HIP events on the launch stream, with
@@ -114,7 +167,7 @@ def dominant_gemm_launch(args, device):
     out = {"kernel": "gemm8p_kernel<k-major, k-major>", "shape": [M, F, D], "epilogue": "bias+gelu+aux_out", "avg_launch_ms": ms,
            "achieved": flops / ms / 1e9, "unit": "TFLOP/s", "frac": flops / ms / 1e9 / PEAK["bf16"],
            "algorithmic_bytes": 2.0 * (M * D + F * D + 2 * M * F), "traffic": None}
-    pmc = next((f for f in (os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", n) for n in ("r04_pmc_gemm.json", "r03_pmc_gemm.json", "r02_pmc_gemm.json", "r01_pmc_gemm.json"))
+    pmc = next((f for f in (os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", n) for n in ("r06_pmc_gemm.json", "r05_pmc_gemm.json", "r04_pmc_gemm.json", "r03_pmc_gemm.json", "r02_pmc_gemm.json", "r01_pmc_gemm.json"))
                 if os.path.exists(f)), None)
     if pmc is not None:
         rec = json.load(open(pmc))
@@ -221,19 +274,33 @@ def measure_train(args, device, rank, lib, traffic=True):
         dom = max(table.items(), key=lambda kv: kv[1]["ms"])
         name, r = dom
         if r["flops"] > 0:
-            ach = r["flops"] / (r["ms"] * 1e-3) / 1e12
+            # `achieved` / `frac` are by ALGORITHMIC FLOPs (the batch's own lengths through the survey's formulas; tile
+            # padding and whatever the kernels execute beyond that earn nothing); the executed-FLOP figure (what the launches' descriptors
+            # add up to, tile rounding included) stays beside it as `*_executed`.
+            wa = importlib.import_module("chimera-st_amd.w2v2_transformer").SYNTHETIC_W2V["wav2vec_small_bench"]
+            alg = algorithmic_tflop(sample, ns, args.model == "chimera", eval(wa.conv_feature_layers))
+            ach_x = r["flops"] / (r["ms"] * 1e-3) / 1e12
+            ach = alg[name] / (r["ms"] * 1e-3) if name in alg else ach_x
             roof = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK[args.dtype], "unit": "TFLOP/s",
-                    "frac": ach / PEAK[args.dtype], "traffic": None, "launches": r["launches"],
-                    "avg_launch_ms": r["ms"] / max(r["launches"], 1)}
+                    "frac": ach / PEAK[args.dtype], "frac_algorithmic": ach / PEAK[args.dtype], "achieved_executed": ach_x,
+                    "frac_executed": ach_x / PEAK[args.dtype], "traffic": None, "launches": r["launches"],
+                    "avg_launch_ms": r["ms"] / max(r["launches"], 1),
+                    "algorithmic_tflop_per_update": {k: round(v, 4) for k, v in alg.items()},
+                    "step_mfu_algorithmic": alg["total"] / (dt / args.steps) / PEAK[args.dtype]}
         else:
             ach = r["bytes"] / (r["ms"] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                     "traffic": None, "launches": r["launches"], "avg_launch_ms": r["ms"] / max(r["launches"], 1)}
         roof["per_class_ms"] = {k: round(v["ms"], 3) for k, v in table.items() if v["launches"]}
+        if r["flops"] > 0:
+            a_ms = table["attn_fwd"]["ms"] + table["attn_bwd"]["ms"]
+            # QK^T + PV of every attention of the update (forward + 2x backward, algorithmic) over the attention kernels' time
+            roof["attention"] = {"ms": round(a_ms, 3), "algorithmic_tflop": round(alg["attention"], 4),
+                                 "achieved": alg["attention"] / (a_ms * 1e-3), "frac": alg["attention"] / (a_ms * 1e-3) / PEAK[args.dtype]}
         roof["algorithmic_bytes"] = r["bytes"] / max(r["launches"], 1)
         # HBM-side traffic of the same launches from the committed PMC pass of this command (counters need their own rocprofv3
         # run and cannot be read inside the timed process); only quoted for the workload it was collected on
-        pmc = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_gemm_class.json", "r04_pmc_gemm_class.json", "r03_pmc_gemm_class.json", "r02_pmc_gemm_class.json", "r01f_pmc_gemm_class.json")) if os.path.exists(f)), None)
+        pmc = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r06_pmc_gemm_class.json", "r05_pmc_gemm_class.json", "r04_pmc_gemm_class.json", "r03_pmc_gemm_class.json", "r02_pmc_gemm_class.json", "r01f_pmc_gemm_class.json")) if os.path.exists(f)), None)
         if traffic and name == "gemm" and pmc and args.model == "s2t_w2v2" and args.batch == 32 and args.seconds == 30.0 and args.dtype == "bf16":
             rec = json.load(open(pmc))
             if abs(rec["gemm_class_launches_per_update"] - r["launches"]) <= 16:
@@ -247,52 +314,51 @@ def measure_train(args, device, rank, lib, traffic=True):
     return trainer, task, tasks, ns, sample, dt, out, roof
 
 
-def h2d_overlapped(trainer, sample, device, steps=4):
-    """Updates fed from PINNED HOST batches: batch i + 1 crosses PCIe on a copy stream while update i runs (double buffer), the compute
-    stream waits only for the event of its own batch.  Returns utterances/s with the transfer inside the clock (SURVEY section 8d
-    defines the metric with H2D; the bench contract's `value` starts with the batch resident, so this is reported beside it)."""
-    def pin(x):
+def h2d_overlapped(trainer, sample, device, steps=12):
+    """Updates fed from PINNED HOST batches: batch i + 1 crosses PCIe on a copy stream while update i runs.  Two RESIDENT device
+    batches are allocated once and refilled in place (`copy_`, non-blocking): nothing is allocated on the copy stream inside the
+    loop, the compute stream waits only for the event of its own batch, and the copy into a buffer waits for the update that last
+    read it.  Returns utterances/s with the transfer inside the clock (SURVEY section 8d defines the metric with H2D; the bench
+    contract's `value` starts with the batch resident, so this is reported beside it)."""
+    def walk(x, fn):
         if torch.is_tensor(x):
-            return x.detach().cpu().pin_memory()
+            return fn(x)
         if isinstance(x, dict):
-            return {k: pin(v) for k, v in x.items()}
+            return {k: walk(v, fn) for k, v in x.items()}
         return x
 
-    def put(x):
-        if torch.is_tensor(x):
-            return x.to(device, non_blocking=True)
-        if isinstance(x, dict):
-            return {k: put(v) for k, v in x.items()}
-        return x
+    def refill(dst, src):
+        if torch.is_tensor(dst):
+            dst.copy_(src, non_blocking=True)
+        elif isinstance(dst, dict):
+            for k in dst:
+                refill(dst[k], src[k])
 
-    host = [pin(sample), pin(sample)]
+    host = [walk(sample, lambda t: t.detach().cpu().pin_memory()) for _ in range(2)]
+    dev = [walk(sample, lambda t: torch.empty_like(t)) for _ in range(2)]  # on the current (main) stream, before the loop
     copy, main = torch.cuda.Stream(), torch.cuda.current_stream()
-    evs = [torch.cuda.Event(), torch.cuda.Event()]
-
-    def hand_over(x):  # allocated on the copy stream, consumed on the main one: the allocator must not recycle it under an update in flight
-        if torch.is_tensor(x):
-            x.record_stream(main)
-        elif isinstance(x, dict):
-            for v in x.values():
-                hand_over(v)
+    filled = [torch.cuda.Event(), torch.cuda.Event()]   # copy stream: batch landed in dev[j]
+    freed = [torch.cuda.Event(), torch.cuda.Event()]    # main stream: the update that read dev[j] is enqueued behind this point
 
     def stage(i):
+        j = i % 2
         with torch.cuda.stream(copy):
-            dev = put(host[i % 2])
-            evs[i % 2].record(copy)
-        hand_over(dev)
-        return dev
+            if i >= 2:
+                copy.wait_event(freed[j])
+            refill(dev[j], host[j])
+            filled[j].record(copy)
 
     nutt = sample["target"].size(0)
-    nxt = stage(0)
+    torch.cuda.synchronize()
+    stage(0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        main.wait_event(evs[i % 2])
-        cur = nxt
         if i + 1 < steps:
-            nxt = stage(i + 1)
-        trainer.train_step([cur])
+            stage(i + 1)
+        main.wait_event(filled[i % 2])
+        trainer.train_step([dev[i % 2]])
+        freed[i % 2].record(main)
     torch.cuda.synchronize()
     return nutt * steps / (time.perf_counter() - t0)
 
@@ -534,9 +600,12 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": world * args.batch, "max_audio_s": args.seconds,
                        "audio_lengths": args.lengths, "lengths_per_rank": "identical on every rank (fixed work per GPU); contents differ", "target_tokens": "16-128", "vocab": 10000, "dropout": args.dropout, "w2v_layerdrop": args.layerdrop,
                        "parallelism": "dp%d" % world, "loss": float(out["loss"]),
+                       "parity": {"fp32": "1e-3 vs oracle (logits, loss terms, gradients; tests/test_fullsize_gpu.py, test_model_gpu.py)",
+                                  "bf16": "<= 1.5x storage-rounding emulation of the oracle (~1.8e-2 gradient rel-L2 on both sides); "
+                                          "the 1e-3 bar of north_star is met in fp32 storage only"},
                        "h2d": {"included_in_value": False, "note": "inputs resident in HBM when the clock starts (bench contract); one "
-                               "batch pinned host -> device measured separately; value_with_h2d = 4 updates fed from pinned host batches, "
-                               "batch i + 1 copied on a side stream under update i", "ms_per_batch": h2d[0], "bytes_per_batch": h2d[1],
+                               "batch pinned host -> device measured separately; value_with_h2d = 12 updates fed from pinned host batches, "
+                               "batch i + 1 copied on a side stream under update i into one of two resident device batches", "ms_per_batch": h2d[0], "bytes_per_batch": h2d[1],
                                "value_with_h2d": h2d_rate}},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -69,6 +69,10 @@ def validate(trainer, task, args, subset, rank, world):
 
 
 def train_main(argv=None):
+    # Self-launch (below) is the SCRIPT entry's behaviour (fairseq_train.py's __main__ calls train_main() with no argument list); a
+    # programmatic caller that passes argv wants the Trainer back from THIS process and gets ranks only by asking for them
+    # (--distributed-world-size N > 1).
+    from_script = argv is None
     argv = list(sys.argv[1:] if argv is None else argv)
     extra, rest = _extra_train_flags(argv)
     args = registry.parse_args_and_arch(rest)
@@ -81,7 +85,7 @@ def train_main(argv=None):
     # process has not touched the GPU yet (device_count() does not initialise it) and becomes the launcher of the rank processes.
     if "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         ndev = torch.cuda.device_count()
-        want = args.distributed_world_size if args.distributed_world_size is not None else max(ndev, 1)
+        want = args.distributed_world_size if args.distributed_world_size is not None else (max(ndev, 1) if from_script else 1)
         nproc = want if os.environ.get("CST_DIST_BACKEND") else min(max(ndev, 1), want)  # (gloo: ranks may share a GPU — tests)
         if needs_self_launch(nproc):
             entry = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fairseq_train.py")
@@ -117,11 +121,16 @@ def train_main(argv=None):
     epoch = start_epoch
 
     def save(tag_files, epoch_, it_in_epoch, val):
-        if args.no_save or rank != 0:
+        # `args.no_save` is the same on every rank, so this return is rank-agreed.  With --zero-sharding os the optimizer's moments
+        # live in every rank's shards and Trainer.save_checkpoint assembles them with an all-gather: EVERY rank must enter it (only
+        # rank 0 writes, trainer.py save_checkpoint); the file copies stay rank 0's.
+        if args.no_save or (rank != 0 and not trainer.zero):
             return
         extra_ = {"train_iterator": {"epoch": epoch_, "iterations_in_epoch": it_in_epoch}, "val_loss": val, "best": best}
         first = os.path.join(args.save_dir, tag_files[0])
         trainer.save_checkpoint(first, extra_)
+        if rank != 0:
+            return
         for f in tag_files[1:]:
             import shutil
             shutil.copyfile(first, os.path.join(args.save_dir, f))

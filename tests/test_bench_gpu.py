@@ -36,6 +36,11 @@ def test_bench_line_contract():
     r = d["roofline"]
     assert r["bound"] in ("mfma", "hbm") and r["peak"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "traffic" in r
     assert r["unit"] in ("TFLOP/s", "GB/s") and r["launches"] > 0 and r["avg_launch_ms"] > 0
+    if r["bound"] == "mfma":
+        # `frac` is the ALGORITHMIC figure; the executed one (tile rounding included) can only be larger
+        assert r["frac_algorithmic"] == r["frac"] and r["frac_executed"] >= r["frac"] * 0.999 and r["algorithmic_tflop_per_update"]["gemm"] > 0
+        assert 0 < r["attention"]["frac"] < 1 and 0 < r["step_mfu_algorithmic"] < 1
+    assert set(d["config"]["parity"]) == {"fp32", "bf16"}
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == "utterances/s" and c["sample"]
     assert c["reference_equivalent"]["value"] > c["value"] and "profiles/" in c["reference_equivalent"]["source"] and c["reference_equivalent"]["approximate"] is True
