@@ -146,21 +146,24 @@ class BucketedGradAllReduce:
                 self.param_bucket[idx] = b
         self.enabled = True
         # CUs the persistent GEMMs leave to the all-reduce kernels WHILE a bucket is in flight (--ddp-reserve-cus / CST_DDP_RESERVE_CUS;
-        # bucket size: --bucket-cap-mb / CST_BUCKET_CAP_MB).  Default with more than one rank: 32 = one XCD's worth, 12.5 % of the chip.
-        # The persistent GEMM grids own one workgroup per CU, so an RCCL kernel that becomes runnable under them only gets CUs at a GEMM
-        # launch boundary; its ring kernels run a few dozen workgroups (one per channel).  The reservation is taken when a bucket is
-        # launched and dropped as soon as the gradient hooks see every launched collective completed (is_completed(): an event query),
-        # so it is on for about the collectives' own duration (~0.3 ms per 64 MiB bucket at xGMI ring rates) plus the host's lead over
-        # the GPU, not for the whole backward pass: 12.5 % of the GEMM rate over a few ms per update is the bounded price.  UNMEASURED
-        # on more than one GPU (no multi-GPU hardware reached this build): the first 8-GPU session sweeps it (0 switches it off).
+        # bucket size: --bucket-cap-mb / CST_BUCKET_CAP_MB).  DEFAULT 0 (round 6; it was 32 at world > 1 in round 5): the switch is taken
+        # on the HOST when a bucket is launched and released when the host sees the collective completed, and the host runs ahead of the
+        # GPU in backward — every GEMM enqueued in that lead window would run on 224 CUs, including ones that execute before the
+        # collective has started — while no multi-GPU box has reached this build to show that the reservation pays.  Without it an RCCL
+        # kernel gets its CUs at the next GEMM launch boundary (launches are 0.1-3 ms) and the persistent GEMM's per-XCD work claims
+        # absorb the workgroups that start late behind it (gemm8p: only a workgroup's FIRST item is static).  The first 8-GPU session
+        # sweeps 0 / 16 / 32 (tools/ddp_overlap_trace.py) before any non-zero default comes back.
         env_r = os.environ.get("CST_DDP_RESERVE_CUS")
-        self.reserve_cus = int(env_r) if env_r is not None else (32 if self.world > 1 else 0)
+        self.reserve_cus = int(env_r) if env_r is not None else 0
         # CST_DDP_COLLECTIVE = allreduce (default) | rs_ag: the gradient exchange of a bucket as reduce-scatter + all-gather
         # ("rs": reduce-scatter ONLY — rank r ends up with the mean of ITS 1 / world span of every bucket; chosen by the trainer for the
         #  sharded optimizer, which updates those spans and all-gathers the PARAMETERS instead: shard_state() / all_gather_shards())
+        # "rs" is INTERNAL: without the sharded optimizer behind it the unsharded Adam would update the full buffer from gradients
+        # that are reduced on one span per rank only — the environment may not ask for it.
         self.collective = os.environ.get("CST_DDP_COLLECTIVE", "allreduce")
-        if self.collective not in ("allreduce", "rs_ag", "rs"):
-            raise ValueError("CST_DDP_COLLECTIVE must be allreduce, rs_ag or rs, not %r" % self.collective)
+        if self.collective not in ("allreduce", "rs_ag"):
+            raise ValueError("CST_DDP_COLLECTIVE must be allreduce or rs_ag, not %r (reduce-scatter-only buckets are chosen by "
+                             "--zero-sharding os, never by the environment)" % self.collective)
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self._reserved = False
         self.last_early, self.last_missing = 0, []

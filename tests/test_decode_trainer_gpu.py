@@ -29,6 +29,42 @@ def test_decode_matches_reference_generator(beam):
             assert_close(hyps[b][r]["positional_scores"], g[key + "pos_scores"], 1e-3, key + "pos_scores")
 
 
+RECIPE_SETTINGS = {  # tools/ref_harness/make_decode_recipe_goldens.py SETTINGS
+    "recipe": dict(beam_size=10, len_penalty=1.5),                                   # chimera/generate/generate-mustc-final.sh:5-8
+    "recipe_unk": dict(beam_size=10, len_penalty=1.5, unk_penalty=0.5, min_len=4),
+    "short": dict(beam_size=5, len_penalty=0.6),
+    "nonorm": dict(beam_size=4, len_penalty=1.5, normalize_scores=False),
+}
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["engine", "host_loop"])
+@pytest.mark.parametrize("name", sorted(RECIPE_SETTINGS))
+def test_final_decoding_recipe_matches_reference_generator(name, fused):
+    """`--beam 10 --lenpen 1.5` (chimera/generate/generate-mustc-final.sh:5-8) and the other branches of finalize_hypos' length
+    normalisation, the unk penalty and min_len (sequence_generator.py:321-329, :623-624), against what the REAL reference's
+    SequenceGenerator produced on the same inputs (decode_recipe_tiny.npz): every finalized hypothesis of every sentence, in the
+    reference's order — token ids exact, scores to 1e-4 — from the device-resident engine AND the host loop."""
+    g = load_golden("decode_tiny.npz")
+    r = load_golden("decode_recipe_tiny.npz")
+    model, task, args = build_from_golden(g, "chimera", torch.float32)
+    SG = import_module("chimera-st_amd.sequence_generator").SequenceGenerator
+    kw = dict(RECIPE_SETTINGS[name])
+    kw.setdefault("min_len", 1)
+    gen = SG([model], task.target_dictionary, max_len_a=0, max_len_b=int(r["meta/max_len_b"]), fused=fused, **kw)
+    for tag in ("a", "b"):
+        sample = {"net_input": {"src_tokens": torch.from_numpy(r["in/%s/src_tokens" % tag]).cuda(),
+                                "src_lengths": torch.from_numpy(r["in/%s/src_lengths" % tag]).cuda()}}
+        hyps = gen.generate([model], sample)
+        for b in range(len(hyps)):
+            n = int(r["gen/%s/%s/b%d/n" % (name, tag, b)])
+            assert len(hyps[b]) == n, (tag, b)
+            for k in range(n):
+                key = "gen/%s/%s/b%d/r%d/" % (name, tag, b, k)
+                assert hyps[b][k]["tokens"].tolist() == r[key + "tokens"].tolist(), key
+                assert abs(float(hyps[b][k]["score"]) - float(r[key + "score"])) < 1e-4, key
+                assert_close(hyps[b][k]["positional_scores"], r[key + "pos_scores"], 1e-3, key + "pos_scores")
+
+
 def test_decode_text_input_and_incremental_equals_full():
     g = load_golden("decode_tiny.npz")
     model, task, args = build_from_golden(g, "chimera", torch.float32)
