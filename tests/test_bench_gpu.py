@@ -104,6 +104,23 @@ def test_bench_launches_its_own_ranks_when_started_plainly():
     assert r.returncode == 7 and "rank 1 exited with code 7" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
+def test_bench_eight_ranks_started_plainly_share_the_gpu_over_gloo():
+    """`python3 bench.py --gpus 8` with no rank variables — the command of the first 8-GPU session — as far as a 1-GPU box can follow
+    it: the launcher starts EIGHT rank processes (LOCAL_RANK 0..7 all map to cuda:0 here, gloo stands in for RCCL), every rank runs
+    the full-size model on one 2 s utterance, the gradient buckets of 166.8 M parameters travel through the eight-rank collective,
+    rank 0 alone prints the line with n_gpus = 8.  No scaling number is read off this (eight processes time-slice one GPU)."""
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+    e["CST_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--batch", "1",
+                        "--seconds", "2"], capture_output=True, text=True, timeout=1500, env=e, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and r.stdout.strip().splitlines()[-1] == lines[0]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["parallelism"] == "dp8" and d["config"]["global_batch"] == 8 and d["scaling"] == "weak"
+    assert abs(d["value"] - 8 * 1 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6 and d["cpu_baseline"] is None and not d.get("extra")
+
+
 def test_bench_decode_line_contract():
     """--mode decode (BASELINE configs[4]) on a reduced workload: the same one-line contract, an HBM-bound roofline object."""
     e = dict(os.environ)
