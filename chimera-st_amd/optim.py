@@ -13,6 +13,7 @@ import weakref
 import torch
 
 from . import kernels as K
+from .profiling import scope
 
 ALIGN = 8  # elements: keeps every parameter view 16-byte aligned (bf16) for the GEMM loaders
 
@@ -271,9 +272,10 @@ class FusedAdam:
         gnorm: the norm of multiply * grad if the caller already has it on the HOST (the trainer reads the raw sum of squares back
         together with the logging vector); then the clip coefficient is computed there and no device scalar math is queued."""
         if gnorm is not None:
-            multiply = float(multiply)
-            coef = min(1.0, self.clip_norm / (gnorm + 1e-6)) if self.clip_norm > 0 else 1.0
-            self._scale.fill_(coef * multiply)
+            with scope("multiply-grads"):  # (trainer.py:601-606 + :613: here both are ONE scalar the Adam kernel applies on its way)
+                multiply = float(multiply)
+                coef = min(1.0, self.clip_norm / (gnorm + 1e-6)) if self.clip_norm > 0 else 1.0
+                self._scale.fill_(coef * multiply)
         else:
             gnorm = self.grad_norm(multiply)  # `multiply` may be a python float or a 1-element device tensor
             if self.clip_norm > 0:

@@ -13,6 +13,7 @@ import torch
 from . import registry
 from .dictionary import Dictionary
 from .registry import register_task
+from .profiling import scope
 
 
 def collate_tokens(values, pad_idx, eos_idx, left_pad=False, move_eos_to_beginning=False):
@@ -62,10 +63,12 @@ class FairseqTask:
             model.set_num_updates(update_num)
         if hasattr(criterion, "set_num_updates"):
             criterion.set_num_updates(update_num)
-        loss, sample_size, logging_output = criterion(model, sample)
+        with scope("forward"):
+            loss, sample_size, logging_output = criterion(model, sample)
         if ignore_grad:
             loss = loss * 0
-        optimizer.backward(loss)
+        with scope("backward"):
+            optimizer.backward(loss)
         return loss, sample_size, logging_output
 
     def valid_step(self, sample, model, criterion):

@@ -13,6 +13,7 @@ import torch.distributed as dist
 
 from .distributed import DistributedFairseqModel, all_reduce_stats
 from . import rng
+from .profiling import scope
 from .optim import ALIGN, FlatParamBuffers, FusedAdam, qkv_groups
 
 
@@ -131,6 +132,12 @@ class Trainer:
         return mv(sample)
 
     def train_step(self, samples, raise_oom=False):
+        """`_train_step` inside the "train_step-N" range of the reference (fairseq_cli/train.py:225-227; N = updates done so far).
+        Phase ranges are roctx markers, off unless CST_ROCTX=1 (profiling.py)."""
+        with scope("train_step-%d" % self.num_updates):
+            return self._train_step(samples, raise_oom)
+
+    def _train_step(self, samples, raise_oom=False):
         """One update over a list of micro-batches.  Returns the summed logging output (device scalars converted to floats in the
         step's single host read), or None when the update was skipped because a rank ran out of memory (trainer.py:524-544, 564-570).
 
@@ -173,10 +180,11 @@ class Trainer:
                 log, ss = {k: v * 0 for k, v in log.items()}, 0
             logs.append(log)
             sample_size += ss
-        if self.ddp:
-            self.model.all_reduce()  # waits for the overlapped bucket reductions; launches the stragglers
-        else:
-            self.buffers.gather_grads()  # one multi-tensor copy of every autograd-owned gradient into the flat buffer
+        with scope("reduce-grads"):
+            if self.ddp:
+                self.model.all_reduce()  # waits for the overlapped bucket reductions; launches the stragglers
+            else:
+                self.buffers.gather_grads()  # one multi-tensor copy of every autograd-owned gradient into the flat buffer
         # logging scalars + sample_size + OOM flag + late-gradient count + one gradient-norm slot per rank: ONE fp64 device vector,
         # one small all-reduce, one host read
         if self._log_keys is None:
@@ -221,10 +229,13 @@ class Trainer:
             slots[self.rank] = self.optimizer.grad_sumsq()[0].double()
             return slots
 
-        vec = assemble()
-        if self.ddp:
-            dist.all_reduce(vec)
-        vals = vec.tolist()  # the step's only host sync
+        # "clip-grads" (trainer.py:613-614): the gradient's sum of squares is the device half of the clip; its host half (the
+        # coefficient) and "multiply-grads" (trainer.py:601-606) are one scalar folded into the Adam kernel (optim.step)
+        with scope("clip-grads"):
+            vec = assemble()
+            if self.ddp:
+                dist.all_reduce(vec)
+            vals = vec.tolist()  # the step's only host sync
         out = dict(zip(keys, vals[:len(keys)]))
         if vals[len(keys)] != 0:  # some rank lost this update's gradients: nobody steps (trainer.py:564-570)
             self.optimizer.zero_grad()
@@ -264,7 +275,8 @@ class Trainer:
             return out
         self._nonfinite_run = 0
         multiply = self.world / out["sample_size"] if out["sample_size"] > 0 else 0.0
-        out["gnorm"] = self.optimizer.step(multiply=multiply, gnorm=math.sqrt(sumsq[self.rank]) * multiply)
+        with scope("optimizer"):
+            out["gnorm"] = self.optimizer.step(multiply=multiply, gnorm=math.sqrt(sumsq[self.rank]) * multiply)
         self.num_updates += 1
         out["lr"] = self.optimizer.get_lr()
         return out

@@ -15,11 +15,11 @@ from conftest import ROOT, load_pkg
 pytestmark = pytest.mark.gpu
 
 
-def _build(batch=4, dropout=0.0):
+def _build(batch=4, dropout=0.0, model="s2t_w2v2"):
     sys.path.insert(0, ROOT)
     import bench
     load_pkg()
-    args = Namespace(batch=batch, seconds=30.0, lengths="uniform", dtype="bf16", model="s2t_w2v2", dropout=dropout, layerdrop=0.0)
+    args = Namespace(batch=batch, seconds=30.0, lengths="uniform", dtype="bf16", model=model, dropout=dropout, layerdrop=0.0)
     torch.manual_seed(1)
     trainer, task, tasks, ns = bench.build(args, torch.device("cuda", 0))
     return trainer, bench.make_batch(tasks, task, args, 0, torch.device("cuda", 0))
@@ -72,6 +72,47 @@ def test_the_bench_batch_itself_is_bit_reproducible_and_its_loss_is_the_one_benc
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["config"]["batch_per_gpu"] == 32 and d["config"]["loss"] == float(out["loss"]), (d["config"]["loss"], float(out["loss"]))
+
+
+def test_the_chimera_bench_batch_is_bit_reproducible_and_its_loss_is_the_one_bench_prints():
+    """The Chimera leg of the bench line (`extra.chimera`: BASELINE configs[3], B = 32 x <= 30 s, triplet_st_mt_contrastive, dropout
+    0.1) at the size it is timed: the packed triplet path (criterions.py: audio and text pass walk the shared encoder / memory /
+    decoder layers ONCE, > 31 k packed wav2vec2 rows + the text rows) has no other test at this size.  Run to run every gradient bit
+    is equal; the unpaired, padded route (CST_NO_PACK=1: two separate passes over padded batches — different row layout, different
+    dropout sites) lands at the same loss to bf16 rounding with dropout off; and the first update's loss is the one
+    `bench.py --model chimera --steps 1 --warmup 0` prints."""
+    import json
+    import subprocess
+    trainer, sample = _build(batch=32, dropout=0.1, model="chimera")
+    assert sample["net_input"]["src_tokens"].shape[0] == 32 and "src_text" in sample
+    l1, g1 = _loss_and_grads(trainer, sample, overlap=True)
+    l2, g2 = _loss_and_grads(trainer, sample, overlap=True)
+    assert torch.isfinite(g1.float()).all() and float(g1.float().norm()) > 0
+    assert l1 == l2 and torch.equal(g1, g2), "B = 32 Chimera update differs run to run: %r vs %r, %d elements" % (l1, l2, int((g1 != g2).sum()))
+    out = trainer.train_step([sample])
+    assert out is not None and abs(float(out["loss"]) - l1) <= 1e-6 * abs(l1), (out["loss"], l1)
+    for k in ("st_loss", "mt_loss", "contrastive_loss"):
+        assert out[k] == out[k] and out[k] > 0, (k, out[k])
+    del trainer, sample, g1, g2
+    torch.cuda.empty_cache()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", "chimera", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                        "--no-roofline", "--no-extra"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["batch_per_gpu"] == 32 and d["config"]["loss"] == float(out["loss"]), (d["config"]["loss"], float(out["loss"]))
+    assert "Chimera" in d["config"]["workload"]
+    # dropout off (the masks of the two routes are different sites): packed pair route vs two padded passes, the same loss to bf16
+    # rounding of a different row layout
+    trainer, sample = _build(batch=32, dropout=0.0, model="chimera")
+    lp, gp = _loss_and_grads(trainer, sample, overlap=True)
+    os.environ["CST_NO_PACK"] = "1"
+    try:
+        lu, gu = _loss_and_grads(trainer, sample, overlap=True)
+    finally:
+        del os.environ["CST_NO_PACK"]
+    assert abs(lp - lu) <= 2e-3 * abs(lu), "packed %.5f vs padded %.5f" % (lp, lu)
+    rel = float((gp.float() - gu.float()).norm() / gu.float().norm())
+    assert rel < 5e-2, rel  # two bf16 roundings of every activation apart (the bf16-vs-oracle gradient distance is 1.8e-2)
 
 
 def test_full_size_update_properties():
@@ -153,8 +194,9 @@ def _hip_forward_backward(trainer, sample, chimera):
     return float(loss), log, logits.float().cpu(), (memory.float().cpu() if memory is not None else None), grads, stats
 
 
-@pytest.mark.parametrize("model,samples", [("s2t_w2v2", (160000, 96000)), ("chimera", (160000, 96000)), ("s2t_w2v2", (480000, 272000))],
-                         ids=["s2t_w2v2", "chimera", "s2t_w2v2-30s"])
+@pytest.mark.parametrize("model,samples", [("s2t_w2v2", (160000, 96000)), ("chimera", (160000, 96000)), ("s2t_w2v2", (480000, 272000)),
+                                           ("chimera", (480000, 272000))],
+                         ids=["s2t_w2v2", "chimera", "s2t_w2v2-30s", "chimera-30s"])
 def test_full_dimension_fp32_parity_with_oracle(model, samples):
     """fp32 storage: loss <= 1e-4 relative, logits / memory / EVERY parameter gradient <= 1e-3 * max(1, |ref|max)
     (BASELINE north_star: 'logits/grads within 1e-3'), no exemptions.  The random parameters are first moved off the ReLU
@@ -190,8 +232,9 @@ def test_full_dimension_fp32_parity_with_oracle(model, samples):
     assert n > 300 and excused == 0  # every gradient entry within 1e-3, no exemption used
 
 
-@pytest.mark.parametrize("model,samples", [("s2t_w2v2", (160000, 96000)), ("chimera", (160000, 96000)), ("s2t_w2v2", (480000, 272000))],
-                         ids=["s2t_w2v2", "chimera", "s2t_w2v2-30s"])
+@pytest.mark.parametrize("model,samples", [("s2t_w2v2", (160000, 96000)), ("chimera", (160000, 96000)), ("s2t_w2v2", (480000, 272000)),
+                                           ("chimera", (480000, 272000))],
+                         ids=["s2t_w2v2", "chimera", "s2t_w2v2-30s", "chimera-30s"])
 def test_full_dimension_bf16_gap_is_storage_rounding(model, samples):
     """bf16 storage (what bench.py measures).  The 30 s + 17 s case puts the kernels the bench times — the DMA-staged attention
     kernels (bf16 only: 24 key tiles per sequence, packed row offsets) and the persistent 256 x 256 GEMM — under the oracle at the

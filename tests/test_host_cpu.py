@@ -906,3 +906,47 @@ def test_world8_every_route_equals_one_process_bit_for_bit(tmp_path):
         assert torch.equal(st2["state"][key]["exp_avg"], st1["state"][key]["exp_avg"])
         assert torch.equal(st2["state"][key]["exp_avg_sq"], st1["state"][key]["exp_avg_sq"])
     assert fresh.num_updates == 4 and all(torch.equal(a, b) for a, b in zip(fresh.buffers.params, one.buffers.params))
+
+
+def test_roctx_phase_ranges_follow_the_reference_scopes(tmp_path):
+    import subprocess
+    import sys
+    """CST_ROCTX=1: one update emits the reference's record_function scopes (fairseq_cli/train.py:225-227, fairseq_task.py:439-444,
+    trainer.py:601-627) as roctx push / pop pairs, properly nested, in the reference's order; without the variable nothing is
+    loaded and `scope()` is the shared no-op.  (Run in a child process: the switch is read at import.)"""
+    prog = tmp_path / "ranges.py"
+    prog.write_text('''
+import sys, importlib
+from argparse import Namespace
+sys.path.insert(0, %r)
+import torch
+P = importlib.import_module("chimera-st_amd.profiling")
+seen = []
+if P.enabled():
+    class Fake:
+        def roctxRangePushA(self, name): seen.append("+" + name.decode()); return 0
+        def roctxRangePop(self): seen.append("-"); return 0
+    P._lib = Fake()
+sys.path.insert(0, %r)
+import test_host_cpu as T
+tr = T._cpu_trainer(0)
+tr.train_step([{"x": torch.randn(5, 6)}])
+tr.train_step([{"x": torch.randn(5, 6)}])
+print("RANGES " + " ".join(seen))
+print("NULL", P.scope("x") is P.scope("y"))
+''' % (ROOT, os.path.join(ROOT, "tests")))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "CST_ROCTX")}
+    r = subprocess.run([sys.executable, str(prog)], capture_output=True, text=True, timeout=300, env=dict(env, CST_ROCTX="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RANGES")][0].split()[1:]
+    # (_cpu_trainer swaps optimizer.step for plain SGD, so "multiply-grads" — which lives inside the real step — is not in this list)
+    one = lambda n: ["+train_step-%d" % n, "+forward", "-", "+backward", "-", "+reduce-grads", "-", "+clip-grads", "-", "+optimizer", "-", "-"]
+    assert line == one(0) + one(1), line
+    r = subprocess.run([sys.executable, str(prog)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "RANGES" in r.stdout and [l for l in r.stdout.splitlines() if l.startswith("RANGES")][0].split()[1:] == []
+    assert "NULL True" in r.stdout
+    # the real library loads and takes a push / pop (no tracer attached: the calls are no-ops inside roctx)
+    r = subprocess.run([sys.executable, "-c", "import sys, importlib; sys.path.insert(0, %r); P = importlib.import_module('chimera-st_amd.profiling');\n"
+                        "with P.scope('forward'): pass\nprint('ok', P._lib is not None)" % ROOT], capture_output=True, text=True, timeout=300,
+                       env=dict(env, CST_ROCTX="1"))
+    assert r.returncode == 0 and "ok True" in r.stdout, r.stderr[-1500:]
