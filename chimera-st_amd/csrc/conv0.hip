@@ -373,6 +373,192 @@ __global__ __launch_bounds__(256) void conv0_bwd_reg_kernel(const T* dy, const f
   }
 }
 
+// ---- the backward pass with both contractions on the matrix cores (bf16 storage, k = 10, C = 512) -----------------------------
+// The register kernel above is bound by VALU issue: 38 lane operations per output element, 20 of them the two 10-tap contractions
+// (u = sum_j w[c][j] x[s t + j] recomputed, r[j][c] += dz x[s t + j]).  Here both are bf16 MFMAs (v_mfma_f32_16x16x32_bf16, fp32
+// accumulate) and the VALU keeps GroupNorm + GELU' + the dz rounding (14 operations per element, packed two frames per instruction):
+//   u  : M = 16 frames, N = 16 channels, K = 32 taps (10 real: the weight operand is zero beyond).  The fp32 wave enters as hi + lo
+//        bf16 halves (hi = upper 16 bits, lo = bf16(x - hi): x = hi + lo to 2^-17 — two MFMAs), the weights are bf16 as stored.
+//        D: lane (q = l & 15, g = l >> 4) holds channel q of the set, frames 4g .. 4g + 3 of the 16-frame tile.
+//   dz : VALU on those values (the lane owns 4 consecutive channels 4q + e of a 64-channel block: dy arrives as 8-byte loads);
+//        s2 = rstd * sum dz (u - mean) is one packed fma.
+//   r  : v_mfma_f32_16x16x16_bf16, M = 16 "taps" (row 10 is a row of ones: its sum is s1 = sum dz), N = 16 channels, K = 16 frames
+//        (k = 4g + i: exactly the frames u left in the lane — no exchange, no staging).  dz enters rounded to bf16 — the
+//        precision every other weight gradient of the bf16 path has (they are GEMMs over bf16-stored gradients) — the wave again
+//        as hi + lo.  D: lane holds channel q, tap rows 4g .. 4g + 3.
+// (First built with r on v_mfma_f32_16x16x4_f32, exact fp32: correct, and no faster than the register kernel — counters showed
+// VALU-busy + MFMA-busy = 87 % of the kernel's cycles: the fp32-input MFMA runs at the fp32 vector rate and does not overlap the VALU.)
+// Block = 8 waves over 2048 frames, one 64-channel block per wave (no cross-wave sums); 4 waves per SIMD (two blocks per CU).
+// Partials have the layout of the register kernel ([B][blocks][k + 2][C]): the reduce and finish kernels are shared.
+constexpr int C0M_PAD = 96;  // floats behind the staged wave: zeros[32] (operand reads past the last real frame) | ones[16] | zeros[48]
+__global__ __launch_bounds__(512, 4) void conv0_bwd_mfma_kernel(const bf16_t* dy, const float* wav, const bf16_t* w, const bf16_t* gamma,
+                                                                const bf16_t* beta, const float* mean, const float* rstd, float* ws,
+                                                                int64_t S, int64_t L, int stride, const int32_t* blim) {
+  constexpr int KC = 10, C = 512;
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int span_max = (C0R_BWD_TB - 1) * stride + KC;
+  float* const sx = sm;                                   // [span_max + C0M_PAD]: wave | zeros[32] | ones[16] | zeros[48]
+  const int ones_at = span_max + 32, zeros_at = span_max + 48;
+  const int sx_floats = (span_max + C0M_PAD + 3) & ~3;
+  bf16_t* const wl = reinterpret_cast<bf16_t*>(sm + sx_floats);                       // [C][16] taps, zero beyond KC
+  float* const pr = sm + sx_floats + C * 8;                                           // [C][4]: mean, rstd * gamma, beta, rstd
+  const int64_t b = blockIdx.y;
+  const int64_t t0 = (int64_t)blockIdx.x * C0R_BWD_TB;
+  const int64_t Lb = (blim && blim[b] < L) ? blim[b] : L;
+  const int64_t left = Lb - t0;
+  const int nt = left <= 0 ? 0 : (int)(left < C0R_BWD_TB ? left : C0R_BWD_TB);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane & 15, g = lane >> 4;
+  const int cbase = wave * 64;
+  // ---- stage: wave span (zero behind it), weights, per-channel constants ----
+  const int span = nt > 0 ? (nt - 1) * stride + KC : 0;
+  for (int i = tid; i < span_max + C0M_PAD; i += 512)
+    sx[i] = i < span ? wav[b * S + t0 * stride + i] : ((i >= ones_at && i < zeros_at) ? 1.0f : 0.0f);
+  for (int i = tid; i < C * 16; i += 512) {
+    const int c = i >> 4, j = i & 15;
+    wl[i] = j < KC ? w[c * KC + j] : static_cast<bf16_t>(0.0f);
+  }
+  for (int c = tid; c < C; c += 512) {
+    const float rs = rstd[b * C + c];
+    pr[4 * c + 0] = mean[b * C + c];
+    pr[4 * c + 1] = rs * static_cast<float>(gamma[c]);
+    pr[4 * c + 2] = static_cast<float>(beta[c]);
+    pr[4 * c + 3] = rs;
+  }
+  __syncthreads();
+  f32x4 R[4];
+  v2f s2p[4];  // sum dz (u - mean): even / odd frames of the lane's (added in that order at the end)
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    R[e] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    s2p[e] = v2f{0.0f, 0.0f};
+  }
+  const int nsteps = (nt + 15) >> 4;  // 16 frames per step
+  // dy of (frame ts + 4g + i, channels cbase + 4q .. + 3): one 8-byte BUFFER load each — the descriptor ends behind the block's last
+  // real frame, so rows beyond nt (the block's partial last step, the prefetch behind the last step) come back as zeros through the
+  // range check: dz = 0, nothing is added, no clamps and no tail code in the loop.
+  const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + (b * L + t0) * (int64_t)C), (short)0, nt * C * 2, 0x00020000);
+  const int dy_lane = (4 * g * C + cbase + 4 * q) * 2;
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  typedef short s16x4_t __attribute__((ext_vector_type(4)));
+  u32x2_t dn[4];
+  auto load_dy = [&](int st) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      dn[i] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rdy, dy_lane + i * C * 2, st * 16 * C * 2, 0));
+  };
+  // x = hi + lo of two neighbouring values: hi = the upper 16 bits (exact in bf16; one byte permute packs two), lo = bf16(x - hi)
+  auto split2 = [](float x0, float x1) -> uint2 {
+    const unsigned b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
+    const v2f lo = v2f{x0, x1} - v2f{__uint_as_float(b0 & 0xffff0000u), __uint_as_float(b1 & 0xffff0000u)};
+    return uint2{__builtin_amdgcn_perm(b1, b0, 0x07060302u), __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2_t))};
+  };
+  // r operand: tap row m = q: x[s (ts + 4g + i) + m]; row 10 reads the strip of ones, rows 11 .. 15 the strip of zeros
+  const int r_off = q < KC ? (4 * g * stride + q) : (q == KC ? ones_at : zeros_at);
+  const int r_mul = q < KC ? 16 * stride : 0;
+  const int r_inc = q < KC ? stride : 0;
+  // per-lane LDS bases: what depends on e is a compile-time offset from them
+  // (lanes g >= 2 carry taps 16 .. 31 of the u MFMA: their weight operand comes from the strip of zeros)
+  const bf16_t* const wl_lane = g < 2 ? wl + (cbase + 4 * q) * 16 + 8 * g : reinterpret_cast<const bf16_t*>(sx + zeros_at);
+  const float* const pr_lane = pr + 4 * (cbase + 4 * q);
+  load_dy(0);
+  for (int st = 0; st < nsteps; ++st) {
+    u32x2_t dc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dc[i] = dn[i];
+    load_dy(st + 1);  // the next step's rows travel under this step's arithmetic
+    // u operand: frame row q of the tile, taps 8 (g & 1) .. + 7;  r operand: tap row q over the lane's frames 4g .. 4g + 3
+    u32x4 hw, lw;
+    u32x2_t rh, rl;
+    {
+      const float* xs = sx + (st * 16 + q) * stride + 8 * (g & 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint2 hl = split2(xs[2 * j], xs[2 * j + 1]);
+        hw[j] = hl.x;
+        lw[j] = hl.y;
+      }
+      const float* xr = sx + r_off + st * r_mul;
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        const uint2 hl = split2(xr[2 * jp * r_inc], xr[(2 * jp + 1) * r_inc]);
+        rh[jp] = hl.x;
+        rl[jp] = hl.y;
+      }
+    }
+    const bf16x8 ah = __builtin_bit_cast(bf16x8, hw), al = __builtin_bit_cast(bf16x8, lw);
+    const s16x4_t rah = __builtin_bit_cast(s16x4_t, rh), ral = __builtin_bit_cast(s16x4_t, rl);
+#pragma unroll
+    for (int ep = 0; ep < 4; ep += 2) {
+      f32x4 u[2];  // the four MFMAs of two channel sets first: the VALU below meets finished results
+#pragma unroll
+      for (int eo = 0; eo < 2; ++eo) {
+        const bf16x8 bw = *reinterpret_cast<const bf16x8*>(wl_lane + (ep + eo) * 16);
+        u[eo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bw, f32x4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+        u[eo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bw, u[eo], 0, 0, 0);
+      }
+#pragma unroll
+      for (int eo = 0; eo < 2; ++eo) {
+        const int e = ep + eo;
+        const f32x4 prm = *reinterpret_cast<const f32x4*>(pr_lane + 4 * e);
+        const v2f mu2 = {prm[0], prm[0]}, rg2 = {prm[1], prm[1]}, be2 = {prm[2], prm[2]};
+        // the lane's two frame pairs walk the polynomial side by side (a dependent packed fma right behind its producer waits)
+        v2f d[2], t[2], xc[2], x2[2], p[2];
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip) {
+          const unsigned w0 = e < 2 ? dc[2 * ip][0] : dc[2 * ip][1], w1 = e < 2 ? dc[2 * ip + 1][0] : dc[2 * ip + 1][1];
+          d[ip] = v2f{__uint_as_float((e & 1) ? (w0 & 0xffff0000u) : (w0 << 16)), __uint_as_float((e & 1) ? (w1 & 0xffff0000u) : (w1 << 16))};
+          t[ip] = v2f{u[eo][2 * ip], u[eo][2 * ip + 1]} - mu2;
+        }
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip) {
+          const v2f a = __builtin_elementwise_fma(t[ip], rg2, be2);
+          xc[ip] = v2f{__builtin_amdgcn_fmed3f(a[0], -4.0f, 4.0f), __builtin_amdgcn_fmed3f(a[1], -4.0f, 4.0f)};
+        }
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip) x2[ip] = xc[ip] * xc[ip];
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip)
+          p[ip] = __builtin_elementwise_fma(v2f{-1.5577683143419563e-08f, -1.5577683143419563e-08f}, x2[ip], v2f{1.1633505891950335e-06f, 1.1633505891950335e-06f});
+        constexpr float PC[6] = {-3.7250658351695165e-05f, 0.0006728997686877847f, -0.0075911665335297585f, 0.0555923730134964f,
+                                 -0.26155415177345276f, 0.7965189218521118f};  // (dgelu_poly_f, cst_common.h)
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+          for (int ip = 0; ip < 2; ++ip) p[ip] = __builtin_elementwise_fma(p[ip], x2[ip], v2f{PC[k], PC[k]});
+        u32x2_t zb;
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip) {
+          const v2f gp = __builtin_elementwise_fma(p[ip], xc[ip], v2f{0.5f, 0.5f});
+          const v2f z = d[ip] * gp;
+          s2p[e] = __builtin_elementwise_fma(z, t[ip], s2p[e]);
+          zb[ip] = __builtin_bit_cast(unsigned, __builtin_convertvector(z, bf16x2_t));
+        }
+        // r: K = 16 frames = this tile (v_mfma_f32_16x16x16_bf16: k = 4g + i is exactly the frame layout u left in the lane)
+        const s16x4_t bz = __builtin_bit_cast(s16x4_t, zb);
+        R[e] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(rah, bz, R[e], 0, 0, 0);
+        R[e] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ral, bz, R[e], 0, 0, 0);
+      }
+    }
+  }
+  // ---- s2 over the four frame groups of the wave (lane exchange, g order); every wave owns its 64 channels: no cross-wave sums ----
+  float* const o = ws + (b * gridDim.x + blockIdx.x) * (KC + 2) * (int64_t)C;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = cbase + 4 * q + e;
+    const float v = s2p[e][0] + s2p[e][1];
+    const float v1 = __shfl(v, q + 16, 64), v2 = __shfl(v, q + 32, 64), v3 = __shfl(v, q + 48, 64);
+    if (g == 0) o[C + c] = (((v + v1) + v2) + v3) * pr[4 * c + 3];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int tap = 4 * g + rr;                       // rows 0 .. 9: r[tap]; row 10: s1
+      if (tap <= KC) o[(tap == KC ? 0 : 2 + tap) * C + c] = R[e][rr];
+    }
+  }
+}
+
 // fixed-order sum of an utterance's block partials: part [B][nblk][rows][C] -> acc [B][rows][C]; grid (B, rows), one thread per channel
 __global__ void conv0_bwd_reduce_kernel(const float* part, float* acc, int nblk, int rows, int C) {
   const int64_t b = blockIdx.x;
@@ -505,7 +691,14 @@ extern "C" int cst_conv0_gn_gelu_bwd(const void* dy, const float* wav, const voi
     size_t lds_r = sizeof(float) * ((size_t)C0R_BWD_TB * stride + k);
     if (lds_r < sizeof(float) * 256 * 4) lds_r = sizeof(float) * 256 * 4;
     dim3 gr((unsigned)cst_ceil_div(L, C0R_BWD_TB), (unsigned)B);
-    if (dtype == CST_BF16) {
+    static const bool no_mfma = getenv("CST_CONV0_NO_MFMA") != nullptr;  // (A/B switch: the register kernel)
+    if (dtype == CST_BF16 && C == 512 && !no_mfma) {
+      const int span_max = (C0R_BWD_TB - 1) * stride + 10;
+      const size_t lds_m = sizeof(float) * (size_t)(((span_max + C0M_PAD + 3) & ~3) + 512 * 8 + 512 * 4);
+      hipLaunchKernelGGL(conv0_bwd_mfma_kernel, gr, dim3(512), lds_m, s, (const bf16_t*)dy, wav, (const bf16_t*)w, (const bf16_t*)gamma, (const bf16_t*)beta, mean, rstd, workspace, S, L, stride, frame_limit);
+      hipLaunchKernelGGL(conv0_bwd_reduce_kernel, rg, dim3(256), 0, s, workspace, acc, nblk, k + 2, (int)C);
+      hipLaunchKernelGGL(conv0_bwd_finish_kernel<bf16_t>, fg, dim3(FB * FC), 0, s, acc, gram, (const bf16_t*)w, (const bf16_t*)gamma, mean, rstd, dw, dgamma, dbeta, B, C, L, k);
+    } else if (dtype == CST_BF16) {
       hipLaunchKernelGGL((conv0_bwd_reg_kernel<bf16_t, 10>), gr, dim3(256), lds_r, s, (const bf16_t*)dy, wav, (const bf16_t*)w, (const bf16_t*)gamma, (const bf16_t*)beta, mean, rstd, workspace, S, L, (int)C, stride, frame_limit);
       hipLaunchKernelGGL(conv0_bwd_reduce_kernel, rg, dim3(256), 0, s, workspace, acc, nblk, k + 2, (int)C);
       hipLaunchKernelGGL(conv0_bwd_finish_kernel<bf16_t>, fg, dim3(FB * FC), 0, s, acc, gram, (const bf16_t*)w, (const bf16_t*)gamma, mean, rstd, dw, dgamma, dbeta, B, C, L, k);
