@@ -103,7 +103,10 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wav
 template <bool AK, bool BKM, int MODE>
 __global__ __launch_bounds__(NTHREADS) void gemm8p_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // the wave number as a SCALAR: the DMA destinations (M0 values) derived from it are then scalar arithmetic instead of six VGPRs kept
+  // across the K loop and a v_readfirstlane per DMA
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int lrow = lane & 31, hi = lane >> 5;
   const int ntiles = p.tiles_m * p.tiles_n;

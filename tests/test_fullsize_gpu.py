@@ -107,9 +107,14 @@ def test_the_chimera_bench_batch_is_bit_reproducible_and_its_loss_is_the_one_ben
     lp, gp = _loss_and_grads(trainer, sample, overlap=True)
     os.environ["CST_NO_PACK"] = "1"
     try:
-        lu, gu = _loss_and_grads(trainer, sample, overlap=True)
+        # the unpaired route sends two gradients to every shared parameter: which parameters may take the deferred-reduction route
+        # is a property of the route (trainer._defer_ok re-reads the switches and re-marks the shared ones); launch-each here
+        trainer.optimizer.defer_reductions = trainer._defer_ok()
+        lu, gu = _loss_and_grads(trainer, sample, overlap=False)
     finally:
         del os.environ["CST_NO_PACK"]
+        trainer.optimizer.defer_reductions = trainer._defer_ok()
+    assert torch.isfinite(gu.float()).all()
     assert abs(lp - lu) <= 2e-3 * abs(lu), "packed %.5f vs padded %.5f" % (lp, lu)
     rel = float((gp.float() - gu.float()).norm() / gu.float().norm())
     assert rel < 5e-2, rel  # two bf16 roundings of every activation apart (the bf16-vs-oracle gradient distance is 1.8e-2)
