@@ -253,10 +253,12 @@ __device__ __forceinline__ void store4(float* p, const float (&v)[4]) {
 }
 __device__ __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
   using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
   bf16x4 r;
 #pragma unroll
   for (int e = 0; e < 4; ++e) r[e] = static_cast<__bf16>(v[e]);
-  *reinterpret_cast<bf16x4*>(p) = r;
+  // (layer 0's output is 2-3 GB per batch, written once and far larger than the caches: streaming store)
+  __builtin_nontemporal_store(__builtin_bit_cast(u32x2_t, r), reinterpret_cast<u32x2_t*>(p));
 }
 
 constexpr int C0R_TB = 128;  // frames per block (forward)
@@ -390,6 +392,7 @@ __global__ __launch_bounds__(256) void conv0_bwd_reg_kernel(const T* dy, const f
 // VALU-busy + MFMA-busy = 87 % of the kernel's cycles: the fp32-input MFMA runs at the fp32 vector rate and does not overlap the VALU.)
 // Block = 8 waves over 2048 frames, one 64-channel block per wave (no cross-wave sums); 4 waves per SIMD (two blocks per CU).
 // Partials have the layout of the register kernel ([B][blocks][k + 2][C]): the reduce and finish kernels are shared.
+constexpr int CONV0_DY_AUX = 2;  // nt: the gradient is read once (2-3 GB per batch)
 constexpr int C0M_PAD = 96;  // floats behind the staged wave: zeros[32] (operand reads past the last real frame) | ones[16] | zeros[48]
 __global__ __launch_bounds__(512, 4) void conv0_bwd_mfma_kernel(const bf16_t* dy, const float* wav, const bf16_t* w, const bf16_t* gamma,
                                                                 const bf16_t* beta, const float* mean, const float* rstd, float* ws,
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(512, 4) void conv0_bwd_mfma_kernel(const bf16_t* dy
   auto load_dy = [&](int st) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      dn[i] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rdy, dy_lane + i * C * 2, st * 16 * C * 2, 0));
+      dn[i] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rdy, dy_lane + i * C * 2, st * 16 * C * 2, CONV0_DY_AUX));
   };
   // x = hi + lo of two neighbouring values: hi = the upper 16 bits (exact in bf16; one byte permute packs two), lo = bf16(x - hi)
   auto split2 = [](float x0, float x1) -> uint2 {

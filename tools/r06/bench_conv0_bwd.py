@@ -17,6 +17,17 @@ for i, s in enumerate(audio):
 w = (0.5 * torch.randn(C, kk, generator=g)).to(dt).cuda()
 ga, be = (1 + 0.1 * torch.randn(C, generator=g)).to(dt).cuda(), (0.1 * torch.randn(C, generator=g)).to(dt).cuda()
 y, mean, rstd, gram = K.conv0_fwd(wav, w, ga, be, kk, st)
+lim0 = torch.tensor([(s_ - kk) // st + 1 for s_ in audio], dtype=torch.int32, device="cuda")
+for _ in range(3):
+    K.conv0_fwd(wav, w, ga, be, kk, st, frame_limit=lim0)
+torch.cuda.synchronize()
+f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+f0.record()
+for _ in range(10):
+    K.conv0_fwd(wav, w, ga, be, kk, st, frame_limit=lim0)
+f1.record()
+torch.cuda.synchronize()
+print("forward, frame limits: %.3f ms" % (f0.elapsed_time(f1) / 10))
 dy = torch.randn(B, L, C, generator=torch.Generator(device="cuda").manual_seed(5), device="cuda").to(dt)
 lim = torch.tensor([(s - kk) // st + 1 for s in audio], dtype=torch.int32, device="cuda")
 for i in range(B):
