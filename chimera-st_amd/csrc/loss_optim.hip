@@ -152,14 +152,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* master, float* m, floa
     const int64_t n4 = n / 4;
     for (int64_t q = tid0; q < n4; q += nth) {
       const int64_t i = 4 * q;
-      // (every array is touched once per update and is far larger than the caches: streaming loads / stores)
-      f32x4 pm = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(master + i)), mm = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(m + i)),
-            vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v + i));
+      f32x4 pm = *reinterpret_cast<const f32x4*>(master + i), mm = *reinterpret_cast<const f32x4*>(m + i), vv = *reinterpret_cast<const f32x4*>(v + i);
       float g[4];
       if constexpr (sizeof(TG) == 2) {
-        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-        const u32x2_t raw2 = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(grad + i));
-        const uint2 raw = {raw2[0], raw2[1]};
+        const uint2 raw = *reinterpret_cast<const uint2*>(grad + i);
         g[0] = __uint_as_float(raw.x << 16); g[1] = __uint_as_float(raw.x & 0xffff0000u);
         g[2] = __uint_as_float(raw.y << 16); g[3] = __uint_as_float(raw.y & 0xffff0000u);
       } else {
@@ -172,9 +168,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* master, float* m, floa
         adam_one(g[e] * gs, mi, vi, pp, lr, beta1, beta2, eps, wd, step_size);
         mm[e] = mi; vv[e] = vi; pm[e] = pp;
       }
-      __builtin_nontemporal_store(mm, reinterpret_cast<f32x4*>(m + i));
-      __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(v + i));
-      __builtin_nontemporal_store(pm, reinterpret_cast<f32x4*>(master + i));
+      *reinterpret_cast<f32x4*>(m + i) = mm;
+      *reinterpret_cast<f32x4*>(v + i) = vv;
+      *reinterpret_cast<f32x4*>(master + i) = pm;
       if constexpr (sizeof(TP) == 2) {
         typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
         bf16x4_t o;

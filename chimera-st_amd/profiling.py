@@ -23,7 +23,8 @@ def _load():
     global _lib
     if _lib is None:
         last = None
-        for name in ("libroctx64.so", "/opt/rocm/lib/libroctx64.so", "librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so"):
+        # rocprofv3 (rocprofiler-sdk) intercepts ITS roctx library; the legacy libroctx64 (roctracer) is the fallback for older tools
+        for name in ("librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so", "libroctx64.so", "/opt/rocm/lib/libroctx64.so"):
             try:
                 _lib = ctypes.CDLL(name)
                 break

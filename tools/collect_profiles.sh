@@ -12,7 +12,7 @@ rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum GRBM_GUI_ACTIVE -d $O/pmc_hb
 rocprofv3 --kernel-trace --stats -d $O/dec_trace -o trace -- python3 $R/bench.py --mode decode > $O/dec_trace.log 2>&1
 # phase ranges (round 6): the reference's record_function scopes as roctx markers, CSV so that the per-range statistics can be read as text
 export CST_ROCTX=1
-rocprofv3 --marker-trace --stats --output-format csv -d $O/roctx -o roctx -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-extra > $O/roctx.log 2>&1
+rocprofv3 --marker-trace --kernel-trace --stats --output-format csv -d $O/roctx -o roctx -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-extra > $O/roctx.log 2>&1
 unset CST_ROCTX
 (for f in $(find $O/roctx -name '*marker*stats*.csv' -o -name '*marker_api_stats*.csv' | head -2); do echo "== $f"; cat $f; done; for f in $(find $O/roctx -name '*marker*trace*.csv' | head -1); do echo "== $f (first 40 rows)"; head -40 $f; done) > $O/${TAG}_roctx_phases.txt 2>&1
 rm -rf $O/roctx
@@ -50,5 +50,4 @@ tools/probes/mfma_rate.bin 4000 > $O/${TAG}_mfma_shape_probe_raw.txt 2>&1
 python tools/bench_conv_layout.py > $O/${TAG}_conv_layout.txt 2>/dev/null
 python tools/r06/epi_decompose.py 31760 > $O/${TAG}_epilogue_decomposition.txt 2>/dev/null
 (python tools/r06/bench_conv0_bwd.py; CST_CONV0_NO_MFMA=1 python tools/r06/bench_conv0_bwd.py) > $O/${TAG}_conv0_bwd_mfma_vs_register.txt 2>/dev/null
-python tools/r06/bench_adam.py > $O/${TAG}_adam.txt 2>/dev/null
 ls -la $O; du -sh $O
