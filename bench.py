@@ -292,6 +292,11 @@ def measure_train(args, device, rank, lib, traffic=True):
             roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                     "traffic": None, "launches": r["launches"], "avg_launch_ms": r["ms"] / max(r["launches"], 1)}
         roof["per_class_ms"] = {k: round(v["ms"], 3) for k, v in table.items() if v["launches"]}
+        # the HBM-bound launch classes against 8 TB/s: ALGORITHMIC bytes of every launch of the class (each operand once, as its entry
+        # point states them to the profiling table) over the class's time in this update
+        roof["hbm_bound_classes"] = {k: {"ms": round(v["ms"], 3), "achieved_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                                         "frac": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / 8000.0, 4), "launches": v["launches"]}
+                                     for k, v in table.items() if k in ("layernorm", "elementwise", "optim", "loss") and v["launches"] and v["ms"] > 0}
         if r["flops"] > 0:
             a_ms = table["attn_fwd"]["ms"] + table["attn_bwd"]["ms"]
             # QK^T + PV of every attention of the update (forward + 2x backward, algorithmic) over the attention kernels' time

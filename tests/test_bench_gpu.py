@@ -40,6 +40,7 @@ def test_bench_line_contract():
         # `frac` is the ALGORITHMIC figure; the executed one (tile rounding included) can only be larger
         assert r["frac_algorithmic"] == r["frac"] and r["frac_executed"] >= r["frac"] * 0.999 and r["algorithmic_tflop_per_update"]["gemm"] > 0
         assert 0 < r["attention"]["frac"] < 1 and 0 < r["step_mfu_algorithmic"] < 1
+        assert 0 < r["hbm_bound_classes"]["layernorm"]["frac"] < 1 and r["hbm_bound_classes"]["optim"]["achieved_GBps"] > 0
     assert set(d["config"]["parity"]) == {"fp32", "bf16"}
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == "utterances/s" and c["sample"]
