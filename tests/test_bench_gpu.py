@@ -112,7 +112,7 @@ def test_bench_eight_ranks_started_plainly_share_the_gpu_over_gloo():
     rank 0 alone prints the line with n_gpus = 8.  No scaling number is read off this (eight processes time-slice one GPU)."""
     e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
     e["CST_DIST_BACKEND"] = "gloo"
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--batch", "1",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--batch", "1",
                         "--seconds", "2"], capture_output=True, text=True, timeout=1500, env=e, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
