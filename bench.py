@@ -508,6 +508,8 @@ def main():
         # (fairseq/distributed_utils.py:286-303).  Under torchrun (WORLD_SIZE set) nothing changes.
         sys.exit(dist_mod.launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
     rank, world = dist_mod.distributed_init()
+    # intra-op CPU threads: this rank's share of what the container may run (cgroup quota), not the machine's thread count
+    importlib.import_module("chimera-st_amd.hostcfg").limit_host_threads(int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     if os.environ.get("CST_BENCH_FAIL_RANK") == str(rank):  # (tests: a rank that dies must take the self-launched job down with it)
         sys.exit(7)
     assert world == args.gpus or (world == 1 and args.gpus == 1), "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)

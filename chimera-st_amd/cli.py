@@ -18,6 +18,7 @@ import torch
 
 from . import checkpoint_utils, criterions, registry, s2t_transformer, tasks, w2v2_transformer, w2v2_transformer_interlingua  # noqa: F401
 from .distributed import distributed_init, launch_ranks, needs_self_launch
+from .hostcfg import limit_host_threads
 from .trainer import Trainer
 
 
@@ -94,6 +95,7 @@ def train_main(argv=None):
                 raise SystemExit(code)
             return None
     rank, world = distributed_init()
+    limit_host_threads(int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     device = torch.device("cuda", torch.cuda.current_device())
     torch.manual_seed(args.seed)
     task = registry.setup_task(args)
@@ -241,6 +243,7 @@ def generate_main(argv=None):
     p.add_argument("--seed", type=int, default=1)
     p.add_argument("--quiet", action="store_true")
     args, ignored = p.parse_known_args(argv)
+    limit_host_threads()
     overrides = {"data": args.data, "config_yaml": args.config_yaml, "max_source_positions": args.max_source_positions,
                  "max_target_positions": args.max_target_positions}
     models, margs, task = checkpoint_utils.load_model_ensemble_and_task(args.path.split(":")[:1], arg_overrides=overrides)

@@ -14,6 +14,7 @@ import torch.distributed as dist
 from .distributed import DistributedFairseqModel, all_reduce_stats
 from . import rng
 from .profiling import scope
+from .hostcfg import limit_host_threads
 from .optim import ALIGN, FlatParamBuffers, FusedAdam, qkv_groups
 
 
@@ -34,6 +35,7 @@ class Trainer:
     def __init__(self, args, task, model, criterion, device="cuda"):
         self.args, self.task, self.criterion = args, task, criterion
         self.device = torch.device(device)
+        limit_host_threads(int(os.environ.get("LOCAL_WORLD_SIZE", dist.get_world_size() if dist.is_initialized() else 1)))  # (hostcfg.py)
         dtype = torch.bfloat16 if getattr(args, "bf16", False) else torch.float32
         if getattr(args, "fp16", False):
             raise NotImplementedError("--fp16: this build computes in bf16 (--bf16) or fp32; gfx950 MFMA rates are equal and "

@@ -18,6 +18,9 @@ os.environ.setdefault("CST_DEFER_POISON", "1")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the suite builds full-size models and runs the oracle on the CPU: keep torch's intra-op pool inside the container's CPU quota
+    # (hostcfg.py — on a 256-thread GPU box with a 16-CPU quota the default pool gets the process throttled)
+    importlib.import_module("chimera-st_amd.hostcfg").limit_host_threads()
 
 
 def load_golden(name):

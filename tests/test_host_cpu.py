@@ -950,3 +950,38 @@ print("NULL", P.scope("x") is P.scope("y"))
                         "with P.scope('forward'): pass\nprint('ok', P._lib is not None)" % ROOT], capture_output=True, text=True, timeout=300,
                        env=dict(env, CST_ROCTX="1"))
     assert r.returncode == 0 and "ok True" in r.stdout, r.stderr[-1500:]
+
+
+def test_host_thread_budget_follows_the_cgroup_quota(tmp_path, monkeypatch):
+    """hostcfg: torch's intra-op pool is cut to what the container may run (cgroup v2 cpu.max / v1 cfs quota, inside the affinity
+    mask), shared between the ranks of a node, never raised; CST_HOST_THREADS overrides (0 = hands off)."""
+    import importlib
+    import os
+    import torch
+    H = importlib.import_module("chimera-st_amd.hostcfg")
+    aff = len(os.sched_getaffinity(0))
+    v2 = tmp_path / "v2"; v2.mkdir()
+    (v2 / "cpu.max").write_text("250000 100000\n")
+    assert H.usable_cpus(str(v2)) == min(aff, 3)
+    (v2 / "cpu.max").write_text("max 100000\n")
+    assert H.usable_cpus(str(v2)) == aff
+    v1 = tmp_path / "v1"; (v1 / "cpu").mkdir(parents=True)
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("150000\n"); (v1 / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    assert H.usable_cpus(str(v1)) == min(aff, 2)
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("-1\n")
+    assert H.usable_cpus(str(v1)) == aff and H.usable_cpus(str(tmp_path / "none")) == aff
+    before = torch.get_num_threads()
+    try:
+        monkeypatch.delenv("CST_HOST_THREADS", raising=False)
+        monkeypatch.setattr(H, "usable_cpus", lambda root="/sys/fs/cgroup": 4)
+        torch.set_num_threads(max(before, 2))
+        assert H.limit_host_threads(2) == 2 and torch.get_num_threads() == 2     # 4 usable CPUs, two ranks on the node
+        assert H.limit_host_threads(1) == 2                                        # never raised
+        assert H.limit_host_threads(64) == 1
+        monkeypatch.setenv("CST_HOST_THREADS", "0")
+        torch.set_num_threads(3)
+        assert H.limit_host_threads(64) == 3                                       # hands off
+        monkeypatch.setenv("CST_HOST_THREADS", "2")
+        assert H.limit_host_threads() == 2
+    finally:
+        torch.set_num_threads(before)
